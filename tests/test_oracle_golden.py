@@ -1,0 +1,148 @@
+"""Pins the oracle (oracle/oracle_np.py) against the golden vectors produced by the real reference
+(tests/golden/make_golden.py).  CPU only."""
+import numpy as np
+import pytest
+
+from oracle import oracle_np as onp
+
+S = 18
+F64_RTOL = 1e-12   # bit-exact on the generating machine; allow libm/SIMD log2 ulp differences elsewhere
+
+
+def _close64(a, b):
+    np.testing.assert_allclose(a, b, rtol=F64_RTOL, atol=1e-15)
+
+
+def _check_single(g, x, prefix_n=""):
+    # counts: bit-exact integers
+    assert np.array_equal(onp.expected_s1(x, S), g[prefix_n + "s1_counts"])
+    assert onp.expected_s1(x, S).dtype == g[prefix_n + "s1_counts"].dtype == np.int64
+    assert np.array_equal(onp.expected_s2(x, S), g[prefix_n + "s2_counts"])
+    # exp_freq: bit-exact float32
+    q1 = onp.normalise(g[prefix_n + "s1_counts"])
+    q2 = onp.normalise(g[prefix_n + "s2_counts"])
+    assert q1.dtype == np.float32 and np.array_equal(q1, g[prefix_n + "s1_exp"])
+    assert np.array_equal(q2, g[prefix_n + "s2_exp"])
+    # scores
+    s1 = onp.score_s1(x, q1, S)
+    _close64(s1, g[prefix_n + "s1_f64"])
+    np.testing.assert_allclose(s1.astype(np.float32), g[prefix_n + "s1_f32"], rtol=2e-7, atol=0)
+    s2 = onp.score_s2(x, q2, S)
+    _close64(s2, g[prefix_n + "s2_f64"])
+    np.testing.assert_allclose(s2.astype(np.float32), g[prefix_n + "s2_f32"], rtol=2e-7, atol=1e-12)
+    return s1, s2
+
+
+def test_real_slice_s1_s2(golden_real):
+    g = golden_real
+    s1, s2 = _check_single(g, g["x"])
+    # on the generating numpy these are bit-identical; record that as information, not as a gate
+    print("S1 bit-exact:", np.array_equal(s1, g["s1_f64"]), " S2 bit-exact:", np.array_equal(s2, g["s2_f64"]))
+
+
+def test_real_slice_s3(golden_real):
+    g = golden_real
+    x = g["x"]
+    c3 = onp.expected_s3(x, S)
+    assert c3.dtype == np.int32 and np.array_equal(c3, g["s3_counts"])
+    q3 = onp.normalise(c3)
+    assert np.array_equal(q3, g["s3_exp"])
+    # reference S3 is float32 with order-dependent accumulation: sequential restatement is bit-exact,
+    # float64 closed form within 1e-4 rel / 5e-6 abs
+    seq = onp.score_s3_f32_sequential(x[:64], q3, S)
+    assert np.array_equal(seq, g["s3_f32"][:64])
+    f64 = onp.score_s3_f64(x, q3, S)
+    np.testing.assert_allclose(f64, g["s3_f32"], rtol=1e-4, atol=5e-6)
+
+
+def test_real_slice_text(golden_real):
+    g = golden_real
+    R = g["x"].shape[0]
+    start0 = int(g["start0"])
+    loc = [("chr1", start0 + 200 * r, start0 + 200 * r + 200) for r in range(R)]
+    txt = onp.format_scores(loc, g["s1_f32"]).encode()
+    assert txt == g["s1_text"].tobytes()
+    assert int(g["count_rows"]) == R
+
+
+def test_synth833(golden_synth):
+    g = golden_synth
+    assert g["x"].shape == (512, 833)
+    _check_single(g, g["x"])
+
+
+def test_s3_small(golden_s3):
+    g = golden_s3
+    x = g["x"]
+    c3 = onp.expected_s3(x, S)
+    assert np.array_equal(c3, g["s3_counts"])
+    q3 = onp.normalise(c3)
+    assert np.array_equal(q3, g["s3_exp"])
+    seq = onp.score_s3_f32_sequential(x[:16], q3, S)
+    assert np.array_equal(seq, g["s3_f32"][:16])
+    np.testing.assert_allclose(onp.score_s3_f64(x, q3, S), g["s3_f32"], rtol=1e-4, atol=5e-6)
+
+
+@pytest.mark.parametrize("sal", [1, 2])
+def test_paired(golden_pair, sal):
+    g = golden_pair
+    xa, xb = g["xa"], g["xb"]
+    comb = np.concatenate([xa, xb], axis=1)
+    p = "s%d_" % sal
+    cnt = (onp.expected_s1 if sal == 1 else onp.expected_s2)(comb, S)
+    assert np.array_equal(cnt, g[p + "counts"])
+    q = onp.normalise(cnt)
+    assert np.array_equal(q, g[p + "exp"])
+    score = onp.score_s1 if sal == 1 else onp.score_s2
+    a = score(xa, q, S).astype(np.float32)
+    b = score(xb, q, S).astype(np.float32)
+    np.testing.assert_allclose(a, g[p + "a"], rtol=2e-7, atol=1e-12)
+    np.testing.assert_allclose(b, g[p + "b"], rtol=2e-7, atol=1e-12)
+    delta, _ = onp.pair_finish(g[p + "a"], g[p + "b"])
+    assert np.array_equal(delta, g[p + "delta"])
+    # seeded null: argsort(rand) shuffle restated exactly (helpers.py:183-194, groupSize == -1)
+    sh = onp.shuffle_rows(comb, g[p + "rand"])
+    na_x, nb_x = sh[:, :xa.shape[1]], sh[:, xa.shape[1]:]
+    if sal == 1:
+        na = onp.score_s1(na_x, q, S).astype(np.float32)
+        nb = onp.score_s1(nb_x, q, S).astype(np.float32)
+    else:  # quirk Q9: S2 keeps the ORIGINAL group's permutation count for the shuffled halves
+        na = onp.score_s2(na_x, q, S, perms=xa.shape[1] * (xa.shape[1] - 1)).astype(np.float32)
+        nb = onp.score_s2(nb_x, q, S, perms=xb.shape[1] * (xb.shape[1] - 1)).astype(np.float32)
+    np.testing.assert_allclose(na, g[p + "na"], rtol=2e-7, atol=1e-12)
+    np.testing.assert_allclose(nb, g[p + "nb"], rtol=2e-7, atol=1e-12)
+    _, dist = onp.pair_finish(g[p + "na"], g[p + "nb"])
+    assert np.array_equal(dist, g[p + "null_dist"])
+    assert np.array_equal(onp.quiescent_mask(xa, xb, int(g["qstate"])), g[p + "quiescent"])
+    assert g[p + "quiescent"].any() and not g[p + "quiescent"].all()
+
+
+def test_edge_cases(golden_edge):
+    g = golden_edge
+    # q == 0 state: masked to 0 (scores.py:550)
+    assert np.array_equal(onp.expected_s1(g["q0_x"], S), g["q0_counts"])
+    q0 = onp.normalise(g["q0_counts"])
+    assert np.array_equal(q0, g["q0_exp"]) and q0[3] == 0
+    probe = onp.score_s1(g["q0_probe"], q0, S)
+    _close64(probe, g["q0_probe_f64"])
+    assert probe[0, 3] == 0.0 and (g["q0_probe"][0] == 3).sum() == 3
+    assert np.array_equal(onp.expected_s2(g["q0_x"], S), g["q0_s2_counts"])
+    _close64(onp.score_s2(g["q0_x"], g["q0_s2_exp"], S), g["q0_s2_f64"])
+    # N = 2
+    x2 = g["n2_x"]
+    assert np.array_equal(onp.expected_s1(x2, S), g["n2_s1_counts"])
+    assert np.array_equal(onp.expected_s2(x2, S), g["n2_s2_counts"])
+    assert np.array_equal(onp.expected_s3(x2, S), g["n2_s3_counts"])
+    _close64(onp.score_s1(x2, g["n2_s1_exp"], S), g["n2_s1_f64"])
+    _close64(onp.score_s2(x2, g["n2_s2_exp"], S), g["n2_s2_f64"])
+    assert np.array_equal(onp.score_s3_f32_sequential(x2, g["n2_s3_exp"], S), g["n2_s3_f32"])
+    # every state present
+    _close64(onp.score_s1(g["all_x"], g["all_exp"], S), g["all_f64"])
+    # helpers
+    assert int(g["nonl_rows"]) == 9 and int(g["gz_rows"]) == 10
+    assert np.array_equal(np.array(onp.split_rows(1246253, 8)), g["split_rows_1246253_8"])
+    assert np.array_equal(np.array(onp.split_rows(7, 3)), g["split_rows_7_3"])
+    # text formatting incl. '-0.00000'
+    txt = onp.format_scores([("chrX", 200, 400)], g["fmt_vals"]).encode()
+    assert txt == g["fmt_text"].tobytes()
+    assert b"-0.00000" in txt
