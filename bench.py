@@ -1,0 +1,213 @@
+#!/usr/bin/env python3
+"""
+bench.py -- S1 scoring throughput of the MI355X engine on the BASELINE.json workload.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = one whole S1 job over this rank's shard of bins, inputs resident in HBM:
+    K1 per-bin histogram + state counts  ->  (N > 1: one RCCL all-reduce of the int64[18] count vector)
+    -> normalise to exp_freq (float32)   ->  S1 score table + score pass -> float32 [bins, 18] scores.
+Workload at every N: `--bins` (15,000,000 = whole-genome scale) synthetic bins x 833 biosamples x 18 states PER GPU
+(weak scaling: a GPU always holds a genome-sized contiguous bin range; the global matrix is N of them, partitioned
+by the reference's splitRows rule, helpers.py:116-118).  Synthetic states are i.i.d. with the empirical chr1 state
+frequencies, generated on device per fixed global chunk seed.
+
+Prints ONE JSON line on rank 0 (contract in the task statement), with `roofline` for the dominant kernel
+(k_bin_hist, HBM-bound, 833 algorithmic bytes per bin) and `cpu_baseline` (the per-bin numpy loop of
+oracle/rowloop_baseline.py on the host cores, N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+FREQS = np.array([.00570, .00293, .00430, .00212, .03260, .10464, .00154, .00057, .01001, .00416, .01554, .00618,
+                  .02498, .00262, .00140, .01412, .05563, .71097])
+CHUNK_BINS = 1 << 20
+SUB_BINS = 1 << 17
+HBM_PEAK_GBPS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def cpu_baseline(n_biosamples, n_states, target_seconds=15.0):
+    """Per-bin numpy loop (the reference's `-l` S1 loop shape) on all host cores, bounded sample.  Runs BEFORE the
+    process touches the GPU (it forks workers)."""
+    from oracle import rowloop_baseline as rb
+    from oracle import oracle_np as onp
+    cores = len(os.sched_getaffinity(0))
+    rng = np.random.default_rng(1234)
+    p = FREQS[:n_states] / FREQS[:n_states].sum()
+    probe = rng.choice(n_states, size=(2000, n_biosamples), p=p).astype(np.int64)
+    q = onp.normalise(onp.expected_s1(probe, n_states))
+    t0 = time.perf_counter()
+    rb.score_rows_s1(probe[:1000], q, n_states)
+    per_core = 1000 / (time.perf_counter() - t0)
+    want = per_core * cores * target_seconds                 # bins for ~target_seconds of wall time
+    sample = int(min(max(want, 4000), 1_000_000))            # distinct bins held in RAM (int8)
+    reps = max(1, int(round(want / sample)))
+    x = rng.choice(n_states, size=(sample, n_biosamples), p=p).astype(np.int8)
+    bps, secs, cores = rb.timed_pool_run(x, q, n_states, cores, reps=reps)
+    return {"value": round(bps / 1e6, 6), "unit": "Mbins/s", "cores": cores, "kind": "port",
+            "sample": "%d synthetic bins x %d biosamples (same state frequencies as the GPU workload) scored %d time(s): "
+                      "per-bin numpy loop of oracle/rowloop_baseline.py (np.unique + numpy.ma p*log2(p/q), the "
+                      "reference's -l S1 loop shape, scores.py:309-344,539-550) on %d forked workers, %.1f s wall"
+                      % (sample, n_biosamples, reps, cores, secs)}
+
+
+def generate_shard(torch, X, n_biosamples, n_states, bin0):
+    """Fill X[:, :N] with synthetic states for global bins [bin0, bin0 + R): global chunk k of 2^20 bins is drawn
+    from torch.Generator seeded 1234 + k in fixed sub-blocks, so the matrix does not depend on the GPU count."""
+    R = X.shape[0]
+    dev = X.device
+    p = FREQS[:n_states] / FREQS[:n_states].sum()
+    bounds = torch.tensor(np.cumsum(p)[:-1], dtype=torch.float32, device=dev)
+    X.fill_(-1)
+    gen = torch.Generator(device=dev)
+    k0, k1 = bin0 // CHUNK_BINS, (bin0 + R - 1) // CHUNK_BINS
+    for k in range(k0, k1 + 1):
+        gen.manual_seed(1234 + k)
+        for sub in range(CHUNK_BINS // SUB_BINS):
+            g0 = k * CHUNK_BINS + sub * SUB_BINS
+            u = torch.rand((SUB_BINS, n_biosamples), generator=gen, device=dev, dtype=torch.float32)
+            lo, hi = max(g0, bin0), min(g0 + SUB_BINS, bin0 + R)
+            if lo >= hi:
+                continue
+            st = torch.bucketize(u[lo - g0:hi - g0], bounds, right=True).to(torch.int8)
+            X[lo - bin0:hi - bin0, :n_biosamples] = st
+            del u, st
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--bins", type=int, default=15_000_000, help="bins per GPU")
+    ap.add_argument("--biosamples", type=int, default=833)
+    ap.add_argument("--states", type=int, default=18)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--packed", action="store_true", help="row pitch = biosamples (unaligned rows) instead of 16-byte padded")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
+        raise SystemExit("WORLD_SIZE=%d does not match --gpus %d" % (world, args.gpus))
+    N, S, R = args.biosamples, args.states, args.bins
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(N, S)          # before any GPU initialisation: it forks
+
+    import torch
+    import torch.distributed as dist
+    from epilogos_amd import engine
+    engine.require_gpu()
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    # ---- resident inputs and preallocated outputs
+    if args.packed:
+        flat = torch.empty(R * N + 64, dtype=torch.int8, device=dev)
+        X = flat[:R * N].view(R, N)
+    else:
+        X = engine.alloc_states(R, N, device=dev)
+    generate_shard(torch, X, N, S, rank * R)
+    H = torch.empty((R, S), dtype=torch.int16, device=dev)
+    counts = torch.zeros(S, dtype=torch.int64, device=dev)
+    q = torch.empty(S, dtype=torch.float32, device=dev)
+    out32 = torch.empty((R, S), dtype=torch.float32, device=dev)
+    ws_norm = torch.empty(256, dtype=torch.uint8, device=dev)
+    ws_s1 = engine.workspace(1, 0, N, S, device=dev)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+          for _ in range(args.steps)]
+
+    def step(k=None):
+        counts.zero_()
+        if k is not None:
+            ev[k][0].record()
+        engine.bin_hist(X, N, S, counts=counts, H=H)                       # STEP 1: expected pass
+        if k is not None:
+            ev[k][1].record()
+        if world > 1:
+            dist.all_reduce(counts, op=dist.ReduceOp.SUM)                  # the single collective (144 bytes)
+        engine.normalise(counts, q=q, ws=ws_norm)                          # STEP 2: combination
+        engine.score_s1_from_binhist(H, N, S, q, out32=out32, ws=ws_s1)    # STEP 3: score pass
+        if k is not None:
+            ev[k][2].record()
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(k)
+    fence()
+    dt = time.perf_counter() - t0
+
+    # sanity of the last step (cheap, outside the timed region): every state byte counted, scores finite
+    total = int(counts.sum().item())
+    assert total == world * R * N, "state counts %d != bins*biosamples %d" % (total, world * R * N)
+    assert bool(torch.isfinite(out32[:: max(R // 4096, 1)]).all())
+
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    hist_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in ev])) if args.steps else float("nan")
+    rest_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in ev])) if args.steps else float("nan")
+
+    if rank == 0:
+        ms_per_step = dt / args.steps * 1e3
+        value = world * R * args.steps / dt / 1e6
+        achieved = R * N / (hist_ms * 1e-3) / 1e9
+        traffic = None
+        tfile = ROOT / "profiles" / "hbm_traffic.json"
+        if tfile.exists():
+            try:
+                traffic = json.loads(tfile.read_text()).get("k_bin_hist_bytes_per_launch_%d_%d" % (R, N))
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "Mbins scored/sec (S1, 18-state, 833 biosamples)",
+            "value": round(value, 3), "unit": "Mbins/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u8", "data": "synthetic",
+            "config": {"workload": "S1 saliency, whole-genome scale: %d bins x %d biosamples x %d states per GPU, "
+                                   "expected pass + count all-reduce + normalise + score pass per step" % (R, N, S),
+                       "bins_per_gpu": R, "biosamples": N, "states": S, "saliency": 1,
+                       "row_pitch_bytes": int(X.stride(0)),
+                       "partition": "contiguous bin ranges per GPU (helpers.splitRows rule), one RCCL all-reduce of int64[%d]" % S},
+            "roofline": {"bound": "hbm", "kernel": "k_bin_hist", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
+                         "algorithmic_bytes_per_bin": N, "avg_launch_ms": round(hist_ms, 4)},
+            "kernels_ms": {"k_bin_hist": round(hist_ms, 4), "allreduce+normalise+table+score_from_hist": round(rest_ms, 4)},
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,51 @@
+"""Build libepilogos_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU)."""
+import os
+import shutil
+import subprocess
+from pathlib import Path
+
+PKG = Path(__file__).resolve().parent
+ROOT = PKG.parent
+CSRC = PKG / "csrc"
+LIB_DIR = PKG / "_lib"
+LIB_PATH = LIB_DIR / "libepilogos_hip.so"
+SOURCES = ["epg_abi.hip", "epg_s1.hip", "epg_s2.hip", "epg_s3.hip"]
+HEADERS = [CSRC / "epg_common.h", CSRC / "epg_count.h", ROOT / "include" / "epilogos_amd.h"]
+ARCH = "gfx950"
+
+
+def _hipcc():
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(exe):
+        raise RuntimeError("hipcc not found: cannot build libepilogos_hip.so")
+    return exe
+
+
+def is_stale():
+    if not LIB_PATH.exists():
+        return True
+    t = LIB_PATH.stat().st_mtime
+    deps = [CSRC / s for s in SOURCES] + HEADERS
+    return any(d.stat().st_mtime > t for d in deps)
+
+
+def build_library(force=False, verbose=False, extra_flags=()):
+    """Compile every HIP source into one shared library.  Returns the path."""
+    if not force and not is_stale():
+        return LIB_PATH
+    LIB_DIR.mkdir(parents=True, exist_ok=True)
+    tmp = LIB_DIR / (LIB_PATH.name + ".tmp.%d" % os.getpid())
+    cmd = [_hipcc(), "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-shared",
+           "-I" + str(ROOT / "include"), "-I" + str(CSRC), *extra_flags,
+           *[str(CSRC / s) for s in SOURCES], "-o", str(tmp)]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise RuntimeError("hipcc failed:\n" + res.stdout + res.stderr)
+    os.replace(tmp, LIB_PATH)
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    print(build_library(force=True, verbose=True))

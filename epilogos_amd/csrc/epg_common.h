@@ -1,0 +1,62 @@
+// Shared helpers for the epilogos_amd HIP sources (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "epilogos_amd.h"
+
+typedef unsigned int u32;
+typedef unsigned long long u64;
+typedef unsigned short u16;
+
+namespace epg {
+
+int fail(int code, const char* fmt, ...);
+int num_cus();
+
+#define EPG_HIP(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t _e = (expr);                                                               \
+        if (_e != hipSuccess)                                                                 \
+            return epg::fail(EPG_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(_e));     \
+    } while (0)
+
+#define EPG_LAUNCH_CHECK(name)                                                                \
+    do {                                                                                      \
+        hipError_t _e = hipGetLastError();                                                    \
+        if (_e != hipSuccess)                                                                 \
+            return epg::fail(EPG_ERR_HIP, "launch of %s failed: %s", name, hipGetErrorString(_e)); \
+    } while (0)
+
+static inline int64_t align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
+
+// (a & m) | (b & ~m): one v_bfi_b32
+__device__ __forceinline__ u32 bfi(u32 m, u32 a, u32 b) { return (a & m) | (b & ~m); }
+
+// 16-byte load from an arbitrarily aligned address (amdhsa enables unaligned access mode; the compiler
+// emits a single global_load_dwordx4)
+__device__ __forceinline__ uint4 ld16(const char* p) {
+    uint4 v;
+    __builtin_memcpy(&v, p, 16);
+    return v;
+}
+
+// sum over the 4 lanes of a quad, result in every lane (two v_add_u32_dpp quad_perm)
+__device__ __forceinline__ u32 quad_sum(u32 v) {
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, false);  // quad_perm [1,0,3,2]
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, false);  // quad_perm [2,3,0,1]
+    return v;
+}
+
+// kl(p, q) = p * log2(p / q) with the reference's masked-zero semantics (scores.py:550):
+// 0 where q == 0, 0 where p/q <= 0.
+__device__ __forceinline__ double kl_term(double p, double q) {
+    if (q == 0.0) return 0.0;
+    const double r = p / q;
+    if (!(r > 0.0)) return 0.0;
+    return p * log2(r);
+}
+
+}  // namespace epg

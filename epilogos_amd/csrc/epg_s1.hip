@@ -1,0 +1,377 @@
+// S1 path: per-bin histogram (K1), expected S1 counts, S1 score (direct and from cached histograms).
+// gfx950 only.  See epg_count.h for the counting core and DESIGN.md for the roofline of each kernel.
+#include "epg_count.h"
+
+namespace epg {
+
+// ---------------------------------------------------------------------------------------------------------------
+// K1: X[R, ldx] int8 -> H[R, S] uint16 (+ counts[S] += column sums).  HBM-bound: N bytes read, 2*S written per bin.
+// Restates np.unique(row, return_counts=True) of scores.py:341/444 and expected.py:111-113,152.
+// ---------------------------------------------------------------------------------------------------------------
+template <int S, int NG>
+__global__ __launch_bounds__(256) void k_bin_hist(const char* __restrict__ X, long R, int N, long ldx,
+                                                   u16* __restrict__ H, u64* __restrict__ counts) {
+    __shared__ u64 s_cnt[S];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 3, b = lane >> 2;
+    const RowGeom g = make_geom(N);
+    if (threadIdx.x < S) s_cnt[threadIdx.x] = 0;
+
+    u32 acc[S];
+#pragma unroll
+    for (int s = 0; s < S; ++s) acc[s] = 0;
+
+    const long ntiles = (R + 15) >> 4;
+    for (long tile = (long)blockIdx.x * 4 + wave; tile < ntiles; tile += (long)gridDim.x * 4) {
+        const long row = tile * 16 + b;
+        const bool valid = row < R;
+        const long rowc = valid ? row : R - 1;
+        u32 cnt[S];
+#pragma unroll
+        for (int s = 0; s < S; ++s) cnt[s] = 0;
+        count_row<S, NG>(X + rowc * ldx, j, g, cnt);
+#pragma unroll
+        for (int s = 0; s < S; ++s) cnt[s] = quad_sum(cnt[s]);
+        if (valid) {
+            if (counts) {
+#pragma unroll
+                for (int s = 0; s < S; ++s) acc[s] += cnt[s];
+            }
+            if (H) {
+                // 2*S bytes per bin; S even -> S/2 dwords, spread over the quad (dword m to lane m & 3)
+                u16* hrow = H + row * S;
+                if constexpr ((S & 1) == 0) {
+                    constexpr int ND = S / 2;
+                    u32 d[ND + 3];
+#pragma unroll
+                    for (int m = 0; m < ND; ++m) d[m] = cnt[2 * m] | (cnt[2 * m + 1] << 16);
+#pragma unroll
+                    for (int m = ND; m < ND + 3; ++m) d[m] = 0;
+                    u32* hp = reinterpret_cast<u32*>(hrow);
+#pragma unroll
+                    for (int k = 0; k < (ND + 3) / 4; ++k) {
+                        const u32 v = sel4(d[4 * k], d[4 * k + 1], d[4 * k + 2], d[4 * k + 3], j);
+                        if (4 * k + j < ND) hp[4 * k + j] = v;
+                    }
+                } else {
+#pragma unroll
+                    for (int k = 0; k < (S + 3) / 4; ++k) {
+                        const u32 v = sel4(cnt[4 * k], 4 * k + 1 < S ? cnt[4 * k + 1] : 0u,
+                                           4 * k + 2 < S ? cnt[4 * k + 2] : 0u, 4 * k + 3 < S ? cnt[4 * k + 3] : 0u, j);
+                        if (4 * k + j < S) hrow[4 * k + j] = (u16)v;
+                    }
+                }
+            }
+        }
+    }
+    if (counts) {
+        __syncthreads();
+        if (j == 0) {
+#pragma unroll
+            for (int s = 0; s < S; ++s)
+                if (acc[s]) atomicAdd(&s_cnt[s], (u64)acc[s]);
+        }
+        __syncthreads();
+        if (threadIdx.x < S && s_cnt[threadIdx.x]) atomicAdd(&counts[threadIdx.x], s_cnt[threadIdx.x]);
+    }
+}
+
+// Any S <= 127, any N, any alignment, never reads past a row's N bytes: one wave per bin, LDS atomics.
+// Used for the matrix's last row when ldx < 16*ceil(N/16) (the fast kernel's last chunk would over-read).
+__global__ __launch_bounds__(256) void k_bin_hist_safe(const char* __restrict__ X, long row_begin, long row_end, int N,
+                                                        long ldx, int S, u16* __restrict__ H, u64* __restrict__ counts) {
+    __shared__ u32 s_h[4][128];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (long row = row_begin + (long)blockIdx.x * 4 + wave; row < row_end; row += (long)gridDim.x * 4) {
+        for (int s = lane; s < S; s += 64) s_h[wave][s] = 0;
+        __builtin_amdgcn_wave_barrier();
+        const char* rp = X + row * ldx;
+        for (int n = lane; n < N; n += 64) {
+            const int v = (unsigned char)rp[n];
+            if (v < S) atomicAdd(&s_h[wave][v], 1u);
+        }
+        __builtin_amdgcn_wave_barrier();
+        for (int s = lane; s < S; s += 64) {
+            const u32 c = s_h[wave][s];
+            if (H) H[row * S + s] = (u16)c;
+            if (counts && c) atomicAdd(&counts[s], (u64)c);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// S1 lookup table: T[c, s] = kl(c / N, q[s]) for c = 0..N  (scores.py:343 rowObsS1 + scores.py:550 klScoreND);
+// T64 is the float64 value, T32 its float32 rounding (the reference's store, scores.py:317).
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void k_s1_table(const float* __restrict__ q, int N, int S, double* __restrict__ T64, float* __restrict__ T32) {
+    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (long)(N + 1) * S) return;
+    const int c = (int)(e / S), s = (int)(e % S);
+    const double p = (double)c / (double)N;
+    const double v = kl_term(p, (double)q[s]);
+    T64[e] = v;
+    T32[e] = (float)v;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// S1 score straight from the state matrix: N bytes read + S*sizeof(OT) written per bin (scores.py:309-317).
+// ---------------------------------------------------------------------------------------------------------------
+template <int S, int NG, typename OT>
+__global__ __launch_bounds__(256) void k_score_s1(const char* __restrict__ X, long R, int N, long ldx,
+                                                   const OT* __restrict__ T, OT* __restrict__ out) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 3, b = lane >> 2;
+    const RowGeom g = make_geom(N);
+    const long ntiles = (R + 15) >> 4;
+    for (long tile = (long)blockIdx.x * 4 + wave; tile < ntiles; tile += (long)gridDim.x * 4) {
+        const long row = tile * 16 + b;
+        const bool valid = row < R;
+        const long rowc = valid ? row : R - 1;
+        u32 cnt[S];
+#pragma unroll
+        for (int s = 0; s < S; ++s) cnt[s] = 0;
+        count_row<S, NG>(X + rowc * ldx, j, g, cnt);
+#pragma unroll
+        for (int s = 0; s < S; ++s) cnt[s] = quad_sum(cnt[s]);
+        if (valid) {
+            OT* orow = out + row * S;
+#pragma unroll
+            for (int k = 0; k < (S + 3) / 4; ++k) {
+                const u32 c = sel4(cnt[4 * k], 4 * k + 1 < S ? cnt[4 * k + 1] : 0u, 4 * k + 2 < S ? cnt[4 * k + 2] : 0u,
+                                   4 * k + 3 < S ? cnt[4 * k + 3] : 0u, j);
+                const int s = 4 * k + j;
+                if (s < S) orow[s] = c ? T[(long)c * S + s] : (OT)0;
+            }
+        }
+    }
+}
+
+// S1 score from cached histograms: 2*S bytes read + S*sizeof(OT) written per bin.  8 elements per thread.
+template <typename OT>
+__global__ __launch_bounds__(256) void k_score_s1_from_hist(const u16* __restrict__ H, long total, int S,
+                                                             const OT* __restrict__ T, OT* __restrict__ out) {
+    const long e0 = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 8;
+    if (e0 >= total) return;
+    int s = (int)(e0 % S);
+    if (e0 + 8 <= total) {
+        const uint4 hv = *reinterpret_cast<const uint4*>(H + e0);
+        const u32 hw[4] = {hv.x, hv.y, hv.z, hv.w};
+        OT v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const u32 c = (hw[k >> 1] >> (16 * (k & 1))) & 0xffffu;
+            v[k] = c ? T[(long)c * S + s] : (OT)0;
+            s = s + 1 == S ? 0 : s + 1;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) out[e0 + k] = v[k];
+    } else {
+        for (long e = e0; e < total; ++e) {
+            const u32 c = H[e];
+            out[e] = c ? T[(long)c * S + s] : (OT)0;
+            s = s + 1 == S ? 0 : s + 1;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// normalise: q = float32( double(C) / double(sum C) )   (expectedCombination.py:42).  Two tiny kernels: integer sum
+// (exact, order-independent), then the divide.
+// ---------------------------------------------------------------------------------------------------------------
+template <typename IT>
+__global__ __launch_bounds__(256) void k_sum_int(const IT* __restrict__ C, long n, long long* __restrict__ total) {
+    long long acc = 0;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) acc += (long long)C[i];
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
+    __shared__ long long s_part[4];
+    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const long long t = s_part[0] + s_part[1] + s_part[2] + s_part[3];
+        if (t) atomicAdd(reinterpret_cast<u64*>(total), (u64)t);
+    }
+}
+
+template <typename IT>
+__global__ __launch_bounds__(256) void k_normalise(const IT* __restrict__ C, long n, const long long* __restrict__ total,
+                                                    float* __restrict__ q) {
+    const double tot = (double)(*total);
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        q[i] = (float)((double)C[i] / tot);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// host-side dispatch
+// ---------------------------------------------------------------------------------------------------------------
+static int grid_for_tiles(long R) {
+    const long ntiles = (R + 15) >> 4;
+    long blocks = (ntiles + 3) / 4;
+    const long cap = (long)num_cus() * 8;
+    if (blocks > cap) blocks = cap;
+    if (blocks < 1) blocks = 1;
+    return (int)blocks;
+}
+
+template <int S, int NG>
+static void launch_bin_hist(const char* X, long R, int N, long ldx, u16* H, u64* counts, hipStream_t st) {
+    hipLaunchKernelGGL((k_bin_hist<S, NG>), dim3(grid_for_tiles(R)), dim3(256), 0, st, X, R, N, ldx, H, counts);
+}
+
+template <int S>
+static void dispatch_bin_hist_ng(const char* X, long R, int N, long ldx, u16* H, u64* counts, hipStream_t st) {
+    const int ng = (N + 127) / 128;
+    switch (ng) {
+        case 1: launch_bin_hist<S, 1>(X, R, N, ldx, H, counts, st); break;
+        case 2: launch_bin_hist<S, 2>(X, R, N, ldx, H, counts, st); break;
+        case 3: launch_bin_hist<S, 3>(X, R, N, ldx, H, counts, st); break;
+        case 4: launch_bin_hist<S, 4>(X, R, N, ldx, H, counts, st); break;
+        case 5: launch_bin_hist<S, 5>(X, R, N, ldx, H, counts, st); break;
+        case 6: launch_bin_hist<S, 6>(X, R, N, ldx, H, counts, st); break;
+        case 7: launch_bin_hist<S, 7>(X, R, N, ldx, H, counts, st); break;
+        default: launch_bin_hist<S, 0>(X, R, N, ldx, H, counts, st); break;
+    }
+}
+
+// rows the fast kernel may touch: all of them unless its 16-byte last chunk could run past the allocation
+static long fast_rows(long R, int N, long ldx) {
+    const long chunks = (N + 15) / 16;
+    return ldx >= 16 * chunks ? R : R - 1;
+}
+
+int bin_hist_impl(const int8_t* X8, int64_t R, int32_t N, int64_t ldx, int32_t S, uint16_t* H, int64_t* counts,
+                  hipStream_t st) {
+    if (R < 0 || N < 1 || ldx < N || S < 1) return fail(EPG_ERR_INVALID_ARG, "bin_hist: bad shape R=%lld N=%d ldx=%lld S=%d", (long long)R, N, (long long)ldx, S);
+    if (S > 31) return fail(EPG_ERR_UNSUPPORTED, "bin_hist: S=%d > 31 not supported by this build", S);
+    if (N > 65535) return fail(EPG_ERR_UNSUPPORTED, "bin_hist: N=%d > 65535 (uint16 per-bin counts)", N);
+    if (R == 0) return EPG_OK;
+    if (!X8) return fail(EPG_ERR_INVALID_ARG, "bin_hist: X is NULL");
+    const char* X = reinterpret_cast<const char*>(X8);
+    u64* cnt = reinterpret_cast<u64*>(counts);
+    const long Rf = fast_rows(R, N, ldx);
+    if (Rf > 0) {
+        switch (S) {
+            case 18: dispatch_bin_hist_ng<18>(X, Rf, N, ldx, H, cnt, st); break;
+            case 15: launch_bin_hist<15, 0>(X, Rf, N, ldx, H, cnt, st); break;
+            case 25: launch_bin_hist<25, 0>(X, Rf, N, ldx, H, cnt, st); break;
+            default: {
+                // generic: count all 31 decodable states into a scratch-free path is not possible with a
+                // different row width, so fall back to the safe kernel for unusual S
+                hipLaunchKernelGGL(k_bin_hist_safe, dim3((int)((Rf + 3) / 4 > num_cus() * 8L ? num_cus() * 8L : (Rf + 3) / 4)),
+                                   dim3(256), 0, st, X, 0L, Rf, N, ldx, S, H, cnt);
+            }
+        }
+        EPG_LAUNCH_CHECK("k_bin_hist");
+    }
+    if (Rf < R) {
+        hipLaunchKernelGGL(k_bin_hist_safe, dim3(1), dim3(256), 0, st, X, Rf, (long)R, N, ldx, S, H, cnt);
+        EPG_LAUNCH_CHECK("k_bin_hist_safe");
+    }
+    return EPG_OK;
+}
+
+template <int S, int NG, typename OT>
+static void launch_score_s1(const char* X, long R, int N, long ldx, const OT* T, OT* out, hipStream_t st) {
+    hipLaunchKernelGGL((k_score_s1<S, NG, OT>), dim3(grid_for_tiles(R)), dim3(256), 0, st, X, R, N, ldx, T, out);
+}
+
+template <typename OT>
+static bool dispatch_score_s1(const char* X, long R, int N, long ldx, int S, const OT* T, OT* out, hipStream_t st) {
+    if (S != 18) return false;
+    const int ng = (N + 127) / 128;
+    switch (ng) {
+        case 1: launch_score_s1<18, 1, OT>(X, R, N, ldx, T, out, st); break;
+        case 2: launch_score_s1<18, 2, OT>(X, R, N, ldx, T, out, st); break;
+        case 3: launch_score_s1<18, 3, OT>(X, R, N, ldx, T, out, st); break;
+        case 4: launch_score_s1<18, 4, OT>(X, R, N, ldx, T, out, st); break;
+        case 5: launch_score_s1<18, 5, OT>(X, R, N, ldx, T, out, st); break;
+        case 6: launch_score_s1<18, 6, OT>(X, R, N, ldx, T, out, st); break;
+        case 7: launch_score_s1<18, 7, OT>(X, R, N, ldx, T, out, st); break;
+        default: launch_score_s1<18, 0, OT>(X, R, N, ldx, T, out, st); break;
+    }
+    return true;
+}
+
+static int64_t s1_table_bytes(int N, int S) { return align_up((int64_t)(N + 1) * S * 8, 256) + align_up((int64_t)(N + 1) * S * 4, 256); }
+
+int64_t s1_ws_bytes(int64_t R, int N, int S) {
+    // table + room for a cached histogram (used when the fused kernel does not cover this S)
+    return s1_table_bytes(N, S) + align_up(R * S * 2, 256);
+}
+
+static int build_s1_table(const float* q, int N, int S, void* ws, double** T64, float** T32, hipStream_t st) {
+    *T64 = reinterpret_cast<double*>(ws);
+    *T32 = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + align_up((int64_t)(N + 1) * S * 8, 256));
+    const long n = (long)(N + 1) * S;
+    hipLaunchKernelGGL(k_s1_table, dim3((int)((n + 255) / 256)), dim3(256), 0, st, q, N, S, *T64, *T32);
+    EPG_LAUNCH_CHECK("k_s1_table");
+    return EPG_OK;
+}
+
+int score_s1_from_hist_impl(const uint16_t* H, int64_t R, int32_t N, int32_t S, const float* q, double* out64,
+                            float* out32, void* ws, int64_t ws_bytes, hipStream_t st) {
+    if (R < 0 || N < 1 || S < 1) return fail(EPG_ERR_INVALID_ARG, "score_s1: bad shape");
+    if (R == 0) return EPG_OK;
+    if (!H || !q || !ws) return fail(EPG_ERR_INVALID_ARG, "score_s1_from_binhist: NULL argument");
+    if (ws_bytes < s1_table_bytes(N, S)) return fail(EPG_ERR_WORKSPACE, "score_s1: workspace %lld < %lld bytes", (long long)ws_bytes, (long long)s1_table_bytes(N, S));
+    if ((reinterpret_cast<uintptr_t>(H) & 15) != 0) return fail(EPG_ERR_INVALID_ARG, "score_s1_from_binhist: H must be 16-byte aligned");
+    double* T64; float* T32;
+    int rc = build_s1_table(q, N, S, ws, &T64, &T32, st);
+    if (rc) return rc;
+    const long total = (long)R * S;
+    const int blocks = (int)((total / 8 + 256) / 256);
+    if (out32) hipLaunchKernelGGL((k_score_s1_from_hist<float>), dim3(blocks), dim3(256), 0, st, H, total, S, T32, out32);
+    if (out64) hipLaunchKernelGGL((k_score_s1_from_hist<double>), dim3(blocks), dim3(256), 0, st, H, total, S, T64, out64);
+    EPG_LAUNCH_CHECK("k_score_s1_from_hist");
+    return EPG_OK;
+}
+
+int score_s1_impl(const int8_t* X8, int64_t R, int32_t N, int64_t ldx, int32_t S, const float* q, double* out64,
+                  float* out32, void* ws, int64_t ws_bytes, hipStream_t st) {
+    if (R < 0 || N < 1 || ldx < N || S < 1) return fail(EPG_ERR_INVALID_ARG, "score_s1: bad shape");
+    if (S > 31) return fail(EPG_ERR_UNSUPPORTED, "score_s1: S=%d > 31 not supported by this build", S);
+    if (R == 0) return EPG_OK;
+    if (!X8 || !q || !ws) return fail(EPG_ERR_INVALID_ARG, "score_s1: NULL argument");
+    const long Rf = fast_rows(R, N, ldx);
+    const bool fused = S == 18 && Rf == R;
+    if (!fused) {
+        // histogram into the workspace, then score from it
+        if (ws_bytes < s1_ws_bytes(R, N, S)) return fail(EPG_ERR_WORKSPACE, "score_s1: workspace %lld < %lld bytes", (long long)ws_bytes, (long long)s1_ws_bytes(R, N, S));
+        u16* H = reinterpret_cast<u16*>(reinterpret_cast<char*>(ws) + s1_table_bytes(N, S));
+        int rc = bin_hist_impl(X8, R, N, ldx, S, H, nullptr, st);
+        if (rc) return rc;
+        return score_s1_from_hist_impl(H, R, N, S, q, out64, out32, ws, s1_table_bytes(N, S), st);
+    }
+    if (ws_bytes < s1_table_bytes(N, S)) return fail(EPG_ERR_WORKSPACE, "score_s1: workspace %lld < %lld bytes", (long long)ws_bytes, (long long)s1_table_bytes(N, S));
+    double* T64; float* T32;
+    int rc = build_s1_table(q, N, S, ws, &T64, &T32, st);
+    if (rc) return rc;
+    const char* X = reinterpret_cast<const char*>(X8);
+    if (out32) dispatch_score_s1<float>(X, R, N, ldx, S, T32, out32, st);
+    if (out64) dispatch_score_s1<double>(X, R, N, ldx, S, T64, out64, st);
+    EPG_LAUNCH_CHECK("k_score_s1");
+    return EPG_OK;
+}
+
+template <typename IT>
+static int normalise_impl(const IT* C, int64_t n, float* q, void* ws, int64_t ws_bytes, hipStream_t st) {
+    if (n < 1 || !C || !q || !ws) return fail(EPG_ERR_INVALID_ARG, "normalise: bad argument");
+    if (ws_bytes < 8) return fail(EPG_ERR_WORKSPACE, "normalise: workspace needs 8 bytes");
+    long long* total = reinterpret_cast<long long*>(ws);
+    EPG_HIP(hipMemsetAsync(total, 0, 8, st));
+    long blocks = (n + 255) / 256;
+    if (blocks > num_cus() * 8L) blocks = num_cus() * 8L;
+    hipLaunchKernelGGL((k_sum_int<IT>), dim3((int)blocks), dim3(256), 0, st, C, (long)n, total);
+    hipLaunchKernelGGL((k_normalise<IT>), dim3((int)blocks), dim3(256), 0, st, C, (long)n, total, q);
+    EPG_LAUNCH_CHECK("k_normalise");
+    return EPG_OK;
+}
+
+int normalise_i64_impl(const int64_t* C, int64_t n, float* q, void* ws, int64_t ws_bytes, hipStream_t st) {
+    return normalise_impl<long long>(reinterpret_cast<const long long*>(C), n, q, ws, ws_bytes, st);
+}
+int normalise_i32_impl(const int32_t* C, int64_t n, float* q, void* ws, int64_t ws_bytes, hipStream_t st) {
+    return normalise_impl<int>(C, n, q, ws, ws_bytes, st);
+}
+
+}  // namespace epg

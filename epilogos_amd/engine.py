@@ -1,0 +1,197 @@
+"""Device plumbing: torch tensors (HBM buffers, streams) in, C-ABI calls out.  PyTorch is used only for
+memory, streams and torch.distributed; every arithmetic step is a kernel of libepilogos_hip.so.
+
+State matrices are int8 [R, ldx] with ldx = N rounded up to 16 bytes (pad bytes are never read as states), which
+is the layout the streaming kernel's 16-byte loads want.  All functions enqueue on torch's current stream and
+return device tensors without synchronising.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _abi
+from ._abi import EpilogosHipError
+
+ROW_ALIGN = 16
+
+
+def require_gpu():
+    if not torch.cuda.is_available():
+        raise EpilogosHipError(-3, "no HIP device visible to torch: the epilogos_amd engine has no CPU fallback")
+    _abi.load()
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def padded_width(N):
+    return (N + ROW_ALIGN - 1) // ROW_ALIGN * ROW_ALIGN
+
+
+def alloc_states(R, N, device="cuda"):
+    """Uninitialised int8 [R, ldx] state matrix; use [:, :N]."""
+    return torch.empty((R, padded_width(N)), dtype=torch.int8, device=device)
+
+
+def states_to_device(x, device="cuda"):
+    """Host int array [R, N] of 0-based states -> padded int8 device matrix."""
+    x = np.ascontiguousarray(x)
+    R, N = x.shape
+    ldx = padded_width(N)
+    host = np.full((R, ldx), -1, dtype=np.int8)
+    host[:, :N] = x.astype(np.int8)
+    return torch.from_numpy(host).to(device)
+
+
+def _check_states(X, N):
+    if X.dtype != torch.int8 or X.dim() != 2 or not X.is_cuda or X.stride(1) != 1:
+        raise ValueError("state matrix must be a 2-D int8 CUDA tensor with unit column stride")
+    if N > X.shape[1]:
+        raise ValueError("N exceeds the row width")
+    return X.shape[0], X.stride(0)
+
+
+def zeros_counts(n, dtype=torch.int64, device="cuda"):
+    return torch.zeros(n, dtype=dtype, device=device)
+
+
+def bin_hist(X, N, S, want_hist=True, counts=None, want_counts=True, H=None):
+    """K1: per-bin histograms H uint16 [R, S] (as int16 storage) and/or counts[S] += column sums."""
+    R, ldx = _check_states(X, N)
+    if H is None and want_hist:
+        H = torch.empty((R, S), dtype=torch.int16, device=X.device)
+    if want_counts and counts is None:
+        counts = zeros_counts(S, device=X.device)
+    _abi.call("epg_bin_hist", _ptr(X), R, N, ldx, S, _ptr(H), _ptr(counts) if want_counts else None, _stream())
+    return H, counts
+
+
+def hist_s2_from_binhist(H, S, counts=None):
+    if counts is None:
+        counts = zeros_counts(S * S, device=H.device)
+    _abi.call("epg_hist_s2_from_binhist", _ptr(H), H.shape[0], S, _ptr(counts), _stream())
+    return counts
+
+
+def hist_s3(X, N, S, counts=None):
+    R, ldx = _check_states(X, N)
+    if counts is None:
+        counts = zeros_counts(N * N * S * S, dtype=torch.int32, device=X.device)
+    nbytes = _abi.call("epg_ws_bytes", 3, R, N, S)
+    ws = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=X.device)
+    _abi.call("epg_hist_s3", _ptr(X), R, N, ldx, S, _ptr(counts), _ptr(ws), ws.numel(), _stream())
+    return counts
+
+
+def normalise(counts, q=None, ws=None):
+    """q = float32(counts / sum(counts)) on device (expectedCombination.py:42)."""
+    if q is None:
+        q = torch.empty(counts.numel(), dtype=torch.float32, device=counts.device)
+    if ws is None:
+        ws = torch.empty(256, dtype=torch.uint8, device=counts.device)
+    name = {torch.int64: "epg_normalise_i64", torch.int32: "epg_normalise_i32"}[counts.dtype]
+    _abi.call(name, _ptr(counts), counts.numel(), _ptr(q), _ptr(ws), ws.numel(), _stream())
+    return q
+
+
+def _outs(R, S, device, want32, want64, out32=None, out64=None):
+    o32 = out32 if out32 is not None else (torch.empty((R, S), dtype=torch.float32, device=device) if want32 else None)
+    o64 = out64 if out64 is not None else (torch.empty((R, S), dtype=torch.float64, device=device) if want64 else None)
+    return o32, o64
+
+
+def workspace(saliency, R, N, S, device="cuda"):
+    """Caller-owned scratch for the score calls of one saliency (tables; plus a histogram cache when R > 0)."""
+    return _ws(saliency, R, N, S, device)
+
+
+def _ws(saliency, R, N, S, device):
+    nbytes = _abi.call("epg_ws_bytes", saliency, R, N, S)
+    return torch.empty(max(nbytes, 256), dtype=torch.uint8, device=device)
+
+
+def score_s1(X, N, S, q, want32=True, want64=False, out32=None, out64=None, ws=None):
+    R, ldx = _check_states(X, N)
+    o32, o64 = _outs(R, S, X.device, want32, want64, out32, out64)
+    if ws is None:
+        ws = _ws(1, R, N, S, X.device)
+    _abi.call("epg_score_s1", _ptr(X), R, N, ldx, S, _ptr(q), _ptr(o64), _ptr(o32), _ptr(ws), ws.numel(), _stream())
+    return o32, o64
+
+
+def score_s1_from_binhist(H, N, S, q, want32=True, want64=False, out32=None, out64=None, ws=None):
+    R = H.shape[0]
+    o32, o64 = _outs(R, S, H.device, want32, want64, out32, out64)
+    if ws is None:
+        ws = _ws(1, 0, N, S, H.device)
+    _abi.call("epg_score_s1_from_binhist", _ptr(H), R, N, S, _ptr(q), _ptr(o64), _ptr(o32), _ptr(ws), ws.numel(),
+              _stream())
+    return o32, o64
+
+
+def score_s2(X, N, S, q, perms=None, want32=True, want64=False):
+    R, ldx = _check_states(X, N)
+    perms = N * (N - 1) if perms is None else perms
+    o32, o64 = _outs(R, S, X.device, want32, want64)
+    ws = _ws(2, R, N, S, X.device)
+    _abi.call("epg_score_s2", _ptr(X), R, N, ldx, S, perms, _ptr(q), _ptr(o64), _ptr(o32), _ptr(ws), ws.numel(),
+              _stream())
+    return o32, o64
+
+
+def score_s2_from_binhist(H, N, S, q, perms=None, want32=True, want64=False, out32=None, out64=None, ws=None):
+    R = H.shape[0]
+    perms = N * (N - 1) if perms is None else perms
+    o32, o64 = _outs(R, S, H.device, want32, want64, out32, out64)
+    if ws is None:
+        ws = _ws(2, 0, N, S, H.device)
+    _abi.call("epg_score_s2_from_binhist", _ptr(H), R, N, S, perms, _ptr(q), _ptr(o64), _ptr(o32), _ptr(ws),
+              ws.numel(), _stream())
+    return o32, o64
+
+
+def score_s3(X, N, S, q, want32=True, want64=False):
+    R, ldx = _check_states(X, N)
+    o32, o64 = _outs(R, S, X.device, want32, want64)
+    ws = _ws(3, R, N, S, X.device)
+    _abi.call("epg_score_s3", _ptr(X), R, N, ldx, S, _ptr(q), _ptr(o64), _ptr(o32), _ptr(ws), ws.numel(), _stream())
+    return o32, o64
+
+
+def pair_finish(a, b, want_dist=True):
+    R, S = a.shape
+    delta = torch.empty_like(a)
+    dist = torch.empty(R, dtype=torch.float32, device=a.device) if want_dist else None
+    _abi.call("epg_pair_finish", _ptr(a), _ptr(b), R, S, _ptr(delta), _ptr(dist), _stream())
+    return delta, dist
+
+
+def quiescent(XA, NA, XB, NB, qstate):
+    R, ldxa = _check_states(XA, NA)
+    R2, ldxb = _check_states(XB, NB)
+    if R != R2:
+        raise ValueError("paired inputs must have the same number of bins")
+    mask = torch.empty(R, dtype=torch.uint8, device=XA.device)
+    _abi.call("epg_quiescent", _ptr(XA), NA, ldxa, _ptr(XB), NB, ldxb, R, qstate, _ptr(mask), _stream())
+    return mask
+
+
+def null_hist(XA, NA, XB, NB, S, ga, gb, seed, row0=0):
+    R, ldxa = _check_states(XA, NA)
+    _, ldxb = _check_states(XB, NB)
+    HA = torch.empty((R, S), dtype=torch.int16, device=XA.device)
+    HB = torch.empty((R, S), dtype=torch.int16, device=XA.device)
+    _abi.call("epg_null_hist", _ptr(XA), NA, ldxa, _ptr(XB), NB, ldxb, R, S, ga, gb, seed, row0, _ptr(HA), _ptr(HB),
+              _stream())
+    return HA, HB
+
+
+def hist_to_numpy(H):
+    """int16-stored uint16 histogram tensor -> numpy uint16."""
+    return H.cpu().numpy().view(np.uint16)

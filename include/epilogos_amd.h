@@ -1,0 +1,121 @@
+/*
+ * epilogos_amd.h -- C ABI of libepilogos_hip.so, the MI355X (gfx950) scoring engine for epilogos.
+ *
+ * This is the drop-in boundary for the reference's scoring hot path.  The reference (meuleman/epilogos) is pure
+ * Python and has no FFI; the path sits behind three Python entry points
+ *     expected.main            (epilogos/expected.py:11)
+ *     expectedCombination.main (epilogos/expectedCombination.py:9)
+ *     scores.main              (epilogos/scores.py:14)
+ * whose per-chunk arithmetic kernels are the functions cited on each prototype below.  A maintainer binds these
+ * symbols with ctypes (see INTEGRATION.md for the stub); epilogos_amd/_abi.py is that binding in this repo.
+ *
+ * Conventions
+ *   - Every function returns EPG_OK (0) or a negative EPG_ERR_* code; epg_last_error() returns a thread-local message.
+ *   - Caller owns every buffer.  The library allocates nothing, retains no pointer after the call returns, and
+ *     enqueues its kernels on `stream` (a hipStream_t; NULL = the default stream).  Calls are asynchronous with
+ *     respect to the host: synchronise the stream before reading results.
+ *   - All data pointers are DEVICE pointers (e.g. torch.Tensor.data_ptr() of a tensor on the current HIP device).
+ *     There is no host/CPU implementation behind this ABI: without a HIP device the calls fail with EPG_ERR_HIP.
+ *   - X is the state matrix: row-major int8 [R, ldx], one row per genomic bin, one byte per biosample, 0-based
+ *     states (file value - 1, helpers.py:154-155); only the first N bytes of a row are read as states
+ *     (ldx >= N; the fast path wants X and ldx 16-byte aligned, any ldx >= N is accepted).  A byte outside
+ *     [0, S) is not counted in any state (the expected pass detects it: sum(counts) != R*N).
+ *   - `counts` outputs ACCUMULATE (+=) so that per-chromosome calls sum into one vector exactly like
+ *     expectedCombination.py:30-35; zero them first.  They are what the single RCCL all-reduce runs on.
+ *   - One host thread per device; calls on different devices/streams are independent.
+ *
+ * Limits of this build: 1 <= S <= 31 for the S1/S2 paths (ChromHMM models in the reference: 15, 18, 25),
+ * N <= 65535 (per-bin counts are stored as uint16).
+ */
+#ifndef EPILOGOS_AMD_H
+#define EPILOGOS_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EPG_OK 0
+#define EPG_ERR_INVALID_ARG (-1)
+#define EPG_ERR_UNSUPPORTED (-2)
+#define EPG_ERR_HIP (-3)
+#define EPG_ERR_WORKSPACE (-4)
+
+#define EPG_ABI_VERSION 1
+
+int epg_version(void);
+const char* epg_last_error(void);
+/* Number of compute units of the current device (used by callers to size nothing; informational) or <0. */
+int epg_device_cus(void);
+
+/* ---- per-bin histogram: the HBM-streaming kernel everything in S1/S2 is built on ---------------------------
+ * H[b, s] = #{n < N : X[b, n] == s} as uint16 [R, S]  (what np.unique(dataArr[row], return_counts=True) yields:
+ * scores.py:341 rowObsS1, scores.py:444 rowObsS2, expected.py:152 s2Calc).
+ * counts[s] += sum_b H[b, s]  (expected.py:106-113 s1Calc).  H or counts may be NULL. */
+int epg_bin_hist(const int8_t* X, int64_t R, int32_t N, int64_t ldx, int32_t S,
+                 uint16_t* H, int64_t* counts, void* stream);
+
+/* ---- expected-frequency pass (STEP 1) ---------------------------------------------------------------------
+ * S1: counts[S]   += state counts                                   -- expected.py:90-116  s1Calc
+ * S2: counts[S*S] += sum_b h_i*h_j (i != j), h_i*(h_i-1) (i == j)   -- expected.py:119-162 s2Calc
+ * S3: counts[N*N*S*S] (int32) += #{b : X[b,a]==i and X[b,c]==j}, a != c  -- expected.py:165-204 s3Calc */
+int epg_hist_s1(const int8_t* X, int64_t R, int32_t N, int64_t ldx, int32_t S, int64_t* counts, void* stream);
+int epg_hist_s2(const int8_t* X, int64_t R, int32_t N, int64_t ldx, int32_t S, int64_t* counts,
+                void* ws, int64_t ws_bytes, void* stream);
+int epg_hist_s2_from_binhist(const uint16_t* H, int64_t R, int32_t S, int64_t* counts, void* stream);
+int epg_hist_s3(const int8_t* X, int64_t R, int32_t N, int64_t ldx, int32_t S, int32_t* counts,
+                void* ws, int64_t ws_bytes, void* stream);
+
+/* ---- combination / normalisation (STEP 2) -------------------------------------------------------------------
+ * q[k] = (float) ( (double) counts[k] / (double) sum(counts) )      -- expectedCombination.py:42
+ * (the sum over files / ranks happens before this call: += accumulation and the RCCL all-reduce). */
+int epg_normalise_i64(const int64_t* counts, int64_t n, float* q, void* ws, int64_t ws_bytes, void* stream);
+int epg_normalise_i32(const int32_t* counts, int64_t n, float* q, void* ws, int64_t ws_bytes, void* stream);
+
+/* ---- score pass (STEP 3) ------------------------------------------------------------------------------------
+ * Workspace size in bytes for the score calls of a given saliency (device memory, caller-allocated). */
+int64_t epg_ws_bytes(int32_t saliency, int64_t R, int32_t N, int32_t S);
+
+/* S1: score[b, s] = kl(h[b,s]/N, q[s]), kl(p, q) = p*log2(p/q), 0 where q == 0 or p == 0
+ *     -- scores.py:259-344 s1Score/rowObsS1 and scores.py:539-550 klScoreND.
+ * out64 (double [R,S], the value before the reference's float32 store) and/or out32 (float [R,S], the value the
+ * reference stores, scores.py:144,317); either may be NULL. */
+int epg_score_s1(const int8_t* X, int64_t R, int32_t N, int64_t ldx, int32_t S, const float* q,
+                 double* out64, float* out32, void* ws, int64_t ws_bytes, void* stream);
+/* Same from cached per-bin histograms; N is the divisor (group width, scores.py:343). */
+int epg_score_s1_from_binhist(const uint16_t* H, int64_t R, int32_t N, int32_t S, const float* q,
+                              double* out64, float* out32, void* ws, int64_t ws_bytes, void* stream);
+
+/* S2: p[i,j] = (h_i*h_j - [i==j]*h_i) / perms, score[b, j] = sum_i kl(p[i,j], q[i,j]) in ascending i
+ *     -- scores.py:347-452 s2Score/rowObsS2.  perms = N*(N-1) of the ORIGINAL group (scores.py:371,397-398). */
+int epg_score_s2(const int8_t* X, int64_t R, int32_t N, int64_t ldx, int32_t S, int64_t perms, const float* q,
+                 double* out64, float* out32, void* ws, int64_t ws_bytes, void* stream);
+/* From cached histograms; N = number of columns H was counted over (upper bound of any count). */
+int epg_score_s2_from_binhist(const uint16_t* H, int64_t R, int32_t N, int32_t S, int64_t perms, const float* q,
+                              double* out64, float* out32, void* ws, int64_t ws_bytes, void* stream);
+
+/* S3: T = kl(float32(1)/(N*(N-1)), q) in float32; score[b, s] = sum_{c: X[b,c]==s} sum_{a != c} T[a,c,X[b,a],s]
+ *     -- scores.py:455-506 s3Score (float64 accumulation here; see DESIGN.md for the tolerance). */
+int epg_score_s3(const int8_t* X, int64_t R, int32_t N, int64_t ldx, int32_t S, const float* q,
+                 double* out64, float* out32, void* ws, int64_t ws_bytes, void* stream);
+
+/* ---- paired mode extras ---------------------------------------------------------------------------------------
+ * delta = a - b (float32); signed_sqdist[b] = sum_s delta^2 * sign(sum_s delta)   -- scores.py:223-232
+ * (signed_sqdist may be NULL). */
+int epg_pair_finish(const float* a, const float* b, int64_t R, int32_t S, float* delta, float* signed_sqdist,
+                    void* stream);
+/* mask[b] = all(XA[b,:]==qstate) && all(XB[b,:]==qstate)                          -- scores.py:294-303 */
+int epg_quiescent(const int8_t* XA, int32_t NA, int64_t ldxa, const int8_t* XB, int32_t NB, int64_t ldxb,
+                  int64_t R, int32_t qstate, uint8_t* mask, void* stream);
+/* Per-row uniform shuffle of the concatenation [A|B] (helpers.py:183-184: argsort of i.i.d. uniforms), written
+ * as per-bin histograms of the two null halves: HA from the first `ga` shuffled columns, HB from the next `gb`
+ * (helpers.py:190-194).  Philox4x32 keyed by (seed, row): reproducible, independent of the launch geometry. */
+int epg_null_hist(const int8_t* XA, int32_t NA, int64_t ldxa, const int8_t* XB, int32_t NB, int64_t ldxb,
+                  int64_t R, int32_t S, int32_t ga, int32_t gb, uint64_t seed, int64_t row0,
+                  uint16_t* HA, uint16_t* HB, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EPILOGOS_AMD_H */

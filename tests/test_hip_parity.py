@@ -1,0 +1,266 @@
+"""GPU parity: the HIP kernels (through the C ABI) against the oracle and the reference's golden vectors.
+Integers bit-exact; float64 KL scores within 1e-6 relative (BASELINE.json north_star) -- asserted much tighter."""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+
+from oracle import oracle_np as onp
+from tests.conftest import synth_states
+
+pytestmark = pytest.mark.gpu
+
+S = 18
+RTOL = 1e-6          # the bar north_star states for float64 KL scores
+RTOL_TIGHT = 1e-11   # what the kernels actually achieve (device log2 vs numpy log2)
+ATOL = 1e-12
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from epilogos_amd import engine
+    engine.require_gpu()
+    return engine
+
+
+def _np(t):
+    return t.cpu().numpy()
+
+
+def _unaligned_states(x, offset=1):
+    """Device view with ldx == N and a base pointer that is not 16-byte aligned."""
+    R, N = x.shape
+    flat = torch.full((R * N + offset + 64,), -1, dtype=torch.int8, device="cuda")
+    flat[offset:offset + R * N] = torch.from_numpy(np.ascontiguousarray(x).astype(np.int8)).reshape(-1).cuda()
+    return flat[offset:offset + R * N].view(R, N)
+
+
+# ---------------------------------------------------------------------------------------------- K1 histogram
+@pytest.mark.parametrize("N", [1, 2, 10, 15, 16, 17, 31, 33, 127, 128, 129, 379, 833, 896, 897, 1100])
+@pytest.mark.parametrize("R", [1, 17, 1000])
+def test_bin_hist_shapes(eng, N, R):
+    x = synth_states(R, N, seed=N * 7 + R)
+    X = eng.states_to_device(x)
+    H, counts = eng.bin_hist(X, N, S)
+    h_ref = onp.bin_hist(x, S)
+    assert np.array_equal(eng.hist_to_numpy(H).astype(np.int64), h_ref)
+    assert np.array_equal(_np(counts), h_ref.sum(axis=0))
+    # counts accumulate (+=), like the per-file sum of expectedCombination.py:30-35
+    eng.bin_hist(X, N, S, want_hist=False, counts=counts)
+    assert np.array_equal(_np(counts), 2 * h_ref.sum(axis=0))
+
+
+@pytest.mark.parametrize("N,R", [(10, 333), (833, 257), (100, 64), (16, 5), (7, 1)])
+@pytest.mark.parametrize("offset", [1, 3, 8])
+def test_bin_hist_unaligned_packed_rows(eng, N, R, offset):
+    x = synth_states(R, N, seed=N + R + offset, uniform=True)
+    X = _unaligned_states(x, offset)
+    assert X.stride(0) == N
+    H, counts = eng.bin_hist(X, N, S)
+    h_ref = onp.bin_hist(x, S)
+    assert np.array_equal(eng.hist_to_numpy(H).astype(np.int64), h_ref)
+    assert np.array_equal(_np(counts), h_ref.sum(axis=0))
+
+
+@pytest.mark.parametrize("S_", [15, 25, 7, 31, 2])
+def test_bin_hist_other_state_models(eng, S_):
+    x = synth_states(777, 127, S=S_, seed=S_, uniform=True)
+    X = eng.states_to_device(x)
+    H, counts = eng.bin_hist(X, 127, S_)
+    h_ref = onp.bin_hist(x, S_)
+    assert np.array_equal(eng.hist_to_numpy(H).astype(np.int64), h_ref)
+    assert np.array_equal(_np(counts), h_ref.sum(axis=0))
+
+
+def test_bin_hist_ignores_invalid_states(eng):
+    x = synth_states(100, 50, seed=5)
+    x[3, 7] = -1      # a 0 in the input file
+    x[9, 0] = 18      # state beyond the model
+    X = eng.states_to_device(x)
+    H, counts = eng.bin_hist(X, 50, S)
+    h = eng.hist_to_numpy(H).astype(np.int64)
+    assert h[3].sum() == 49 and h[9].sum() == 49 and h.sum() == 100 * 50 - 2
+    assert int(_np(counts).sum()) == 100 * 50 - 2
+
+
+def test_bin_hist_skewed_and_extreme(eng):
+    # all-one-state bins (max count = N) and a maximum-width count
+    x = np.full((64, 833), 17, dtype=np.int8)
+    x[1] = 0
+    x[2, ::2] = 5
+    X = eng.states_to_device(x)
+    H, counts = eng.bin_hist(X, 833, S)
+    assert np.array_equal(eng.hist_to_numpy(H).astype(np.int64), onp.bin_hist(x, S))
+
+
+def test_empty_input(eng):
+    X = eng.alloc_states(0, 833)
+    H, counts = eng.bin_hist(X, 833, S)
+    assert H.shape == (0, S) and int(_np(counts).sum()) == 0
+
+
+# ---------------------------------------------------------------------------------------------- S1
+def _s1_check(eng, x, q_np, g64=None, g32=None):
+    N = x.shape[1]
+    X = eng.states_to_device(x)
+    q = torch.from_numpy(q_np).cuda()
+    o32, o64 = eng.score_s1(X, N, S, q, want32=True, want64=True)
+    ref64 = onp.score_s1(x, q_np, S)
+    np.testing.assert_allclose(_np(o64), ref64, rtol=RTOL_TIGHT, atol=1e-15)
+    if g64 is not None:
+        np.testing.assert_allclose(_np(o64), g64, rtol=RTOL_TIGHT, atol=1e-15)
+    # float32 as stored: the float32 rounding of a value within 1e-11 of the reference's float64
+    np.testing.assert_allclose(_np(o32), ref64.astype(np.float32), rtol=2e-7, atol=0)
+    if g32 is not None:
+        np.testing.assert_allclose(_np(o32), g32, rtol=2e-7, atol=0)
+    # cached-histogram route gives the identical bits
+    H, _ = eng.bin_hist(X, N, S)
+    h32, h64 = eng.score_s1_from_binhist(H, N, S, q, want32=True, want64=True)
+    assert torch.equal(h32, o32) and torch.equal(h64, o64)
+    return _np(o32), _np(o64)
+
+
+def test_s1_golden_real_slice(eng, golden_real):
+    g = golden_real
+    x = g["x"]
+    X = eng.states_to_device(x)
+    _, counts = eng.bin_hist(X, x.shape[1], S, want_hist=False)
+    assert np.array_equal(_np(counts), g["s1_counts"])
+    q = eng.normalise(counts)
+    assert np.array_equal(_np(q), g["s1_exp"])          # bit-exact float32 exp_freq
+    o32, o64 = _s1_check(eng, x, g["s1_exp"], g["s1_f64"], g["s1_f32"])
+    print("S1 real slice: float32 bit-exact rows: %d / %d" % ((o32 == g["s1_f32"]).all(axis=1).sum(), o32.shape[0]))
+
+
+def test_s1_golden_synth833(eng, golden_synth):
+    g = golden_synth
+    x = g["x"]
+    X = eng.states_to_device(x)
+    _, counts = eng.bin_hist(X, 833, S, want_hist=False)
+    assert np.array_equal(_np(counts), g["s1_counts"])
+    assert np.array_equal(_np(eng.normalise(counts)), g["s1_exp"])
+    _s1_check(eng, x, g["s1_exp"], g["s1_f64"], g["s1_f32"])
+
+
+def test_s1_edge_q_zero_and_all_states(eng, golden_edge):
+    g = golden_edge
+    X = eng.states_to_device(g["q0_probe"])
+    q = torch.from_numpy(g["q0_exp"]).cuda()
+    _, o64 = eng.score_s1(X, g["q0_probe"].shape[1], S, q, want32=False, want64=True)
+    np.testing.assert_allclose(_np(o64), g["q0_probe_f64"], rtol=RTOL_TIGHT, atol=1e-15)
+    assert _np(o64)[0, 3] == 0.0                         # q == 0 -> masked to 0, not inf/nan
+    _s1_check(eng, g["all_x"], g["all_exp"], g["all_f64"], g["all_f32"])
+    _s1_check(eng, g["n2_x"], g["n2_s1_exp"], g["n2_s1_f64"], g["n2_s1_f32"])
+
+
+@pytest.mark.parametrize("N,R", [(379, 3000), (342, 1025), (1100, 300), (64, 4096)])
+def test_s1_random_vs_oracle(eng, N, R):
+    x = synth_states(R, N, seed=N)
+    q = onp.normalise(onp.expected_s1(x, S))
+    _s1_check(eng, x, q)
+
+
+def test_s1_unaligned(eng):
+    x = synth_states(501, 833, seed=11)
+    q_np = onp.normalise(onp.expected_s1(x, S))
+    X = _unaligned_states(x, 5)
+    q = torch.from_numpy(q_np).cuda()
+    o32, o64 = eng.score_s1(X, 833, S, q, want32=True, want64=True)
+    np.testing.assert_allclose(_np(o64), onp.score_s1(x, q_np, S), rtol=RTOL_TIGHT, atol=1e-15)
+
+
+def test_s1_meets_north_star_tolerance(eng, golden_synth):
+    g = golden_synth
+    X = eng.states_to_device(g["x"])
+    q = torch.from_numpy(g["s1_exp"]).cuda()
+    _, o64 = eng.score_s1(X, 833, S, q, want32=False, want64=True)
+    np.testing.assert_allclose(_np(o64), g["s1_f64"], rtol=RTOL, atol=0)
+
+
+# ---------------------------------------------------------------------------------------------- S2
+def _s2_check(eng, x, q_np, g64=None, g32=None, perms=None):
+    N = x.shape[1]
+    X = eng.states_to_device(x)
+    q = torch.from_numpy(np.ascontiguousarray(q_np).reshape(-1)).cuda()
+    o32, o64 = eng.score_s2(X, N, S, q, perms=perms, want32=True, want64=True)
+    ref64 = onp.score_s2(x, q_np, S, perms=perms)
+    np.testing.assert_allclose(_np(o64), ref64, rtol=RTOL, atol=ATOL)
+    if g64 is not None:
+        np.testing.assert_allclose(_np(o64), g64, rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(_np(o32), ref64.astype(np.float32), rtol=3e-7, atol=ATOL)
+    if g32 is not None:
+        np.testing.assert_allclose(_np(o32), g32, rtol=3e-7, atol=ATOL)
+    err = np.abs(_np(o64) - ref64) / np.maximum(np.abs(ref64), 1e-300)
+    return float(np.max(np.where(np.abs(ref64) > 1e-9, err, 0)))
+
+
+def test_s2_counts_golden(eng, golden_real, golden_synth):
+    for g in (golden_real, golden_synth):
+        x = g["x"]
+        X = eng.states_to_device(x)
+        H, _ = eng.bin_hist(X, x.shape[1], S)
+        c2 = eng.hist_s2_from_binhist(H, S)
+        assert np.array_equal(_np(c2).reshape(S, S), g["s2_counts"])
+        assert np.array_equal(_np(eng.normalise(c2)).reshape(S, S), g["s2_exp"])
+
+
+def test_s2_score_golden(eng, golden_real, golden_synth):
+    e1 = _s2_check(eng, golden_real["x"], golden_real["s2_exp"], golden_real["s2_f64"], golden_real["s2_f32"])
+    e2 = _s2_check(eng, golden_synth["x"], golden_synth["s2_exp"], golden_synth["s2_f64"], golden_synth["s2_f32"])
+    print("S2 max rel err vs oracle: real %.3g synth833 %.3g" % (e1, e2))
+
+
+def test_s2_edge(eng, golden_edge):
+    g = golden_edge
+    _s2_check(eng, g["q0_x"], g["q0_s2_exp"], g["q0_s2_f64"], g["q0_s2_f32"])
+    _s2_check(eng, g["n2_x"], g["n2_s2_exp"], g["n2_s2_f64"], g["n2_s2_f32"])
+
+
+@pytest.mark.parametrize("N,R", [(379, 2000), (833, 700), (40, 3001)])
+def test_s2_random_vs_oracle(eng, N, R):
+    x = synth_states(R, N, seed=N + 1)
+    c2 = onp.expected_s2(x, S)
+    X = eng.states_to_device(x)
+    H, _ = eng.bin_hist(X, N, S)
+    assert np.array_equal(_np(eng.hist_s2_from_binhist(H, S)).reshape(S, S), c2)
+    _s2_check(eng, x, onp.normalise(c2))
+
+
+# ---------------------------------------------------------------------------------------------- paired extras
+def test_pair_finish_and_quiescent(eng, golden_pair):
+    g = golden_pair
+    for sal in (1, 2):
+        p = "s%d_" % sal
+        a = torch.from_numpy(g[p + "a"]).cuda()
+        b = torch.from_numpy(g[p + "b"]).cuda()
+        delta, _ = eng.pair_finish(a, b)
+        assert np.array_equal(_np(delta), g[p + "delta"])
+        na = torch.from_numpy(g[p + "na"]).cuda()
+        nb = torch.from_numpy(g[p + "nb"]).cuda()
+        _, dist = eng.pair_finish(na, nb)
+        assert np.array_equal(_np(dist), g[p + "null_dist"])       # float32, numpy's summation order
+    XA = eng.states_to_device(g["xa"])
+    XB = eng.states_to_device(g["xb"])
+    m = eng.quiescent(XA, 5, XB, 5, int(g["qstate"]))
+    assert np.array_equal(_np(m).astype(bool), g["s1_quiescent"])
+    assert not _np(eng.quiescent(XA, 5, XB, 5, -1)).any()
+
+
+def test_paired_scores_golden(eng, golden_pair):
+    g = golden_pair
+    xa, xb = g["xa"], g["xb"]
+    comb = np.concatenate([xa, xb], axis=1)
+    XC = eng.states_to_device(comb)
+    H, counts = eng.bin_hist(XC, 10, S)
+    assert np.array_equal(_np(counts), g["s1_counts"])
+    q1 = eng.normalise(counts)
+    assert np.array_equal(_np(q1), g["s1_exp"])
+    c2 = eng.hist_s2_from_binhist(H, S)
+    assert np.array_equal(_np(c2).reshape(S, S), g["s2_counts"])
+    q2 = eng.normalise(c2)
+    for xs, key in ((xa, "a"), (xb, "b")):
+        X = eng.states_to_device(xs)
+        o32, _ = eng.score_s1(X, 5, S, q1)
+        np.testing.assert_allclose(_np(o32), g["s1_" + key], rtol=2e-7, atol=0)
+        o32, _ = eng.score_s2(X, 5, S, q2)
+        np.testing.assert_allclose(_np(o32), g["s2_" + key], rtol=3e-7, atol=ATOL)
