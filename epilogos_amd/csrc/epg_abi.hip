@@ -49,7 +49,16 @@ int null_hist_impl(const int8_t*, int32_t, int64_t, const int8_t*, int32_t, int6
 
 using namespace epg;
 
+namespace epg { extern int g_variant; extern int g_blocks_per_cu; }
+
 extern "C" {
+
+// tuning hook for A/B experiments (not part of the public header): kernel variant and persistent-grid size
+int epg_debug_set_variant(int variant, int blocks_per_cu) {
+    if (variant >= 0) epg::g_variant = variant;
+    if (blocks_per_cu > 0) epg::g_blocks_per_cu = blocks_per_cu;
+    return EPG_OK;
+}
 
 int epg_version(void) { return EPG_ABI_VERSION; }
 const char* epg_last_error(void) { return g_err; }

@@ -8,69 +8,72 @@ namespace epg {
 // K1: X[R, ldx] int8 -> H[R, S] uint16 (+ counts[S] += column sums).  HBM-bound: N bytes read, 2*S written per bin.
 // Restates np.unique(row, return_counts=True) of scores.py:341/444 and expected.py:111-113,152.
 // ---------------------------------------------------------------------------------------------------------------
-template <int S, int NG>
+template <int S, int NG, int PIPE>
 __global__ __launch_bounds__(256) void k_bin_hist(const char* __restrict__ X, long R, int N, long ldx,
                                                    u16* __restrict__ H, u64* __restrict__ counts) {
-    __shared__ u64 s_cnt[S];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int j = lane & 3, b = lane >> 2;
-    const RowGeom g = make_geom(N);
-    if (threadIdx.x < S) s_cnt[threadIdx.x] = 0;
+    __shared__ u64 s_cnt[S + 1];
+    constexpr int ND = (S + 1) / 2;
+    const int j = threadIdx.x & 3;
+    if (threadIdx.x <= S) s_cnt[threadIdx.x] = 0;
+    __syncthreads();
 
-    u32 acc[S];
+    // running state counts of this lane's bins, as packed uint16 pairs; flushed to LDS before a half can overflow
+    u32 accp[ND];
 #pragma unroll
-    for (int s = 0; s < S; ++s) acc[s] = 0;
-
-    const long ntiles = (R + 15) >> 4;
-    for (long tile = (long)blockIdx.x * 4 + wave; tile < ntiles; tile += (long)gridDim.x * 4) {
-        const long row = tile * 16 + b;
-        const bool valid = row < R;
-        const long rowc = valid ? row : R - 1;
-        u32 cnt[S];
+    for (int m = 0; m < ND; ++m) accp[m] = 0;
+    const int flush_every = 65535 / N > 1 ? 65535 / N - 1 : 1;
+    int since = 0;
+    auto flush = [&]() {
+        if (j == 0) {
 #pragma unroll
-        for (int s = 0; s < S; ++s) cnt[s] = 0;
-        count_row<S, NG>(X + rowc * ldx, j, g, cnt);
-#pragma unroll
-        for (int s = 0; s < S; ++s) cnt[s] = quad_sum(cnt[s]);
-        if (valid) {
-            if (counts) {
-#pragma unroll
-                for (int s = 0; s < S; ++s) acc[s] += cnt[s];
+            for (int m = 0; m < ND; ++m) {
+                const u32 lo = accp[m] & 0xffffu, hi = accp[m] >> 16;
+                if (lo) atomicAdd(&s_cnt[2 * m], (u64)lo);
+                if (hi) atomicAdd(&s_cnt[2 * m + 1], (u64)hi);
             }
-            if (H) {
-                // 2*S bytes per bin; S even -> S/2 dwords, spread over the quad (dword m to lane m & 3)
-                u16* hrow = H + row * S;
-                if constexpr ((S & 1) == 0) {
-                    constexpr int ND = S / 2;
-                    u32 d[ND + 3];
+        }
 #pragma unroll
-                    for (int m = 0; m < ND; ++m) d[m] = cnt[2 * m] | (cnt[2 * m + 1] << 16);
+        for (int m = 0; m < ND; ++m) accp[m] = 0;
+        since = 0;
+    };
+
+    auto epilogue = [&](long row, bool valid, u32 (&cnt)[S]) {
+        u32 d[ND];
+        pack_reduce<S>(cnt, d);
+        if (counts) {
 #pragma unroll
-                    for (int m = ND; m < ND + 3; ++m) d[m] = 0;
-                    u32* hp = reinterpret_cast<u32*>(hrow);
+            for (int m = 0; m < ND; ++m) accp[m] += valid ? d[m] : 0u;
+            if (++since >= flush_every) flush();
+        }
+        if (H && valid) {
+            u16* hrow = H + row * S;
+            if constexpr ((S & 1) == 0) {
+                // 2*S bytes per bin = ND dwords, dword m written by quad lane m & 3
+                u32* hp = reinterpret_cast<u32*>(hrow);
 #pragma unroll
-                    for (int k = 0; k < (ND + 3) / 4; ++k) {
-                        const u32 v = sel4(d[4 * k], d[4 * k + 1], d[4 * k + 2], d[4 * k + 3], j);
-                        if (4 * k + j < ND) hp[4 * k + j] = v;
-                    }
-                } else {
+                for (int k = 0; k < (ND + 3) / 4; ++k) {
+                    const u32 v = sel4(d[4 * k], 4 * k + 1 < ND ? d[4 * k + 1] : 0u, 4 * k + 2 < ND ? d[4 * k + 2] : 0u,
+                                       4 * k + 3 < ND ? d[4 * k + 3] : 0u, j);
+                    if (4 * k + j < ND) hp[4 * k + j] = v;
+                }
+            } else {
+                // odd S: rows are only 2-byte aligned, store uint16 s = 4k + j
 #pragma unroll
-                    for (int k = 0; k < (S + 3) / 4; ++k) {
-                        const u32 v = sel4(cnt[4 * k], 4 * k + 1 < S ? cnt[4 * k + 1] : 0u,
-                                           4 * k + 2 < S ? cnt[4 * k + 2] : 0u, 4 * k + 3 < S ? cnt[4 * k + 3] : 0u, j);
-                        if (4 * k + j < S) hrow[4 * k + j] = (u16)v;
-                    }
+                for (int k = 0; k < (S + 3) / 4; ++k) {
+                    const u32 v = (j & 2) ? (2 * k + 1 < ND ? d[2 * k + 1] : 0u) : d[2 * k];
+                    const u32 c = (j & 1) ? v >> 16 : v & 0xffffu;
+                    if (4 * k + j < S) hrow[4 * k + j] = (u16)c;
                 }
             }
         }
-    }
+    };
+    if constexpr (PIPE > 0 && NG > 0)
+        tile_loop_pipelined<S, NG, PIPE - 1>(X, R, N, ldx, epilogue);
+    else
+        tile_loop_simple<S, NG>(X, R, N, ldx, epilogue);
+
     if (counts) {
-        __syncthreads();
-        if (j == 0) {
-#pragma unroll
-            for (int s = 0; s < S; ++s)
-                if (acc[s]) atomicAdd(&s_cnt[s], (u64)acc[s]);
-        }
+        flush();
         __syncthreads();
         if (threadIdx.x < S && s_cnt[threadIdx.x]) atomicAdd(&counts[threadIdx.x], s_cnt[threadIdx.x]);
     }
@@ -117,34 +120,28 @@ __global__ void k_s1_table(const float* __restrict__ q, int N, int S, double* __
 // ---------------------------------------------------------------------------------------------------------------
 // S1 score straight from the state matrix: N bytes read + S*sizeof(OT) written per bin (scores.py:309-317).
 // ---------------------------------------------------------------------------------------------------------------
-template <int S, int NG, typename OT>
+template <int S, int NG, typename OT, bool PIPE>
 __global__ __launch_bounds__(256) void k_score_s1(const char* __restrict__ X, long R, int N, long ldx,
                                                    const OT* __restrict__ T, OT* __restrict__ out) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int j = lane & 3, b = lane >> 2;
-    const RowGeom g = make_geom(N);
-    const long ntiles = (R + 15) >> 4;
-    for (long tile = (long)blockIdx.x * 4 + wave; tile < ntiles; tile += (long)gridDim.x * 4) {
-        const long row = tile * 16 + b;
-        const bool valid = row < R;
-        const long rowc = valid ? row : R - 1;
-        u32 cnt[S];
+    constexpr int ND = (S + 1) / 2;
+    const int j = threadIdx.x & 3;
+    auto epilogue = [&](long row, bool valid, u32 (&cnt)[S]) {
+        u32 d[ND];
+        pack_reduce<S>(cnt, d);
+        if (!valid) return;
+        OT* orow = out + row * S;
 #pragma unroll
-        for (int s = 0; s < S; ++s) cnt[s] = 0;
-        count_row<S, NG>(X + rowc * ldx, j, g, cnt);
-#pragma unroll
-        for (int s = 0; s < S; ++s) cnt[s] = quad_sum(cnt[s]);
-        if (valid) {
-            OT* orow = out + row * S;
-#pragma unroll
-            for (int k = 0; k < (S + 3) / 4; ++k) {
-                const u32 c = sel4(cnt[4 * k], 4 * k + 1 < S ? cnt[4 * k + 1] : 0u, 4 * k + 2 < S ? cnt[4 * k + 2] : 0u,
-                                   4 * k + 3 < S ? cnt[4 * k + 3] : 0u, j);
-                const int s = 4 * k + j;
-                if (s < S) orow[s] = c ? T[(long)c * S + s] : (OT)0;
-            }
+        for (int k = 0; k < (S + 3) / 4; ++k) {
+            const u32 v = (j & 2) ? (2 * k + 1 < ND ? d[2 * k + 1] : 0u) : d[2 * k];
+            const u32 c = (j & 1) ? v >> 16 : v & 0xffffu;
+            const int s = 4 * k + j;
+            if (s < S) orow[s] = c ? T[(long)c * S + s] : (OT)0;
         }
-    }
+    };
+    if constexpr (PIPE && NG > 0)
+        tile_loop_pipelined<S, NG, 0>(X, R, N, ldx, epilogue);
+    else
+        tile_loop_simple<S, NG>(X, R, N, ldx, epilogue);
 }
 
 // S1 score from cached histograms: 2*S bytes read + S*sizeof(OT) written per bin.  8 elements per thread.
@@ -204,18 +201,24 @@ __global__ __launch_bounds__(256) void k_normalise(const IT* __restrict__ C, lon
 // ---------------------------------------------------------------------------------------------------------------
 // host-side dispatch
 // ---------------------------------------------------------------------------------------------------------------
+extern int g_blocks_per_cu;
 static int grid_for_tiles(long R) {
     const long ntiles = (R + 15) >> 4;
     long blocks = (ntiles + 3) / 4;
-    const long cap = (long)num_cus() * 8;
+    const long cap = (long)num_cus() * g_blocks_per_cu;
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
     return (int)blocks;
 }
 
+int g_variant = 0;  // tuning hook (epg_debug_set_variant): 0 = loads-up-front tile loop (fastest measured), 1 = software-pipelined
+int g_blocks_per_cu = 4;
+
 template <int S, int NG>
 static void launch_bin_hist(const char* X, long R, int N, long ldx, u16* H, u64* counts, hipStream_t st) {
-    hipLaunchKernelGGL((k_bin_hist<S, NG>), dim3(grid_for_tiles(R)), dim3(256), 0, st, X, R, N, ldx, H, counts);
+    const dim3 grid(grid_for_tiles(R)), block(256);
+    if (NG == 0 || g_variant == 0) hipLaunchKernelGGL((k_bin_hist<S, NG, 0>), grid, block, 0, st, X, R, N, ldx, H, counts);
+    else hipLaunchKernelGGL((k_bin_hist<S, NG, 1>), grid, block, 0, st, X, R, N, ldx, H, counts);
 }
 
 template <int S>
@@ -272,7 +275,10 @@ int bin_hist_impl(const int8_t* X8, int64_t R, int32_t N, int64_t ldx, int32_t S
 
 template <int S, int NG, typename OT>
 static void launch_score_s1(const char* X, long R, int N, long ldx, const OT* T, OT* out, hipStream_t st) {
-    hipLaunchKernelGGL((k_score_s1<S, NG, OT>), dim3(grid_for_tiles(R)), dim3(256), 0, st, X, R, N, ldx, T, out);
+    if (g_variant == 1 && NG > 0)
+        hipLaunchKernelGGL((k_score_s1<S, NG, OT, true>), dim3(grid_for_tiles(R)), dim3(256), 0, st, X, R, N, ldx, T, out);
+    else
+        hipLaunchKernelGGL((k_score_s1<S, NG, OT, false>), dim3(grid_for_tiles(R)), dim3(256), 0, st, X, R, N, ldx, T, out);
 }
 
 template <typename OT>
