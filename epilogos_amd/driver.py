@@ -1,0 +1,117 @@
+"""Genome-wide driver: replaces the reference's per-chromosome SLURM fan-out (run.py:190-279) with a contiguous
+bin-range partition across the GPUs of one node and a single all-reduce of the state-count array.
+
+The bins of all input files, concatenated in file order, are split with the reference's own splitRows rule
+(helpers.py:116-118): rank g of G owns global bins [g*R//G, (g+1)*R//G).  Pass 1 counts locally, one
+all-reduce(SUM) over torch.distributed (backend nccl = RCCL over xGMI on GPUs; gloo in the CPU tests) makes the
+counts global, every rank normalises identically, pass 2 scores locally with no further communication.  Integer
+sums make the result independent of G and of the reduction order.  Outputs keep the reference's names: every rank
+writes gzip members for its bin ranges and rank 0 concatenates them per chromosome (a multi-member gzip file is
+a valid gzip file)."""
+import gzip
+import os
+import shutil
+from pathlib import Path
+
+import numpy as np
+
+from . import backend as _backend
+from .helpers import countRows, fileStem, readLocations, readStates, splitRows
+from .scores import formatScores
+
+
+def plan_partition(rows_per_file, world):
+    """[(file_index, lo, hi)] per rank: rank ranges from splitRows on the concatenated bins, cut at file borders."""
+    total = int(sum(rows_per_file))
+    starts = np.concatenate([[0], np.cumsum(rows_per_file)]).astype(np.int64)
+    plans = []
+    for (g_lo, g_hi) in splitRows(total, world):
+        parts = []
+        for f, n in enumerate(rows_per_file):
+            lo, hi = max(g_lo, starts[f]), min(g_hi, starts[f + 1])
+            if lo < hi:
+                parts.append((f, int(lo - starts[f]), int(hi - starts[f])))
+        plans.append(parts)
+    return plans
+
+
+class _Dist:
+    """Thin wrapper so that the single-process case needs no process group."""
+
+    def __init__(self):
+        import torch.distributed as dist
+        self.dist = dist if dist.is_available() and dist.is_initialized() else None
+        self.rank = self.dist.get_rank() if self.dist else 0
+        self.world = self.dist.get_world_size() if self.dist else 1
+
+    def all_reduce_counts(self, counts, device=None):
+        """SUM-all-reduce an integer numpy array; on GPUs the tensor lives on the device so RCCL moves it over xGMI."""
+        if not self.dist:
+            return counts
+        import torch
+        t = torch.from_numpy(np.ascontiguousarray(counts))
+        if device is not None:
+            t = t.to(device)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        return t.cpu().numpy().reshape(counts.shape)
+
+    def barrier(self):
+        if self.dist:
+            self.dist.barrier()
+
+
+def run_single_group(files, numStates, saliency, outputDir, fileTag, verbose=False, backend=None, device=None):
+    """STEP 1-3 for a single group over `files` (one per chromosome).  Returns exp_freq (float32)."""
+    be = backend if backend is not None else _backend.get()
+    d = _Dist()
+    files = [Path(f) for f in files]
+    outputDir = Path(outputDir)
+    rows = [countRows(f) for f in files]
+    my_parts = plan_partition(rows, d.world)[d.rank]
+
+    # STEP 1: local counts over my bin ranges
+    counts, chunks = None, []
+    for (fi, lo, hi) in my_parts:
+        x = readStates(file1Path=files[fi], rowsToCalc=(lo, hi), verbose=verbose)
+        chunks.append(x)
+        c = be.expected_counts(x, numStates, saliency)
+        counts = c if counts is None else counts + c
+    if counts is None:   # a rank without bins still takes part in the collective
+        N = readStates(file1Path=files[0], rowsToCalc=(0, 1), verbose=False).shape[1]
+        shape = {1: (numStates,), 2: (numStates, numStates), 3: (N, N, numStates, numStates)}[saliency]
+        counts = np.zeros(shape, dtype=np.int32 if saliency == 3 else np.int64)
+    # the one exchange step
+    counts = d.all_reduce_counts(counts, device=device)
+    # STEP 2: identical normalisation on every rank
+    q = be.normalise(counts)
+    if d.rank == 0:
+        np.save(outputDir / "exp_freq_{}.npy".format(fileTag), q, allow_pickle=False)
+
+    # STEP 3: local scores, written as gzip members per (file, range)
+    for (fi, lo, hi), x in zip(my_parts, chunks):
+        sc = be.scores(x, numStates, saliency, q)
+        loc = readLocations(files[fi], (lo, hi))
+        stem = fileStem(files[fi])
+        part = outputDir / ".part_scores_{}_{}_{:012d}.gz".format(fileTag, stem, lo)
+        with gzip.open(part, "wt") as g:
+            g.write(formatScores(sc, loc))
+        np.save(outputDir / ".part_scores_{}_{}_{:012d}.npy".format(fileTag, stem, lo), sc, allow_pickle=False)
+    d.barrier()
+    if d.rank == 0:
+        for f in files:
+            stem = fileStem(f)
+            parts = sorted(outputDir.glob(".part_scores_{}_{}_*.gz".format(fileTag, stem)))
+            with open(outputDir / "scores_{}_{}.txt.gz".format(fileTag, stem), "wb") as out:
+                for p in parts:
+                    with open(p, "rb") as src:
+                        shutil.copyfileobj(src, out)
+                    os.remove(p)
+            arrs = []
+            for p in sorted(outputDir.glob(".part_scores_{}_{}_*.npy".format(fileTag, stem))):
+                arrs.append(np.load(p))
+                os.remove(p)
+            loc = readLocations(f)[:sum(a.shape[0] for a in arrs)]
+            np.savez_compressed(outputDir / "temp_scores_{}_{}.npz".format(fileTag, stem), chrName=np.array([loc[0, 0]]),
+                                scoreArr=np.concatenate(arrs, axis=0), locationArr=loc)
+    d.barrier()
+    return q

@@ -1,0 +1,173 @@
+"""`epilogos` command line for the MI355X engine: the option surface of the reference's epilogos/run.py
+(click options :18-73, checkFlags :328-375, checkArguments :378-451, fileTag/paths :158-165) for STEP 1-3.
+The per-chromosome SLURM submission (run.py:454-585) is replaced by a bin-range partition across the GPUs of the
+node (one process per GPU under torch.distributed.run; a single process when WORLD_SIZE is unset).  STEP 4 (regions
+of interest, p-values, plots) is outside this engine's scope: its inputs (scores_*.txt.gz, temp_scores_*.npz,
+pairwiseDelta_*, temp_nullDistances_*, temp_quiescence_*, exp_freq_*.npy) are written exactly as the reference does."""
+import os
+import re
+import sys
+from pathlib import Path, PurePath
+
+import click
+
+from . import __version__
+from .helpers import getNumStates
+
+
+def _natural_key(p):
+    return [int(t) if t.isdigit() else t for t in re.split(r"(\d+)", Path(p).name)]
+
+
+def checkArguments(mode, saliency, inputDirPath, inputDirPath2, outputDirPath, numProcesses, numStates, quiescentState,
+                   groupSize):
+    """Subset of reference run.py:378-451 relevant to STEP 1-3; same exceptions."""
+    if mode == "paired" and saliency == 3:
+        raise ValueError("Paired epilogos supports only a saliency of 1 or 2")
+    if saliency not in (1, 2, 3):
+        raise ValueError("Please ensure that saliency metric is either 1, 2, or 3")
+    for d in [inputDirPath] + ([inputDirPath2] if mode == "paired" else []):
+        if not d.exists():
+            raise FileNotFoundError("Given path does not exist: {}".format(str(d)))
+        if not d.is_dir():
+            raise NotADirectoryError("Given path is not a directory: {}".format(str(d)))
+        if not list(d.glob("*")):
+            raise OSError("Ensure that directory is not empty: {}".format(str(d)))
+    if outputDirPath == inputDirPath:
+        print("ERROR: Output directory cannot be the same as the input directory")
+        sys.exit()
+    if not outputDirPath.exists():
+        outputDirPath.mkdir(parents=True)
+    if not outputDirPath.is_dir():
+        raise NotADirectoryError("Given path is not a directory: {}".format(str(outputDirPath)))
+    if numProcesses < 0:
+        print("ERROR: Number of cores must be positive or zero (0 means use all cores)")
+        sys.exit()
+    if quiescentState >= numStates:
+        print("ERROR: Quiescent state must be a valid state (at most the number of states)")
+        sys.exit()
+    if groupSize < -1 or groupSize == 0:
+        print("ERROR: Group size must be positive")
+        sys.exit()
+
+
+@click.command(context_settings=dict(help_option_names=["-h", "--help"]))
+@click.option("-m", "--mode", "mode", type=click.Choice(["single", "paired"]), default="single", show_default=True,
+              help="single for single group epilogos and paired for 2 group epilogos")
+@click.option("-l", "--local", "commandLineBool", is_flag=True,
+              help="Run in this process (always the case for the GPU engine; accepted for compatibility)")
+@click.option("-i", "--input-directory", "inputDirectory", type=str, help="Directory with one matrix file per chromosome")
+@click.option("-a", "--directory-one", "inputDirectory1", type=str, help="First input directory (paired mode)")
+@click.option("-b", "--directory-two", "inputDirectory2", type=str, help="Second input directory (paired mode)")
+@click.option("-o", "--output-directory", "outputDirectory", type=str, help="Output directory")
+@click.option("-j", "--state-info", "stateInfo", type=str, help="State model info file")
+@click.option("-s", "--saliency", "saliency", type=int, default=1, show_default=True, help="Saliency level (1, 2, or 3)")
+@click.option("-c", "--num-cores", "numProcesses", type=int, default=1, help="Accepted for compatibility; ignored")
+@click.option("-x", "--exit", "exitBool", is_flag=True, help="SLURM-only flag; accepted and ignored")
+@click.option("-d", "--diagnostic-figures", "diagnosticBool", is_flag=True, help="STEP 4 flag; accepted and ignored")
+@click.option("-t", "--num-trials", "numTrials", type=int, default=101, help="STEP 4 flag; accepted and ignored")
+@click.option("-z", "--sampling-size", "samplingSize", type=int, default=100000, help="STEP 4 flag; accepted and ignored")
+@click.option("-q", "--quiescent-state", "quiescentState", type=int, default=-1,
+              help="1-based quiescent state for paired filtering; 0 disables it [default: last state]")
+@click.option("-g", "--group-size", "groupSize", type=int, default=-1, show_default=True,
+              help="Size of the shuffled null groups in paired mode (default: the input group sizes)")
+@click.option("-v", "--version", "version", is_flag=True, help="Print the version and exit")
+@click.option("-p", "--partition", "partition", type=str, help="SLURM-only flag; accepted and ignored")
+@click.option("-n", "--null-distribution", "pvalBool", is_flag=True, help="STEP 4 flag; accepted and ignored")
+@click.option("-w", "--roi-width", "roiWidth", type=int, default=0, help="STEP 4 flag; accepted and ignored")
+@click.option("-f", "--file-tag", "fileTag", type=str, default="null",
+              help="Tag appended to output filenames [default: input-directory_saliency]")
+@click.option("--exp-freq-mem", "expFreqMem", type=int, default=20000, help="SLURM-only; ignored")
+@click.option("--exp-comb-mem", "expCombMem", type=int, default=8000, help="SLURM-only; ignored")
+@click.option("--score-mem", "scoreMem", type=int, default=40000, help="SLURM-only; ignored")
+@click.option("--roi-mem", "roiMem", type=int, default=-1, help="SLURM-only; ignored")
+@click.option("--null-seed", "nullSeed", type=int, default=None, help="Seed for the paired-mode null shuffles (default: random)")
+def main(mode, commandLineBool, inputDirectory, inputDirectory1, inputDirectory2, outputDirectory, stateInfo, saliency,
+         numProcesses, exitBool, diagnosticBool, numTrials, samplingSize, quiescentState, groupSize, version, partition,
+         pvalBool, roiWidth, fileTag, expFreqMem, expCombMem, scoreMem, roiMem, nullSeed):
+    """Information-theoretic navigation of multi-tissue functional genomic annotations -- MI355X scoring engine."""
+    if version:
+        print("Version:", __version__)
+        sys.exit()
+    # flag combinations (reference run.py:328-375)
+    if mode == "single" and inputDirectory is None:
+        print("ERROR: [-i, --input-directory] is required in single mode"); sys.exit()
+    if mode == "single" and (inputDirectory1 is not None or inputDirectory2 is not None):
+        print("ERROR: [-a] and [-b] are only valid in paired mode"); sys.exit()
+    if mode == "paired" and (inputDirectory1 is None or inputDirectory2 is None):
+        print("ERROR: [-a, --directory-one] and [-b, --directory-two] are required in paired mode"); sys.exit()
+    if mode == "paired" and inputDirectory is not None:
+        print("ERROR: [-i] is only valid in single mode"); sys.exit()
+    if outputDirectory is None:
+        print("ERROR: [-o, --output-directory] is required"); sys.exit()
+    if stateInfo is None:
+        print("ERROR: [-j, --state-info] is required"); sys.exit()
+
+    numStates = getNumStates(stateInfo)
+    quiescentState = numStates - 1 if quiescentState == -1 else quiescentState - 1     # 1-based -> 0-based, 0 -> off
+    inputDirPath = Path(inputDirectory if mode == "single" else inputDirectory1)
+    inputDirPath2 = Path(inputDirectory2) if mode == "paired" else Path("")
+    if not PurePath(inputDirPath).is_absolute():
+        inputDirPath = Path.cwd() / inputDirPath
+    if mode == "paired" and not PurePath(inputDirPath2).is_absolute():
+        inputDirPath2 = Path.cwd() / inputDirPath2
+    outputDirPath = Path(outputDirectory)
+    if not PurePath(outputDirPath).is_absolute():
+        outputDirPath = Path.cwd() / outputDirPath
+    checkArguments(mode, saliency, inputDirPath, inputDirPath2, outputDirPath, numProcesses, numStates, quiescentState,
+                   groupSize)
+    if fileTag == "null":
+        fileTag = ("{}_s{}".format(inputDirPath.name, saliency) if mode == "single"
+                   else "{}_{}_s{}".format(inputDirPath.name, inputDirPath2.name, saliency))
+    storedExpPath = outputDirPath / "exp_freq_{}.npy".format(fileTag)
+
+    # one process per GPU when launched under torch.distributed.run
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+    device = None
+    if torch.cuda.is_available():
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+        device = torch.device("cuda", torch.cuda.current_device())
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl" if device is not None else "gloo")
+    rank = int(os.environ.get("RANK", "0"))
+    say = print if rank == 0 else (lambda *a, **k: None)
+
+    files = sorted(inputDirPath.glob("*"), key=_natural_key)
+    say("State Model =", numStates, " Saliency level =", saliency, " GPUs =", world)
+    if mode == "single":
+        from .driver import run_single_group
+        say("\nSTEP 1-3: background counts -> all-reduce -> scores (bin-range partition over %d GPU(s))" % world)
+        run_single_group(files, numStates, saliency, outputDirPath, fileTag, verbose=False, device=device)
+    else:
+        if world > 1:
+            raise click.UsageError("paired mode runs on one GPU in this build")
+        from . import scores as scores_mod
+        from .expected import main as expected
+        from .expectedCombination import main as expectedCombination
+        scores_mod.NULL_SEED = nullSeed
+        say("\nSTEP 1: Per data file background frequency calculation")
+        pairs = []
+        for file in files:
+            if not list(inputDirPath2.glob(file.name)):
+                raise FileNotFoundError("File not found: {}".format(str(inputDirPath2 / file.name)))
+            pairs.append((file, next(inputDirPath2.glob(file.name))))
+        for file, file2 in pairs:
+            expected(file, file2, numStates, saliency, outputDirPath, fileTag, numProcesses, False)
+        say("\nSTEP 2: Background frequency combination")
+        expectedCombination(outputDirPath, storedExpPath, fileTag, False)
+        say("\nSTEP 3: Score calculation")
+        for file, file2 in pairs:
+            scores_mod.main(file, file2, numStates, saliency, outputDirPath, storedExpPath, fileTag, numProcesses,
+                            quiescentState, groupSize, False)
+    say("\nSTEP 4 (regions of interest / p-values / figures) is not part of the GPU engine; its inputs are in",
+        outputDirPath)
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

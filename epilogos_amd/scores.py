@@ -1,0 +1,94 @@
+"""STEP 3 -- per-file scores.  Same call signature, argv form and on-disk artefacts as the reference's
+epilogos/scores.py (main :14-56, calculateScores :116-169, calculateScoresPairwise :172-256, writeScores :509-536):
+  single: scores_{tag}_{stem}.txt.gz and temp_scores_{tag}_{stem}.npz {chrName, scoreArr float32, locationArr object}
+  paired: pairwiseDelta_{tag}_{stem}.txt.gz, temp_nullDistances_{tag}_{stem}.npz, temp_quiescence_{tag}_{stem}.npz
+All arithmetic runs on the GPU through the C ABI."""
+import gzip
+from pathlib import Path
+from sys import argv
+from time import time
+
+import numpy as np
+
+from . import backend as _backend
+from .helpers import countRows, fileStem, readLocations, readStates, strToBool
+
+NULL_SEED = None   # paired nulls are unseeded in the reference (helpers.py:183); set an int for reproducible runs
+
+
+def main(file1, file2, numStates, saliency, outputDir, expFreqPath, fileTag, numProcesses, quiescentState, groupSize,
+         verbose):
+    if verbose: tTotal = time()
+    file1Path, file2Path, outputDirPath = Path(file1), Path(file2), Path(outputDir)
+    filename = fileStem(file1Path)
+    if not verbose: print("    {}\t".format(filename), end="", flush=True)
+    totalRows = countRows(file1Path)
+    if str(file2) == "null":
+        calculateScores(saliency, file1Path, totalRows, numStates, outputDirPath, expFreqPath, fileTag, filename, verbose)
+    else:
+        calculateScoresPairwise(saliency, file1Path, file2Path, totalRows, numStates, outputDirPath, expFreqPath,
+                                fileTag, filename, quiescentState, groupSize, verbose)
+    print("Total Time:", time() - tTotal, flush=True) if verbose else print("\t[Done]", flush=True)
+
+
+def calculateScores(saliency, file1Path, totalRows, numStates, outputDirPath, expFreqPath, fileTag, filename, verbose):
+    if saliency not in (1, 2, 3):
+        raise ValueError("Please ensure that saliency metric is either 1, 2, or 3")
+    expFreqArr = np.load(expFreqPath, allow_pickle=False)
+    dataArr = readStates(file1Path=file1Path, rowsToCalc=(0, totalRows), verbose=verbose)
+    scoreArr = _backend.get().scores(dataArr, numStates, saliency, expFreqArr)
+    locationArr = readLocations(file1Path)[:totalRows]
+    writeScores(scoreArr, outputDirPath / "scores_{}_{}.txt.gz".format(fileTag, filename), locationArr)
+    chrName = locationArr[0, 0]
+    np.savez_compressed(outputDirPath / "temp_scores_{}_{}.npz".format(fileTag, filename), chrName=np.array([chrName]),
+                        scoreArr=scoreArr, locationArr=locationArr)
+
+
+def calculateScoresPairwise(saliency, file1Path, file2Path, totalRows, numStates, outputDirPath, expFreqPath, fileTag,
+                            filename, quiescentState, groupSize, verbose):
+    if saliency not in (1, 2):
+        raise ValueError("Please ensure that saliency metric is either 1 or 2 for Pairwise Epilogos")
+    be = _backend.get()
+    expFreqArr = np.load(expFreqPath, allow_pickle=False)
+    file1Arr = readStates(file1Path=file1Path, rowsToCalc=(0, totalRows), verbose=verbose)
+    file2Arr = readStates(file1Path=file2Path, rowsToCalc=(0, totalRows), verbose=verbose)
+    n1, n2 = file1Arr.shape[1], file2Arr.shape[1]
+    perms1, perms2 = n1 * (n1 - 1), n2 * (n2 - 1)
+    score1 = be.scores(file1Arr, numStates, saliency, expFreqArr, perms=perms1)
+    score2 = be.scores(file2Arr, numStates, saliency, expFreqArr, perms=perms2)
+    seed = NULL_SEED if NULL_SEED is not None else int(np.random.SeedSequence().generate_state(1)[0])
+    null1, null2 = be.null_scores(file1Arr, file2Arr, numStates, saliency, expFreqArr, groupSize, seed)
+    realDiffArr, _ = be.pair_finish(score1, score2)
+    _, nullDistancesArr = be.pair_finish(null1, null2)
+    quiescenceArr = be.quiescent(file1Arr, file2Arr, quiescentState)
+
+    locationArr = readLocations(file1Path)[:totalRows]
+    writeScores(realDiffArr, outputDirPath / "pairwiseDelta_{}_{}.txt.gz".format(fileTag, filename), locationArr)
+    chrName = locationArr[0, 0]
+    np.savez_compressed(outputDirPath / "temp_nullDistances_{}_{}.npz".format(fileTag, filename),
+                        chrName=np.array([chrName]), nullDistances=nullDistancesArr)
+    np.savez_compressed(outputDirPath / "temp_quiescence_{}_{}.npz".format(fileTag, filename),
+                        chrName=np.array([chrName]), quiescenceArr=quiescenceArr)
+
+
+def formatScores(dataArr, locationArr):
+    """Text of the reference's writeScores (scores.py:530-532): 'chr\\tstart\\tend\\t' + '%.5f' values, tab separated."""
+    dataArr = np.asarray(dataArr, dtype=np.float32)
+    cells = np.char.mod("%.5f", dataArr.astype(np.float64))   # float32 -> float64 is exact: same digits as format()
+    out = []
+    for i in range(dataArr.shape[0]):
+        loc = locationArr[i]
+        out.append("{}\t{}\t{}\t{}\n".format(loc[0], loc[1], loc[2], "\t".join(cells[i])))
+    return "".join(out)
+
+
+def writeScores(dataArr, outputTxtPath, locationArr, chunk=200000):
+    """gzip text file, one line per bin (reference scores.py:509-536)."""
+    with gzip.open(outputTxtPath, "wt") as outputTxt:
+        for r0 in range(0, dataArr.shape[0], chunk):
+            outputTxt.write(formatScores(dataArr[r0:r0 + chunk], locationArr[r0:r0 + chunk]))
+
+
+if __name__ == "__main__":
+    main(argv[1], argv[2], int(argv[3]), int(argv[4]), argv[5], argv[6], argv[7], int(argv[8]), int(argv[9]),
+         int(argv[10]), strToBool(argv[11]))

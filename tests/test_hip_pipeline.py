@@ -1,0 +1,62 @@
+"""GPU end-to-end: the stage drivers and the CLI with the real HIP backend on the reference's golden slice."""
+import gzip
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+
+from tests.test_host_logic import write_tsv
+
+pytestmark = pytest.mark.gpu
+S = 18
+
+
+def _text_to_array(txt):
+    return np.array([[float(v) for v in l.split("\t")[3:]] for l in txt.decode().splitlines()], dtype=np.float32)
+
+
+def test_cli_single_s1_real_slice(tmp_path, golden_real):
+    from click.testing import CliRunner
+    from epilogos_amd import backend
+    from epilogos_amd.run import main
+    assert backend._override is None           # the product backend, not a stand-in
+    g = golden_real
+    ind, out = tmp_path / "in10", tmp_path / "out"
+    ind.mkdir()
+    write_tsv(ind / "matrix_chr1.txt.gz", g["x"], start0=int(g["start0"]))
+    meta = tmp_path / "metadata.tsv"
+    meta.write_text("zero_index\tone_index\n" + "".join("%d\t%d\n" % (i, i + 1) for i in range(S)))
+    res = CliRunner().invoke(main, ["-l", "-i", str(ind), "-j", str(meta), "-o", str(out)])
+    assert res.exit_code == 0, res.output
+    assert np.array_equal(np.load(out / "exp_freq_in10_s1.npy"), g["s1_exp"])          # bit-exact exp_freq
+    with gzip.open(out / "scores_in10_s1_matrix_chr1.txt.gz", "rb") as fh:
+        text = fh.read()
+    ref = g["s1_text"].tobytes()
+    got_lines, ref_lines = text.split(b"\n"), ref.split(b"\n")
+    assert len(got_lines) == len(ref_lines)
+    same = sum(a == b for a, b in zip(got_lines, ref_lines))
+    print("identical text lines: %d / %d" % (same, len(ref_lines)))
+    assert same >= 0.999 * len(ref_lines)
+    np.testing.assert_allclose(_text_to_array(text), _text_to_array(ref), atol=1.01e-5)
+    z = np.load(out / "temp_scores_in10_s1_matrix_chr1.npz", allow_pickle=True)
+    np.testing.assert_allclose(z["scoreArr"], g["s1_f32"], rtol=2e-7, atol=0)
+
+
+@pytest.mark.parametrize("sal", [1, 2])
+def test_stage_drivers_hip(tmp_path, golden_real, sal):
+    from epilogos_amd import expected, expectedCombination, scores
+    g = golden_real
+    out = tmp_path / "out"
+    out.mkdir()
+    f = tmp_path / "matrix_chr1.txt"
+    write_tsv(f, g["x"], start0=int(g["start0"]))
+    tag = "t_s%d" % sal
+    expected.main(f, "null", S, sal, out, tag, 1, False)
+    tmp = np.load(out / ("temp_exp_freq_%s_matrix_chr1.npy" % tag))
+    assert np.array_equal(tmp, g["s%d_counts" % sal]) and tmp.dtype == np.int64
+    expectedCombination.main(out, out / ("exp_freq_%s.npy" % tag), tag, False)
+    assert np.array_equal(np.load(out / ("exp_freq_%s.npy" % tag)), g["s%d_exp" % sal])
+    scores.main(f, "null", S, sal, out, out / ("exp_freq_%s.npy" % tag), tag, 1, S - 1, -1, False)
+    z = np.load(out / ("temp_scores_%s_matrix_chr1.npz" % tag), allow_pickle=True)
+    np.testing.assert_allclose(z["scoreArr"], g["s%d_f32" % sal], rtol=3e-7, atol=1e-12)

@@ -1,0 +1,222 @@
+"""CPU tests of the host side: helpers, stage drivers (file names, dtypes, text bytes), partition planning and the
+world_size-2 gloo path.  The arithmetic is supplied by an oracle-backed stand-in (tests/fake_backend.py) -- the
+product backend needs a GPU and is covered by the -m gpu tests."""
+import gzip
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from epilogos_amd import backend, driver, helpers
+from tests.fake_backend import OracleBackend
+
+ROOT = Path(__file__).resolve().parents[1]
+S = 18
+
+
+def write_tsv(path, x0, chrom="chr1", start0=0, trailing_newline=True):
+    lines = ["{}\t{}\t{}\t{}".format(chrom, start0 + 200 * r, start0 + 200 * r + 200,
+                                     "\t".join(str(int(v) + 1) for v in x0[r])) for r in range(x0.shape[0])]
+    txt = "\n".join(lines) + ("\n" if trailing_newline else "")
+    opener = gzip.open if str(path).endswith(".gz") else open
+    with opener(path, "wt") as f:
+        f.write(txt)
+
+
+@pytest.fixture()
+def fake_backend():
+    backend.set_for_testing(OracleBackend())
+    yield
+    backend.set_for_testing(None)
+
+
+@pytest.fixture()
+def state_info(tmp_path):
+    p = tmp_path / "metadata.tsv"
+    p.write_text("zero_index\tone_index\tshort_name\n" + "".join("%d\t%d\tS%d\n" % (i, i + 1, i) for i in range(S)))
+    return p
+
+
+def test_helpers_match_reference_vectors(tmp_path, golden_edge):
+    g = golden_edge
+    x = g["q0_x"][:10]
+    write_tsv(tmp_path / "nonl.txt", x, trailing_newline=False)
+    write_tsv(tmp_path / "rows.txt.gz", x)
+    assert helpers.countRows(tmp_path / "nonl.txt") == int(g["nonl_rows"]) == 9      # quirk Q6
+    assert helpers.countRows(tmp_path / "rows.txt.gz") == int(g["gz_rows"]) == 10
+    assert np.array_equal(np.array(helpers.splitRows(1246253, 8)), g["split_rows_1246253_8"])
+    assert np.array_equal(np.array(helpers.splitRows(7, 3)), g["split_rows_7_3"])
+    got = helpers.readStates(file1Path=tmp_path / "rows.txt.gz", rowsToCalc=(2, 7))
+    assert got.dtype == np.int8 and np.array_equal(got, x[2:7])
+    assert helpers.strToBool("True") is True and helpers.strToBool("False") is False
+    with pytest.raises(ValueError):
+        helpers.strToBool("true")
+    assert helpers.fileStem("/a/b/matrix_chr1.txt.gz") == "matrix_chr1"
+
+
+def test_read_states_paired(tmp_path):
+    rng = np.random.default_rng(3)
+    xa = rng.integers(0, S, size=(20, 4)).astype(np.int8)
+    xb = rng.integers(0, S, size=(20, 6)).astype(np.int8)
+    write_tsv(tmp_path / "a.txt", xa); write_tsv(tmp_path / "b.txt", xb)
+    comb = helpers.readStates(tmp_path / "a.txt", tmp_path / "b.txt", (0, 20), expBool=True)
+    assert np.array_equal(comb, np.concatenate([xa, xb], axis=1))
+    a, b, sa, sb = helpers.readStates(tmp_path / "a.txt", tmp_path / "b.txt", (0, 20), expBool=False,
+                                      rng=np.random.default_rng(0))
+    assert sa.shape == (20, 4) and sb.shape == (20, 6)
+    # a per-row shuffle keeps every row's multiset of states
+    assert np.array_equal(np.sort(np.concatenate([sa, sb], axis=1), axis=1), np.sort(comb, axis=1))
+    _, _, sa, sb = helpers.readStates(tmp_path / "a.txt", tmp_path / "b.txt", (0, 20), expBool=False, groupSize=3,
+                                      rng=np.random.default_rng(0))
+    assert sa.shape == (20, 3) and sb.shape == (20, 3)
+
+
+@pytest.mark.parametrize("sal", [1, 2, 3])
+def test_stage_drivers_reproduce_reference_outputs(tmp_path, golden_real, fake_backend, sal):
+    """expected.main -> expectedCombination.main -> scores.main on the real slice: artefact names, dtypes, and for S1
+    the exact text the reference wrote (tests/golden/real_slice.npz: s1_text)."""
+    from epilogos_amd import expected, expectedCombination, scores
+    g = golden_real
+    x = g["x"] if sal < 3 else g["x"][:96]
+    ind, out = tmp_path / "in10", tmp_path / "out"
+    ind.mkdir(); out.mkdir()
+    f = ind / "matrix_chr1.txt.gz"
+    write_tsv(f, x, start0=int(g["start0"]))
+    tag = "in10_s%d" % sal
+    expected.main(f, "null", S, sal, out, tag, 1, False)
+    tmp = np.load(out / ("temp_exp_freq_%s_matrix_chr1.npy" % tag))
+    if sal < 3:
+        assert np.array_equal(tmp, g["s%d_counts" % sal]) and tmp.dtype == g["s%d_counts" % sal].dtype
+    else:
+        assert tmp.dtype == np.int32 and tmp.shape == (10, 10, S, S)
+    expPath = out / ("exp_freq_%s.npy" % tag)
+    expectedCombination.main(out, expPath, tag, False)
+    assert not list(out.glob("temp_exp_freq_*"))                              # temporaries removed
+    q = np.load(expPath)
+    assert q.dtype == np.float32
+    if sal < 3:
+        assert np.array_equal(q, g["s%d_exp" % sal])
+    scores.main(f, "null", S, sal, out, expPath, tag, 1, S - 1, -1, False)
+    with gzip.open(out / ("scores_%s_matrix_chr1.txt.gz" % tag), "rb") as fh:
+        text = fh.read()
+    z = np.load(out / ("temp_scores_%s_matrix_chr1.npz" % tag), allow_pickle=True)
+    assert z["scoreArr"].dtype == np.float32 and z["scoreArr"].shape == (x.shape[0], S)
+    assert z["chrName"][0] == "chr1" and z["locationArr"].shape == (x.shape[0], 3)
+    if sal == 1:
+        assert text == g["s1_text"].tobytes()
+        assert np.array_equal(z["scoreArr"], g["s1_f32"])
+    if sal == 2:
+        np.testing.assert_allclose(z["scoreArr"], g["s2_f32"], rtol=2e-7, atol=1e-12)
+
+
+def test_paired_stage_drivers(tmp_path, golden_pair, fake_backend):
+    from epilogos_amd import expected, expectedCombination, scores
+    g = golden_pair
+    a, b, out = tmp_path / "A", tmp_path / "B", tmp_path / "out"
+    for d in (a, b, out):
+        d.mkdir()
+    write_tsv(a / "matrix_chr1.txt", g["xa"]); write_tsv(b / "matrix_chr1.txt", g["xb"])
+    tag = "A_B_s1"
+    expected.main(a / "matrix_chr1.txt", b / "matrix_chr1.txt", S, 1, out, tag, 1, False)
+    expectedCombination.main(out, out / ("exp_freq_%s.npy" % tag), tag, False)
+    assert np.array_equal(np.load(out / ("exp_freq_%s.npy" % tag)), g["s1_exp"])
+    scores.NULL_SEED = 7
+    scores.main(a / "matrix_chr1.txt", b / "matrix_chr1.txt", S, 1, out, out / ("exp_freq_%s.npy" % tag), tag, 1,
+                int(g["qstate"]), -1, False)
+    with gzip.open(out / ("pairwiseDelta_%s_matrix_chr1.txt.gz" % tag), "rt") as fh:
+        rows = [l.rstrip("\n").split("\t") for l in fh]
+    delta = np.array([[float(v) for v in r[3:]] for r in rows], dtype=np.float32)
+    np.testing.assert_allclose(delta, g["s1_delta"], atol=5.1e-6)            # %.5f text
+    qz = np.load(out / ("temp_quiescence_%s_matrix_chr1.npz" % tag))
+    assert np.array_equal(qz["quiescenceArr"], g["s1_quiescent"])
+    nz = np.load(out / ("temp_nullDistances_%s_matrix_chr1.npz" % tag))
+    assert nz["nullDistances"].shape == (g["xa"].shape[0],) and nz["nullDistances"].dtype == np.float32
+
+
+def test_invalid_state_is_reported(tmp_path, fake_backend):
+    from epilogos_amd import expected
+    x = np.zeros((5, 4), dtype=np.int8)
+    x[2, 1] = S          # file value S+1: outside the model
+    write_tsv(tmp_path / "m.txt", x)
+    with pytest.raises(ValueError):
+        expected.main(tmp_path / "m.txt", "null", S, 1, tmp_path, "t", 1, False)
+    with pytest.raises(ValueError):
+        expected.main(tmp_path / "m.txt", "null", S, 4, tmp_path, "t", 1, False)
+
+
+def test_plan_partition_properties():
+    rows = [1246253, 7, 0, 999, 51304566 // 200]
+    total = sum(rows)
+    for world in (1, 2, 3, 8, 16):
+        plans = driver.plan_partition(rows, world)
+        assert len(plans) == world
+        covered = np.zeros(total, dtype=np.int8) if total < 5_000_000 else None
+        seen = {f: [] for f in range(len(rows))}
+        for parts in plans:
+            for (f, lo, hi) in parts:
+                assert 0 <= lo < hi <= rows[f]
+                seen[f].append((lo, hi))
+        for f, ivs in seen.items():            # each file's rows are covered exactly once, in order
+            ivs.sort()
+            pos = 0
+            for lo, hi in ivs:
+                assert lo == pos
+                pos = hi
+            assert pos == rows[f]
+        sizes = [sum(hi - lo for _, lo, hi in p) for p in plans]
+        assert max(sizes) - min(sizes) <= 1     # splitRows balance
+
+
+def _decompressed(path):
+    with gzip.open(path, "rb") as fh:
+        return fh.read()
+
+
+def test_two_rank_gloo_matches_single_process(tmp_path, golden_real):
+    """world_size 2 over gloo on CPU: partition + all-reduce + per-rank gzip members == the single-process output."""
+    g = golden_real
+    ind = tmp_path / "in"
+    ind.mkdir()
+    x = g["x"]
+    write_tsv(ind / "matrix_chr1.txt", x[:1500], chrom="chr1", start0=int(g["start0"]))
+    write_tsv(ind / "matrix_chr2.txt", x[1500:], chrom="chr2")
+    outs = {}
+    for world in (1, 2):
+        out = tmp_path / ("out%d" % world)
+        out.mkdir()
+        env = dict(os.environ, PYTHONPATH=str(ROOT), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29400 + os.getpid() % 500))
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+               "--master-addr", "127.0.0.1", "--master-port", env["MASTER_PORT"],
+               str(ROOT / "tests" / "gloo_worker.py"), str(ind), str(out)]
+        res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+        assert res.returncode == 0, res.stdout + res.stderr
+        outs[world] = out
+    for name in ("scores_t_s1_matrix_chr1.txt.gz", "scores_t_s1_matrix_chr2.txt.gz"):
+        assert _decompressed(outs[1] / name) == _decompressed(outs[2] / name)
+    assert np.array_equal(np.load(outs[1] / "exp_freq_t_s1.npy"), np.load(outs[2] / "exp_freq_t_s1.npy"))
+    assert np.array_equal(np.load(outs[1] / "exp_freq_t_s1.npy"), g["s1_exp"])     # == the reference's exp_freq
+    z1 = np.load(outs[1] / "temp_scores_t_s1_matrix_chr2.npz", allow_pickle=True)
+    z2 = np.load(outs[2] / "temp_scores_t_s1_matrix_chr2.npz", allow_pickle=True)
+    assert np.array_equal(z1["scoreArr"], z2["scoreArr"]) and z2["chrName"][0] == "chr2"
+    # chr1 holds the first 1500 bins of the slice: its text is the reference's first 1500 lines
+    ref_lines = g["s1_text"].tobytes().split(b"\n")
+    assert _decompressed(outs[2] / "scores_t_s1_matrix_chr1.txt.gz") == b"\n".join(ref_lines[:1500]) + b"\n"
+
+
+def test_cli_single_mode(tmp_path, golden_real, fake_backend, state_info):
+    from click.testing import CliRunner
+    from epilogos_amd.run import main
+    g = golden_real
+    ind, out = tmp_path / "in10", tmp_path / "out"
+    ind.mkdir()
+    write_tsv(ind / "matrix_chr1.txt.gz", g["x"], start0=int(g["start0"]))
+    res = CliRunner().invoke(main, ["-l", "-i", str(ind), "-j", str(state_info), "-o", str(out), "-c", "8"])
+    assert res.exit_code == 0, res.output
+    assert _decompressed(out / "scores_in10_s1_matrix_chr1.txt.gz") == g["s1_text"].tobytes()   # default tag: {dir}_s{sal}
+    assert np.array_equal(np.load(out / "exp_freq_in10_s1.npy"), g["s1_exp"])
+    res = CliRunner().invoke(main, ["-i", str(ind), "-j", str(state_info), "-o", str(out), "-s", "3", "-m", "paired",
+                                    "-a", str(ind), "-b", str(ind)])
+    assert res.exit_code == 0 and "ERROR" in res.output                                     # -i with paired mode
