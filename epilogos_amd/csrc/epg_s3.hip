@@ -1,19 +1,218 @@
-// S3 path (biosample-pair saliency) -- placeholder until the tiled kernels land; fails loudly.
+// S3 path (biosample-pair saliency).  gfx950 only.
+//
+// Expected pass (reference expected.py:165-204 s3Calc): C[a,b,i,j] = #{bins : x[a] == i and x[b] == j}, a != b.
+//   k_s3_hist: a block owns TA "a" biosamples x 64 "b" biosamples x a slice of <= 65535 bins and keeps their
+//   TA*64*S*S co-occurrence counters as packed uint16 pairs in LDS (<= 150 KB); each lane is one b, reads its
+//   state byte (a coalesced 64-byte row segment per wave and bin) and issues one ds_add_u32 per a.  The slice
+//   length bounds every counter by 65535; the flush adds the non-zero counters to the int32 global array.
+//   Integer arithmetic only => exact and independent of launch geometry.  Bound: LDS atomic rate
+//   (R*N*(N-1) increments), see DESIGN.md.
+//
+// Score pass (reference scores.py:455-506 s3Score):
+//   T[a,b,i,j] = kl(float32(1)/P, q[a,b,i,j]) in float32 (scores.py:479-480), stored transposed as
+//   T2[b][j][a][i] so that the N*S values needed for one (b, j) are contiguous;
+//   score[bin, s] = sum_{b: x_b == s} sum_{a != b} T[a, b, x_a, s]   (closed form of scores.py:496-498).
+//   k_s3_score: a block owns one b and a slice of bins; for every state s present in the slice's column b it
+//   stages the tile T2[b][s][:][:] (N*S floats, <= 150 KB) in LDS and, for each bin with x_b == s, a wave
+//   gathers tile[a][x_a] over all a (coalesced row read, LDS gather), reduces in float64 and adds the result to
+//   the float64 score.  The diagonal a == b contributes 0 because q[a,a,:,:] == 0 (kl masks q == 0).
 #include "epg_common.h"
 
 namespace epg {
 
-int64_t s3_ws_bytes(int64_t, int, int) { return 256; }
+constexpr int S3_TB = 64;             // b biosamples per block (= lanes of a wave)
+constexpr int S3_SLICE = 65535;       // bins per slice: packed uint16 counters cannot overflow
+constexpr int S3_LDS_BUDGET = 150 * 1024;
 
-int hist_s3_impl(const int8_t*, int64_t, int32_t, int64_t, int32_t, int32_t*, void*, int64_t, hipStream_t) {
-    return fail(EPG_ERR_UNSUPPORTED, "hist_s3: not implemented in this build");
+__global__ __launch_bounds__(256) void k_s3_hist(const char* __restrict__ X, long R, int N, long ldx, int S, int TA,
+                                                  int n_btiles, int* __restrict__ counts) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    u32* hist = reinterpret_cast<u32*>(smem);
+    const int SS = S * S;
+    const int words = (TA * S3_TB * SS + 1) / 2;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long tile = blockIdx.x;                 // (a-tile, b-tile)
+    const int a0 = (int)(tile / n_btiles) * TA;
+    const int b = (int)(tile % n_btiles) * S3_TB + lane;
+    const long r0 = (long)blockIdx.y * S3_SLICE;
+    const long r1 = r0 + S3_SLICE < R ? r0 + S3_SLICE : R;
+
+    for (int w = threadIdx.x; w < words; w += 256) hist[w] = 0;
+    __syncthreads();
+
+    const bool b_ok = b < N;
+    for (long row = r0 + wave; row < r1; row += 4) {
+        const char* rp = X + row * ldx;
+        const int xb = b_ok ? (int)(unsigned char)rp[b] : 255;
+        if (xb < S) {
+            for (int ta = 0; ta < TA; ++ta) {
+                const int a = a0 + ta;
+                if (a >= N || a == b) continue;
+                const int xa = (int)(unsigned char)rp[a];
+                if (xa >= S) continue;
+                const int idx = (ta * S3_TB + lane) * SS + xa * S + xb;
+                atomicAdd(&hist[idx >> 1], 1u << (16 * (idx & 1)));
+            }
+        }
+    }
+    __syncthreads();
+    for (int w = threadIdx.x; w < words; w += 256) {
+        const u32 v = hist[w];
+        if (!v) continue;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const u32 c = h ? v >> 16 : v & 0xffffu;
+            if (!c) continue;
+            const int idx = 2 * w + h;
+            const int ta = idx / (S3_TB * SS);
+            const int rem = idx - ta * S3_TB * SS;
+            const int bl = rem / SS, ij = rem - bl * SS;
+            const long a = a0 + ta, bb = (long)(tile % n_btiles) * S3_TB + bl;
+            atomicAdd(&counts[((a * N + bb) * SS) + ij], (int)c);
+        }
+    }
 }
-int score_s3_impl(const int8_t*, int64_t, int32_t, int64_t, int32_t, const float*, double*, float*, void*, int64_t, hipStream_t) {
-    return fail(EPG_ERR_UNSUPPORTED, "score_s3: not implemented in this build");
+
+// T2[b][j][a][i] = float32 kl(float32(1)/P, q[a,b,i,j]); float32 arithmetic like scores.py:479-480.
+__global__ void k_s3_table(const float* __restrict__ q, int N, int S, float* __restrict__ T2) {
+    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long total = (long)N * N * S * S;
+    if (e >= total) return;
+    // e indexes T2: ((b*S + j)*N + a)*S + i
+    const int i = (int)(e % S);
+    long t = e / S;
+    const int a = (int)(t % N);
+    t /= N;
+    const int j = (int)(t % S);
+    const int b = (int)(t / S);
+    const float qv = q[(((long)a * N + b) * S + i) * S + j];
+    const float obs = 1.0f / (float)((long)N * (N - 1));
+    float v = 0.0f;
+    if (qv != 0.0f) {
+        const float r = obs / qv;
+        if (r > 0.0f) v = obs * log2f(r);
+    }
+    T2[e] = v;
 }
-int null_hist_impl(const int8_t*, int32_t, int64_t, const int8_t*, int32_t, int64_t, int64_t, int32_t, int32_t, int32_t,
-                   uint64_t, int64_t, uint16_t*, uint16_t*, hipStream_t) {
-    return fail(EPG_ERR_UNSUPPORTED, "null_hist: not implemented in this build");
+
+constexpr int S3_SCORE_SLICE = 8192;
+
+__global__ __launch_bounds__(256) void k_s3_score(const char* __restrict__ X, long R, int N, long ldx, int S,
+                                                   const float* __restrict__ T2, double* __restrict__ out64) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* tile = reinterpret_cast<float*>(smem);                                        // [N*S]
+    unsigned char* col = reinterpret_cast<unsigned char*>(smem) + (size_t)N * S * 4;     // [S3_SCORE_SLICE]
+    __shared__ u32 present;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = blockIdx.x % N;                 // b fastest: blocks of one slice run together (rows stay in L2)
+    const long slice = blockIdx.x / N;
+    const long r0 = slice * S3_SCORE_SLICE;
+    const int nb = (int)((R - r0) < S3_SCORE_SLICE ? (R - r0) : S3_SCORE_SLICE);
+
+    if (threadIdx.x == 0) present = 0;
+    __syncthreads();
+    u32 mine = 0;
+    for (int k = threadIdx.x; k < nb; k += 256) {
+        const unsigned char v = (unsigned char)X[(r0 + k) * ldx + b];
+        col[k] = v;
+        if (v < S) mine |= 1u << v;
+    }
+    if (mine) atomicOr(&present, mine);
+    __syncthreads();
+    const u32 have = present;
+
+    for (int s = 0; s < S; ++s) {
+        if (!((have >> s) & 1u)) continue;       // block-uniform
+        __syncthreads();                           // previous tile fully consumed
+        const float* src = T2 + ((long)b * S + s) * N * S;
+        for (int e = threadIdx.x; e < N * S; e += 256) tile[e] = src[e];
+        __syncthreads();
+        // each wave scans a quarter of the slice, 64 bins at a time
+        const int per = (nb + 3) / 4;
+        const int k0 = wave * per, k1 = (k0 + per) < nb ? (k0 + per) : nb;
+        for (int kb = k0; kb < k1; kb += 64) {
+            const int k = kb + lane;
+            const bool hit = k < k1 && col[k] == (unsigned char)s;
+            unsigned long long m = __ballot(hit);
+            while (m) {
+                const int bit = __ffsll((long long)m) - 1;
+                m &= m - 1;
+                const long row = r0 + kb + bit;
+                const char* rp = X + row * ldx;
+                double acc = 0.0;
+                for (int a = lane; a < N; a += 64) {
+                    const int xa = (int)(unsigned char)rp[a];
+                    if (xa < S) acc += (double)tile[a * S + xa];
+                }
+                for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+                if (lane == 0) atomicAdd(&out64[row * S + s], acc);
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_f64_to_f32(const double* __restrict__ in, long n, float* __restrict__ out) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) out[i] = (float)in[i];
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+static int s3_ta(int S) {
+    int ta = S3_LDS_BUDGET / (S3_TB * S * S * 2);
+    if (ta > 4) ta = 4;
+    return ta;
+}
+
+int64_t s3_table_bytes(int N, int S) { return align_up((int64_t)N * N * S * S * 4, 256); }
+int64_t s3_ws_bytes(int64_t R, int N, int S) { return s3_table_bytes(N, S) + align_up(R * S * 8, 256); }
+
+int hist_s3_impl(const int8_t* X8, int64_t R, int32_t N, int64_t ldx, int32_t S, int32_t* counts, void*, int64_t, hipStream_t st) {
+    if (R < 0 || N < 2 || ldx < N || S < 1) return fail(EPG_ERR_INVALID_ARG, "hist_s3: bad shape R=%lld N=%d ldx=%lld S=%d", (long long)R, N, (long long)ldx, S);
+    if (S > 31) return fail(EPG_ERR_UNSUPPORTED, "hist_s3: S=%d > 31 not supported by this build", S);
+    if (R == 0) return EPG_OK;
+    if (!X8 || !counts) return fail(EPG_ERR_INVALID_ARG, "hist_s3: NULL argument");
+    const int TA = s3_ta(S);
+    if (TA < 1) return fail(EPG_ERR_UNSUPPORTED, "hist_s3: S=%d needs more LDS than a CU has", S);
+    const int n_atiles = (N + TA - 1) / TA, n_btiles = (N + S3_TB - 1) / S3_TB;
+    const long nslices = (R + S3_SLICE - 1) / S3_SLICE;
+    if (nslices > 65535) return fail(EPG_ERR_UNSUPPORTED, "hist_s3: R=%lld too large for one call (max %lld bins)", (long long)R, 65535LL * S3_SLICE);
+    const size_t shmem = (size_t)((TA * S3_TB * S * S + 1) / 2) * 4;
+    EPG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_s3_hist), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+    hipLaunchKernelGGL(k_s3_hist, dim3((unsigned)(n_atiles * n_btiles), (unsigned)nslices), dim3(256), shmem, st,
+                       reinterpret_cast<const char*>(X8), (long)R, N, (long)ldx, S, TA, n_btiles, counts);
+    EPG_LAUNCH_CHECK("k_s3_hist");
+    return EPG_OK;
+}
+
+int score_s3_impl(const int8_t* X8, int64_t R, int32_t N, int64_t ldx, int32_t S, const float* q, double* out64, float* out32,
+                  void* ws, int64_t ws_bytes, hipStream_t st) {
+    if (R < 0 || N < 2 || ldx < N || S < 1) return fail(EPG_ERR_INVALID_ARG, "score_s3: bad shape");
+    if (S > 31) return fail(EPG_ERR_UNSUPPORTED, "score_s3: S=%d > 31 not supported by this build", S);
+    if (R == 0) return EPG_OK;
+    if (!X8 || !q || !ws) return fail(EPG_ERR_INVALID_ARG, "score_s3: NULL argument");
+    const size_t shmem = (size_t)N * S * 4 + S3_SCORE_SLICE;
+    if (shmem > 160 * 1024 - 64) return fail(EPG_ERR_UNSUPPORTED, "score_s3: N*S = %d exceeds the LDS tile (N*S*4 + 8 KB <= 160 KB)", N * S);
+    const int64_t tb = s3_table_bytes(N, S);
+    const int64_t need = tb + (out64 ? 0 : align_up(R * S * 8, 256));
+    if (ws_bytes < need) return fail(EPG_ERR_WORKSPACE, "score_s3: workspace %lld < %lld bytes", (long long)ws_bytes, (long long)need);
+    float* T2 = reinterpret_cast<float*>(ws);
+    double* acc = out64 ? out64 : reinterpret_cast<double*>(reinterpret_cast<char*>(ws) + tb);
+    const long total = (long)N * N * S * S;
+    hipLaunchKernelGGL(k_s3_table, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, q, N, S, T2);
+    EPG_LAUNCH_CHECK("k_s3_table");
+    EPG_HIP(hipMemsetAsync(acc, 0, (size_t)R * S * 8, st));
+    const long nslices = (R + S3_SCORE_SLICE - 1) / S3_SCORE_SLICE;
+    if (nslices * N > 0x7fffffffL) return fail(EPG_ERR_UNSUPPORTED, "score_s3: R*N too large for one call");
+    EPG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_s3_score), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+    hipLaunchKernelGGL(k_s3_score, dim3((unsigned)(nslices * N)), dim3(256), shmem, st, reinterpret_cast<const char*>(X8), (long)R, N,
+                       (long)ldx, S, T2, acc);
+    EPG_LAUNCH_CHECK("k_s3_score");
+    if (out32) {
+        long blocks = ((long)R * S + 255) / 256;
+        if (blocks > num_cus() * 8L) blocks = num_cus() * 8L;
+        hipLaunchKernelGGL(k_f64_to_f32, dim3((unsigned)blocks), dim3(256), 0, st, acc, (long)R * S, out32);
+        EPG_LAUNCH_CHECK("k_f64_to_f32");
+    }
+    return EPG_OK;
 }
 
 }  // namespace epg

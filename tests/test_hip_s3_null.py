@@ -1,0 +1,167 @@
+"""GPU parity for the S3 kernels and the paired-mode null shuffle."""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+
+from oracle import oracle_np as onp
+from tests.conftest import synth_states
+
+pytestmark = pytest.mark.gpu
+S = 18
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from epilogos_amd import engine
+    engine.require_gpu()
+    return engine
+
+
+def _np(t):
+    return t.cpu().numpy()
+
+
+def _s3_counts(eng, x):
+    N = x.shape[1]
+    X = eng.states_to_device(x)
+    c = eng.hist_s3(X, N, S)
+    return c, _np(c).reshape(N, N, S, S)
+
+
+def test_s3_counts_golden(eng, golden_s3, golden_real, golden_edge):
+    for x, want in ((golden_s3["x"], golden_s3["s3_counts"]), (golden_real["x"], golden_real["s3_counts"]),
+                    (golden_edge["n2_x"], golden_edge["n2_s3_counts"])):
+        c, got = _s3_counts(eng, x)
+        assert got.dtype == np.int32 and np.array_equal(got, want)
+        N = x.shape[1]
+        assert np.array_equal(_np(eng.normalise(c)).reshape(N, N, S, S), onp.normalise(want))
+
+
+def test_s3_counts_exp_golden(eng, golden_s3):
+    c, got = _s3_counts(eng, golden_s3["x"])
+    assert np.array_equal(_np(eng.normalise(c)).reshape(got.shape), golden_s3["s3_exp"])   # bit-exact float32 exp_freq
+
+
+@pytest.mark.parametrize("N,R", [(70, 500), (65, 130), (3, 70000), (129, 64)])
+def test_s3_counts_random(eng, N, R):
+    x = synth_states(R, N, seed=N)
+    x[0, 0] = -1                                   # an invalid state is skipped in every pair it takes part in
+    c, got = _s3_counts(eng, x)
+    xo = x.copy()
+    want = onp.expected_s3(xo, S)
+    assert np.array_equal(got, want)
+    X = eng.states_to_device(x)
+    eng.hist_s3(X, N, S, counts=c)                 # accumulates
+    assert np.array_equal(_np(c).reshape(got.shape), 2 * want)
+
+
+def _s3_score_check(eng, x, q, gold32=None):
+    N = x.shape[1]
+    X = eng.states_to_device(x)
+    qd = torch.from_numpy(np.ascontiguousarray(q, dtype=np.float32).reshape(-1)).cuda()
+    o32, o64 = eng.score_s3(X, N, S, qd, want32=True, want64=True)
+    ref = onp.score_s3_f64(x, q, S)
+    # float32 table (device log2f vs numpy log2 on float32: <= 1 ulp per entry), float64 accumulation
+    np.testing.assert_allclose(_np(o64), ref, rtol=2e-6, atol=1e-9)
+    np.testing.assert_allclose(_np(o32), ref.astype(np.float32), rtol=3e-6, atol=1e-9)
+    if gold32 is not None:   # the reference's float32 sequential accumulation (SURVEY 8c tolerance)
+        np.testing.assert_allclose(_np(o32), gold32, rtol=1e-4, atol=5e-6)
+    o32b, _ = eng.score_s3(X, N, S, qd, want32=True, want64=False)
+    np.testing.assert_allclose(_np(o32b), _np(o32), rtol=1e-6, atol=1e-9)      # atomics: order may differ in the last bit
+
+
+def test_s3_score_golden(eng, golden_s3, golden_real, golden_edge):
+    _s3_score_check(eng, golden_s3["x"], golden_s3["s3_exp"], golden_s3["s3_f32"])
+    _s3_score_check(eng, golden_real["x"][:600], golden_real["s3_exp"], golden_real["s3_f32"][:600])
+    _s3_score_check(eng, golden_edge["n2_x"], golden_edge["n2_s3_exp"], golden_edge["n2_s3_f32"])
+
+
+def test_s3_score_random(eng):
+    x = synth_states(9000, 70, seed=3)             # more than one slice of 8192 bins
+    q = onp.normalise(onp.expected_s3(x, S))
+    _s3_score_check(eng, x[:300], q)
+    X = eng.states_to_device(x)
+    qd = torch.from_numpy(q.reshape(-1)).cuda()
+    o32, o64 = eng.score_s3(X, 70, S, qd, want32=True, want64=True)
+    ref_tail = onp.score_s3_f64(x[8100:8300], q, S)
+    np.testing.assert_allclose(_np(o64)[8100:8300], ref_tail, rtol=2e-6, atol=1e-9)
+
+
+# ------------------------------------------------------------------------------------------------ null shuffle
+def test_null_hist_properties(eng):
+    R, NA, NB = 4000, 37, 29
+    xa = synth_states(R, NA, seed=1)
+    xb = synth_states(R, NB, seed=2)
+    XA, XB = eng.states_to_device(xa), eng.states_to_device(xb)
+    tot = onp.bin_hist(np.concatenate([xa, xb], axis=1), S)
+    HA, HB = eng.null_hist(XA, NA, XB, NB, S, NA, NB, seed=123)
+    ha, hb = eng.hist_to_numpy(HA).astype(np.int64), eng.hist_to_numpy(HB).astype(np.int64)
+    assert (ha.sum(axis=1) == NA).all() and (hb.sum(axis=1) == NB).all()
+    assert np.array_equal(ha + hb, tot)            # a permutation: every column lands in exactly one group
+    # reproducible, seed-dependent, independent of which slice of rows a call covers (row0 offsets)
+    HA2, HB2 = eng.null_hist(XA, NA, XB, NB, S, NA, NB, seed=123)
+    assert torch.equal(HA, HA2) and torch.equal(HB, HB2)
+    HA3, _ = eng.null_hist(XA, NA, XB, NB, S, NA, NB, seed=124)
+    assert not torch.equal(HA, HA3)
+    XAs, XBs = eng.states_to_device(xa[1000:1500]), eng.states_to_device(xb[1000:1500])
+    HAs, HBs = eng.null_hist(XAs, NA, XBs, NB, S, NA, NB, seed=123, row0=1000)
+    assert torch.equal(HAs, HA[1000:1500]) and torch.equal(HBs, HB[1000:1500])
+    # group-size option: two groups of g columns drawn without replacement
+    g = 20
+    HAg, HBg = eng.null_hist(XA, NA, XB, NB, S, g, g, seed=5)
+    hag, hbg = eng.hist_to_numpy(HAg).astype(np.int64), eng.hist_to_numpy(HBg).astype(np.int64)
+    assert (hag.sum(axis=1) == g).all() and (hbg.sum(axis=1) == g).all() and (hag + hbg <= tot).all()
+
+
+def test_null_hist_is_a_uniform_shuffle(eng):
+    """Same row repeated: the count of state s in group A is hypergeometric(M, K_s, NA) -- check mean and variance,
+    and compare with numpy's argsort-of-uniforms shuffle (the reference's method, helpers.py:183-184)."""
+    R, NA, NB = 60000, 12, 9
+    M = NA + NB
+    base = np.array([0] * 8 + [5] * 6 + [17] * 7, dtype=np.int8)
+    xa = np.tile(base[:NA], (R, 1))
+    xb = np.tile(base[NA:], (R, 1))
+    HA, _ = eng.null_hist(eng.states_to_device(xa), NA, eng.states_to_device(xb), NB, S, NA, NB, seed=99)
+    ha = eng.hist_to_numpy(HA).astype(np.float64)
+    rng = np.random.default_rng(0)
+    comb = np.tile(base, (R, 1))
+    sh = onp.shuffle_rows(comb, rng.random(comb.shape))[:, :NA]
+    for s, K in ((0, 8), (5, 6), (17, 7)):
+        mean = NA * K / M
+        var = NA * (K / M) * (1 - K / M) * (M - NA) / (M - 1)
+        assert abs(ha[:, s].mean() - mean) < 5 * np.sqrt(var / R)
+        assert abs(ha[:, s].var() - var) < 0.05 * var
+        ref = (sh == s).sum(axis=1)
+        # same distribution as the reference's shuffle: compare the empirical pmf
+        pm_gpu = np.bincount(ha[:, s].astype(int), minlength=NA + 1) / R
+        pm_ref = np.bincount(ref, minlength=NA + 1) / R
+        assert np.abs(pm_gpu - pm_ref).max() < 0.01
+
+
+def test_paired_pipeline_hip(tmp_path, golden_pair):
+    import gzip
+    from epilogos_amd import expected, expectedCombination, scores
+    from tests.test_host_logic import write_tsv
+    g = golden_pair
+    a, b, out = tmp_path / "A", tmp_path / "B", tmp_path / "out"
+    for d in (a, b, out):
+        d.mkdir()
+    write_tsv(a / "matrix_chr1.txt", g["xa"]); write_tsv(b / "matrix_chr1.txt", g["xb"])
+    for sal in (1, 2):
+        tag = "A_B_s%d" % sal
+        expected.main(a / "matrix_chr1.txt", b / "matrix_chr1.txt", S, sal, out, tag, 1, False)
+        expectedCombination.main(out, out / ("exp_freq_%s.npy" % tag), tag, False)
+        assert np.array_equal(np.load(out / ("exp_freq_%s.npy" % tag)), g["s%d_exp" % sal])
+        scores.NULL_SEED = 11
+        scores.main(a / "matrix_chr1.txt", b / "matrix_chr1.txt", S, sal, out, out / ("exp_freq_%s.npy" % tag), tag, 1,
+                    int(g["qstate"]), -1, False)
+        with gzip.open(out / ("pairwiseDelta_%s_matrix_chr1.txt.gz" % tag), "rt") as fh:
+            delta = np.array([[float(v) for v in l.rstrip("\n").split("\t")[3:]] for l in fh], dtype=np.float32)
+        np.testing.assert_allclose(delta, g["s%d_delta" % sal], atol=1.01e-5)
+        assert np.array_equal(np.load(out / ("temp_quiescence_%s_matrix_chr1.npz" % tag))["quiescenceArr"], g["s1_quiescent"])
+        nd = np.load(out / ("temp_nullDistances_%s_matrix_chr1.npz" % tag))["nullDistances"]
+        gd = g["s%d_null_dist" % sal]
+        assert nd.shape == gd.shape and nd.dtype == np.float32
+        # unseeded in the reference: same scale and sign balance, not the same draws
+        assert 0.5 < (np.abs(nd).mean() + 1e-12) / (np.abs(gd).mean() + 1e-12) < 2.0
