@@ -37,7 +37,7 @@ SUB_BINS = 1 << 17
 HBM_PEAK_GBPS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
-def cpu_baseline(n_biosamples, n_states, target_seconds=15.0):
+def cpu_baseline(n_biosamples, n_states, target_seconds=12.0):
     """Per-bin numpy loop (the reference's `-l` S1 loop shape) on all host cores, bounded sample.  Runs BEFORE the
     process touches the GPU (it forks workers)."""
     from oracle import rowloop_baseline as rb
@@ -45,21 +45,15 @@ def cpu_baseline(n_biosamples, n_states, target_seconds=15.0):
     cores = len(os.sched_getaffinity(0))
     rng = np.random.default_rng(1234)
     p = FREQS[:n_states] / FREQS[:n_states].sum()
-    probe = rng.choice(n_states, size=(2000, n_biosamples), p=p).astype(np.int64)
-    q = onp.normalise(onp.expected_s1(probe, n_states))
-    t0 = time.perf_counter()
-    rb.score_rows_s1(probe[:1000], q, n_states)
-    per_core = 1000 / (time.perf_counter() - t0)
-    want = per_core * cores * target_seconds                 # bins for ~target_seconds of wall time
-    sample = int(min(max(want, 4000), 1_000_000))            # distinct bins held in RAM (int8)
-    reps = max(1, int(round(want / sample)))
+    sample = max(cores * 1000, 100_000)                      # distinct bins held in RAM (int8), >= 1000 per worker
     x = rng.choice(n_states, size=(sample, n_biosamples), p=p).astype(np.int8)
-    bps, secs, cores = rb.timed_pool_run(x, q, n_states, cores, reps=reps)
+    q = onp.normalise(onp.expected_s1(x[:2000], n_states))
+    bps, secs, cores, bins = rb.timed_pool_run(x, q, n_states, cores, seconds=target_seconds)
     return {"value": round(bps / 1e6, 6), "unit": "Mbins/s", "cores": cores, "kind": "port",
-            "sample": "%d synthetic bins x %d biosamples (same state frequencies as the GPU workload) scored %d time(s): "
-                      "per-bin numpy loop of oracle/rowloop_baseline.py (np.unique + numpy.ma p*log2(p/q), the "
-                      "reference's -l S1 loop shape, scores.py:309-344,539-550) on %d forked workers, %.1f s wall"
-                      % (sample, n_biosamples, reps, cores, secs)}
+            "sample": "%d bin-scorings in %.1f s wall over %d distinct synthetic bins x %d biosamples (same state "
+                      "frequencies as the GPU workload): per-bin numpy loop of oracle/rowloop_baseline.py (np.unique + "
+                      "numpy.ma p*log2(p/q), the reference's -l S1 loop shape, scores.py:309-344,539-550) on %d forked "
+                      "workers" % (bins, secs, sample, n_biosamples, cores)}
 
 
 def generate_shard(torch, X, n_biosamples, n_states, bin0):

@@ -36,32 +36,40 @@ def score_rows_s1(x, q, S):
     return out
 
 
-def _worker(rng):
-    lo, hi = rng
+def _worker(args):
+    lo, hi, deadline = args
     xs = _G["x"][lo:hi].astype(np.int64)          # the reference holds states as int64 (helpers.py:154-155)
+    q, S = _G["q"], _G["S"]
+    done, acc, block = 0, 0.0, 500
     t0 = time.perf_counter()
-    acc = 0.0
-    for _ in range(_G["reps"]):
-        acc += float(score_rows_s1(xs, _G["q"], _G["S"]).sum())
-    return acc, time.perf_counter() - t0
+    while True:                                    # sweep the slice (again and again) until the deadline
+        for r0 in range(0, xs.shape[0], block):
+            acc += float(score_rows_s1(xs[r0:r0 + block], q, S).sum())
+            done += min(block, xs.shape[0] - r0)
+            if time.time() >= deadline:
+                return done, time.perf_counter() - t0, acc
+        if xs.shape[0] == 0:
+            return done, time.perf_counter() - t0, acc
 
 
 def _noop(_):
     return 0
 
 
-def timed_pool_run(x, q, S, cores=None, reps=1):
-    """Score all rows of x `reps` times with `cores` forked workers over contiguous row ranges (the reference's
-    splitRows rule, helpers.py:116-118).  The pool is started (and warmed) before the clock.  Returns
-    (bins_per_second, seconds, cores)."""
+def timed_pool_run(x, q, S, cores=None, seconds=10.0):
+    """Score rows of x with `cores` forked workers over contiguous row ranges (the reference's splitRows rule,
+    helpers.py:116-118) for about `seconds` of wall time: every worker keeps sweeping its range until the common
+    deadline and reports how many bins it finished.  The pool is started (and warmed) before the clock.
+    Returns (bins_per_second, seconds, cores, bins_scored)."""
     cores = cores or len(os.sched_getaffinity(0))
     R = x.shape[0]
-    _G.update(x=x, q=q, S=S, reps=reps)
-    ranges = [(i * R // cores, (i + 1) * R // cores) for i in range(cores)]
+    _G.update(x=x, q=q, S=S)
     ctx = get_context("fork")
     with ctx.Pool(cores) as pool:
         pool.map(_noop, range(cores))
         t0 = time.perf_counter()
-        pool.map(_worker, ranges, chunksize=1)
+        deadline = time.time() + seconds
+        res = pool.map(_worker, [(i * R // cores, (i + 1) * R // cores, deadline) for i in range(cores)], chunksize=1)
         dt = time.perf_counter() - t0
-    return R * reps / dt, dt, cores
+    bins = sum(r[0] for r in res)
+    return bins / dt, dt, cores, bins
