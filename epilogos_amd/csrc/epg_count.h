@@ -144,144 +144,35 @@ __device__ __forceinline__ void count_row(const char* rowp, int j, const RowGeom
     }
 }
 
-// load group t (slots 2t, 2t+1) of a row; the last group of a row is the only one that needs tail handling
-template <int NG>
-__device__ __forceinline__ void load_group(const char* rowp, int t, int j, const RowGeom& g, u32 (&w)[8]) {
-    if (t < NG - 1) {
-        load_slot<false>(rowp, 2 * t, j, g, &w[0]);
-        load_slot<false>(rowp, 2 * t + 1, j, g, &w[4]);
-    } else {
-        load_slot<true>(rowp, 2 * t, j, g, &w[0]);
-        load_slot<true>(rowp, 2 * t + 1, j, g, &w[4]);
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// Software-pipelined tile loop (NG > 0): every wave keeps one whole tile (2*NG loads of 1 KiB) in flight.
-// Group t of the NEXT tile is requested into the registers group t of the CURRENT tile has just been counted
-// out of, so a tile's VALU work overlaps the HBM latency of the next tile inside the wave, with one register
-// set.  hipcc cannot be made to keep that order (it hoists the refills into a second register set and waits for
-// all of them before the first count), so the loads are inline asm and the vmcnt bookkeeping is ours:
-//   steady state, before counting group t: the VMEM ops issued after group t's two loads are
-//   2*(NG-1-t) loads of later groups + (<= 3 stores of the previous epilogue) + 2*t refills already issued
-//   => s_waitcnt vmcnt(2*(NG-1)) is sufficient whatever the stores do (loads retire in order; a store that
-//   retires early only lowers the counter, one that is still pending only makes us wait longer);
-//   last tile of the wave (no refills): vmcnt(2*(NG-1-t)).
-// Compiler-generated VMEM in the epilogue must be stores only (its own s_waitcnt accounting does not see the
-// asm loads; a compiler-inserted vmcnt(0) would be correct but would drain the prefetch).
-// ---------------------------------------------------------------------------------------------------------------
-typedef u32 u32x4 __attribute__((ext_vector_type(4)));
-
-// POL: cache policy of the streaming loads: 0 default, 1 nt, 2 sc1, 3 sc0 sc1 (the last three bypass the CU's L1)
-template <int OFF, int POL>
-__device__ __forceinline__ void gload16_asm(u32x4& dst, const char* p) {
-    if constexpr (POL == 0) asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(dst) : "v"(p), "i"(OFF) : "memory");
-    if constexpr (POL == 1) asm volatile("global_load_dwordx4 %0, %1, off offset:%2 nt" : "=v"(dst) : "v"(p), "i"(OFF) : "memory");
-    if constexpr (POL == 2) asm volatile("global_load_dwordx4 %0, %1, off offset:%2 sc1" : "=v"(dst) : "v"(p), "i"(OFF) : "memory");
-    if constexpr (POL == 3) asm volatile("global_load_dwordx4 %0, %1, off offset:%2 sc0 sc1" : "=v"(dst) : "v"(p), "i"(OFF) : "memory");
-}
-
-template <int N>
-__device__ __forceinline__ void wait_vm(u32x4& a, u32x4& b) {
-    asm volatile("s_waitcnt vmcnt(%2)" : "+v"(a), "+v"(b) : "i"(N) : "memory");
-}
-
-template <int I>
-struct IC { static constexpr int value = I; };
-
-template <int N, int I = 0, typename F>
-__device__ __forceinline__ void static_for(F&& f) {
-    if constexpr (I < N) {
-        f(IC<I>{});
-        static_for<N, I + 1>(f);
-    }
-}
-
-template <int S, int NG, int POL, typename Epilogue>
-__device__ __forceinline__ void tile_loop_pipelined(const char* __restrict__ X, long R, int N, long ldx, Epilogue&& epilogue) {
+// Tile loop.  A wave owns "super-tiles" of 32 consecutive bins = two 16-bin tiles counted back to back; NG > 0
+// issues all 2*NG loads of a tile up front (13.5 KB in flight per wave at N = 833), NG == 0 handles any N one group
+// at a time.  epilogue(half, row, valid, cnt) gets the lane's partial counts of one tile; finish(st, row0, rows) runs
+// once per super-tile so the outputs of 32 bins can be written as whole 128-byte lines (32 rows of H are 1152 bytes
+// = 9 lines; 36-byte row pieces written straight from the quads cost 0.35 ms of a 2.4 ms launch: partial-line
+// writes interleaved with the read stream).
+// Measured alternatives that were NOT faster and were removed: (a) refilling group t of the next tile right after
+// counting it, with inline-asm loads and hand-counted vmcnt (2.46 vs 2.33 ms); (b) flat line-granular loads staged
+// through LDS so that no 128-byte line is requested twice (2.40 ms); (c) nt / sc1 / sc0 sc1 loads (3.1-3.4 ms).
+template <int S, int NG, typename Epilogue, typename Finish>
+__device__ __forceinline__ void tile_loop(const char* __restrict__ X, long R, int N, long ldx, Epilogue&& epilogue, Finish&& finish) {
     const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // keep the tile index in SGPRs
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int j = lane & 3, b = lane >> 2;
     const RowGeom g = make_geom(N);
-    const long ntiles = (R + 15) >> 4;
-    const long stride = (long)gridDim.x * 4;
-    long tile = (long)blockIdx.x * 4 + wave;
-    if (tile >= ntiles) return;
-
-    // lane constants of the row's last group: clamped chunk offsets (relative to the lane base 16*j) and OR-masks
-    constexpr int TA = 2 * (NG - 1), TB = 2 * (NG - 1) + 1;      // slots of the last group
-    const int cA = 4 * TA + j, cB = 4 * TB + j;
-    const long offA = 16L * (cA < g.last ? cA : g.last) - 16L * j;
-    const long offB = 16L * (cB < g.last ? cB : g.last) - 16L * j;
-    u32 fix[8];
+    const long nsuper = (R + 31) >> 5;
+    for (long st = (long)blockIdx.x * 4 + wave; st < nsuper; st += (long)gridDim.x * 4) {
 #pragma unroll
-    for (int d = 0; d < 4; ++d) {
-        fix[d] = (cA > g.last ? 0xffffffffu : 0u) | (cA == g.last ? g.tail[d] : 0u);
-        fix[4 + d] = (cB > g.last ? 0xffffffffu : 0u) | (cB == g.last ? g.tail[d] : 0u);
-    }
-
-    u32x4 wa[NG], wb[NG];   // slot 2t and 2t+1 of group t
-    auto issue_group = [&](auto tc, const char* lanep) {
-        constexpr int t = decltype(tc)::value;
-        if constexpr (t < NG - 1) {
-            gload16_asm<128 * t, POL>(wa[t], lanep);
-            gload16_asm<128 * t + 64, POL>(wb[t], lanep);
-        } else {
-            gload16_asm<0, POL>(wa[t], lanep + offA);
-            gload16_asm<0, POL>(wb[t], lanep + offB);
+        for (int half = 0; half < 2; ++half) {
+            const long row = st * 32 + half * 16 + b;
+            const bool valid = row < R;
+            u32 cnt[S];
+#pragma unroll
+            for (int s = 0; s < S; ++s) cnt[s] = 0;
+            count_row<S, NG>(X + (valid ? row : R - 1) * ldx, j, g, cnt);
+            epilogue(half, row, valid, cnt);
         }
-    };
-    {
-        const long row = tile * 16 + b;
-        const char* lanep = X + (row < R ? row : R - 1) * ldx + 16 * j;
-        static_for<NG>([&](auto tc) { issue_group(tc, lanep); });
-    }
-    // one tile; HAS_NEXT is compile-time so the steady-state loop has no branches around the asm statements
-    // (a branch makes hipcc merge the "+v" operands of the waits through v_mov copies placed BEFORE the wait)
-    auto do_tile = [&](auto hn) {
-        constexpr bool HAS_NEXT = decltype(hn)::value != 0;
-        const long row = tile * 16 + b;
-        const long nrow = row + stride * 16;
-        const char* nlanep = X + (nrow < R ? nrow : R - 1) * ldx + 16 * j;
-        u32 cnt[S];
-#pragma unroll
-        for (int s = 0; s < S; ++s) cnt[s] = 0;
-        static_for<NG>([&](auto tc) {
-            constexpr int t = decltype(tc)::value;
-            wait_vm<HAS_NEXT ? 2 * (NG - 1) : 2 * (NG - 1 - t)>(wa[t], wb[t]);
-            u32 w[8] = {wa[t].x, wa[t].y, wa[t].z, wa[t].w, wb[t].x, wb[t].y, wb[t].z, wb[t].w};
-            if constexpr (t == NG - 1) {
-#pragma unroll
-                for (int d = 0; d < 8; ++d) w[d] |= fix[d];
-            }
-            count_group<S>(w, cnt);
-            // pin: every count of this group is complete before the refill below overwrites its registers
-            // (the asm statements keep their order; without this hipcc sinks the counting under all refills)
-#pragma unroll
-            for (int s = 0; s < S; ++s) asm volatile("" : "+v"(cnt[s]));
-            if constexpr (HAS_NEXT) issue_group(tc, nlanep);
-        });
-        epilogue(row, row < R, cnt);
-    };
-    for (; tile + stride < ntiles; tile += stride) do_tile(IC<1>{});
-    do_tile(IC<0>{});
-}
-
-// Plain tile loop: NG > 0 issues all loads of a tile up front, NG == 0 handles any N one group at a time.
-template <int S, int NG, typename Epilogue>
-__device__ __forceinline__ void tile_loop_simple(const char* __restrict__ X, long R, int N, long ldx, Epilogue&& epilogue) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int j = lane & 3, b = lane >> 2;
-    const RowGeom g = make_geom(N);
-    const long ntiles = (R + 15) >> 4;
-    for (long tile = (long)blockIdx.x * 4 + wave; tile < ntiles; tile += (long)gridDim.x * 4) {
-        const long row = tile * 16 + b;
-        const bool valid = row < R;
-        u32 cnt[S];
-#pragma unroll
-        for (int s = 0; s < S; ++s) cnt[s] = 0;
-        count_row<S, NG>(X + (valid ? row : R - 1) * ldx, j, g, cnt);
-        epilogue(row, valid, cnt);
+        const long row0 = st * 32;
+        finish(st, row0, (int)(R - row0 < 32 ? R - row0 : 32));
     }
 }
 

@@ -8,12 +8,27 @@ namespace epg {
 // K1: X[R, ldx] int8 -> H[R, S] uint16 (+ counts[S] += column sums).  HBM-bound: N bytes read, 2*S written per bin.
 // Restates np.unique(row, return_counts=True) of scores.py:341/444 and expected.py:111-113,152.
 // ---------------------------------------------------------------------------------------------------------------
-template <int S, int NG, int PIPE>
+// Store `nbytes` (a multiple of 4) staged in the wave's LDS buffer to `dst` (16-byte aligned): whole 16-byte chunks
+// with dwordx4 stores -- consecutive lanes, consecutive chunks, so every store instruction covers whole 128-byte
+// lines -- and a dword tail for a short last super-tile.
+__device__ __forceinline__ void store_staged(const char* lds, char* dst, int nbytes, int lane) {
+    const int nchunks = nbytes >> 4;
+    for (int c = lane; c < nchunks; c += 64)
+        *reinterpret_cast<uint4*>(dst + 16 * c) = *reinterpret_cast<const uint4*>(lds + 16 * c);
+    const int tail0 = nchunks << 4;
+    for (int o = tail0 + 4 * lane; o < nbytes; o += 256)
+        *reinterpret_cast<u32*>(dst + o) = *reinterpret_cast<const u32*>(lds + o);
+}
+
+template <int S, int NG>
 __global__ __launch_bounds__(256) void k_bin_hist(const char* __restrict__ X, long R, int N, long ldx,
                                                    u16* __restrict__ H, u64* __restrict__ counts) {
-    __shared__ u64 s_cnt[S + 1];
     constexpr int ND = (S + 1) / 2;
-    const int j = threadIdx.x & 3;
+    constexpr int ROWB = 2 * S;                        // bytes of one row of H
+    __shared__ u64 s_cnt[S + 1];
+    __shared__ __attribute__((aligned(16))) char s_stage[4][32 * ROWB];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 3, b = lane >> 2;
     if (threadIdx.x <= S) s_cnt[threadIdx.x] = 0;
     __syncthreads();
 
@@ -37,7 +52,7 @@ __global__ __launch_bounds__(256) void k_bin_hist(const char* __restrict__ X, lo
         since = 0;
     };
 
-    auto epilogue = [&](long row, bool valid, u32 (&cnt)[S]) {
+    auto epilogue = [&](int half, long row, bool valid, u32 (&cnt)[S]) {
         u32 d[ND];
         pack_reduce<S>(cnt, d);
         if (counts) {
@@ -45,32 +60,30 @@ __global__ __launch_bounds__(256) void k_bin_hist(const char* __restrict__ X, lo
             for (int m = 0; m < ND; ++m) accp[m] += valid ? d[m] : 0u;
             if (++since >= flush_every) flush();
         }
-        if (H && valid) {
-            u16* hrow = H + row * S;
+        if (H) {
+            // stage the bin's uint16 row: d[] already is that layout, one dword per pair of states
+            char* srow = &s_stage[wave][(half * 16 + b) * ROWB];
             if constexpr ((S & 1) == 0) {
-                // 2*S bytes per bin = ND dwords, dword m written by quad lane m & 3
-                u32* hp = reinterpret_cast<u32*>(hrow);
 #pragma unroll
                 for (int k = 0; k < (ND + 3) / 4; ++k) {
                     const u32 v = sel4(d[4 * k], 4 * k + 1 < ND ? d[4 * k + 1] : 0u, 4 * k + 2 < ND ? d[4 * k + 2] : 0u,
                                        4 * k + 3 < ND ? d[4 * k + 3] : 0u, j);
-                    if (4 * k + j < ND) hp[4 * k + j] = v;
+                    if (4 * k + j < ND) *reinterpret_cast<u32*>(srow + 4 * (4 * k + j)) = v;
                 }
             } else {
-                // odd S: rows are only 2-byte aligned, store uint16 s = 4k + j
 #pragma unroll
                 for (int k = 0; k < (S + 3) / 4; ++k) {
                     const u32 v = (j & 2) ? (2 * k + 1 < ND ? d[2 * k + 1] : 0u) : d[2 * k];
                     const u32 c = (j & 1) ? v >> 16 : v & 0xffffu;
-                    if (4 * k + j < S) hrow[4 * k + j] = (u16)c;
+                    if (4 * k + j < S) *reinterpret_cast<u16*>(srow + 2 * (4 * k + j)) = (u16)c;
                 }
             }
         }
     };
-    if constexpr (PIPE > 0 && NG > 0)
-        tile_loop_pipelined<S, NG, PIPE - 1>(X, R, N, ldx, epilogue);
-    else
-        tile_loop_simple<S, NG>(X, R, N, ldx, epilogue);
+    auto finish = [&](long st, long row0, int rows) {
+        if (H) store_staged(s_stage[wave], reinterpret_cast<char*>(H) + row0 * ROWB, rows * ROWB, lane);
+    };
+    tile_loop<S, NG>(X, R, N, ldx, epilogue, finish);
 
     if (counts) {
         flush();
@@ -120,55 +133,77 @@ __global__ void k_s1_table(const float* __restrict__ q, int N, int S, double* __
 // ---------------------------------------------------------------------------------------------------------------
 // S1 score straight from the state matrix: N bytes read + S*sizeof(OT) written per bin (scores.py:309-317).
 // ---------------------------------------------------------------------------------------------------------------
-template <int S, int NG, typename OT, bool PIPE>
+template <int S, int NG, typename OT>
 __global__ __launch_bounds__(256) void k_score_s1(const char* __restrict__ X, long R, int N, long ldx,
                                                    const OT* __restrict__ T, OT* __restrict__ out) {
     constexpr int ND = (S + 1) / 2;
-    const int j = threadIdx.x & 3;
-    auto epilogue = [&](long row, bool valid, u32 (&cnt)[S]) {
+    constexpr int ROWB = S * (int)sizeof(OT);
+    __shared__ __attribute__((aligned(16))) char s_stage[4][32 * ROWB];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 3, b = lane >> 2;
+    auto epilogue = [&](int half, long row, bool valid, u32 (&cnt)[S]) {
         u32 d[ND];
         pack_reduce<S>(cnt, d);
-        if (!valid) return;
-        OT* orow = out + row * S;
+        OT* srow = reinterpret_cast<OT*>(&s_stage[wave][(half * 16 + b) * ROWB]);
 #pragma unroll
         for (int k = 0; k < (S + 3) / 4; ++k) {
             const u32 v = (j & 2) ? (2 * k + 1 < ND ? d[2 * k + 1] : 0u) : d[2 * k];
             const u32 c = (j & 1) ? v >> 16 : v & 0xffffu;
             const int s = 4 * k + j;
-            if (s < S) orow[s] = c ? T[(long)c * S + s] : (OT)0;
+            if (s < S) srow[s] = (c && valid) ? T[(long)c * S + s] : (OT)0;
         }
     };
-    if constexpr (PIPE && NG > 0)
-        tile_loop_pipelined<S, NG, 0>(X, R, N, ldx, epilogue);
-    else
-        tile_loop_simple<S, NG>(X, R, N, ldx, epilogue);
+    auto finish = [&](long st, long row0, int rows) {
+        store_staged(s_stage[wave], reinterpret_cast<char*>(out) + row0 * ROWB, rows * ROWB, lane);
+    };
+    tile_loop<S, NG>(X, R, N, ldx, epilogue, finish);
 }
 
-// S1 score from cached histograms: 2*S bytes read + S*sizeof(OT) written per bin.  8 elements per thread.
+// S1 score from cached histograms: 2*S bytes read + S*sizeof(OT) written per bin.  A lane handles 4 consecutive
+// elements (8 bytes of H in, 16/32 bytes out); consecutive lanes take consecutive quads so every load and store
+// instruction covers whole contiguous lines; 4 quads in flight per lane.
 template <typename OT>
 __global__ __launch_bounds__(256) void k_score_s1_from_hist(const u16* __restrict__ H, long total, int S,
                                                              const OT* __restrict__ T, OT* __restrict__ out) {
-    const long e0 = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 8;
-    if (e0 >= total) return;
-    int s = (int)(e0 % S);
-    if (e0 + 8 <= total) {
-        const uint4 hv = *reinterpret_cast<const uint4*>(H + e0);
-        const u32 hw[4] = {hv.x, hv.y, hv.z, hv.w};
-        OT v[8];
+    const long nquads = total >> 2;
+    const long stride = (long)gridDim.x * 256;
+    long qd = (long)blockIdx.x * 256 + threadIdx.x;
+    for (; qd + 3 * stride < nquads; qd += 4 * stride) {
+        uint2 h[4];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const u32 c = (hw[k >> 1] >> (16 * (k & 1))) & 0xffffu;
-            v[k] = c ? T[(long)c * S + s] : (OT)0;
+        for (int u = 0; u < 4; ++u) h[u] = *reinterpret_cast<const uint2*>(H + 4 * (qd + u * stride));
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const long e0 = 4 * (qd + u * stride);
+            int s = (int)(e0 % S);
+            const u32 c[4] = {h[u].x & 0xffffu, h[u].x >> 16, h[u].y & 0xffffu, h[u].y >> 16};
+            OT v[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                v[k] = c[k] ? T[(long)c[k] * S + s] : (OT)0;
+                s = s + 1 == S ? 0 : s + 1;
+            }
+            if constexpr (sizeof(OT) == 4) {
+                *reinterpret_cast<float4*>(out + e0) = make_float4(v[0], v[1], v[2], v[3]);
+            } else {
+                *reinterpret_cast<double2*>(out + e0) = make_double2(v[0], v[1]);
+                *reinterpret_cast<double2*>(out + e0 + 2) = make_double2(v[2], v[3]);
+            }
+        }
+    }
+    for (; qd < nquads; qd += stride) {
+        const long e0 = 4 * qd;
+        int s = (int)(e0 % S);
+        for (int k = 0; k < 4; ++k) {
+            const u32 c = H[e0 + k];
+            out[e0 + k] = c ? T[(long)c * S + s] : (OT)0;
             s = s + 1 == S ? 0 : s + 1;
         }
-#pragma unroll
-        for (int k = 0; k < 8; ++k) out[e0 + k] = v[k];
-    } else {
-        for (long e = e0; e < total; ++e) {
-            const u32 c = H[e];
-            out[e] = c ? T[(long)c * S + s] : (OT)0;
-            s = s + 1 == S ? 0 : s + 1;
-        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (total & 3)) {
+        const long e = (nquads << 2) + threadIdx.x;
+        const u32 c = H[e];
+        out[e] = c ? T[(long)c * S + (int)(e % S)] : (OT)0;
     }
 }
 
@@ -203,22 +238,19 @@ __global__ __launch_bounds__(256) void k_normalise(const IT* __restrict__ C, lon
 // ---------------------------------------------------------------------------------------------------------------
 extern int g_blocks_per_cu;
 static int grid_for_tiles(long R) {
-    const long ntiles = (R + 15) >> 4;
-    long blocks = (ntiles + 3) / 4;
+    const long nsuper = (R + 31) >> 5;
+    long blocks = (nsuper + 3) / 4;
     const long cap = (long)num_cus() * g_blocks_per_cu;
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
     return (int)blocks;
 }
 
-int g_variant = 0;  // tuning hook (epg_debug_set_variant): 0 = loads-up-front tile loop (fastest measured), 1 = software-pipelined
-int g_blocks_per_cu = 4;
+int g_blocks_per_cu = 4;  // persistent grid size (epg_debug_set_variant tunes it for A/B runs)
 
 template <int S, int NG>
 static void launch_bin_hist(const char* X, long R, int N, long ldx, u16* H, u64* counts, hipStream_t st) {
-    const dim3 grid(grid_for_tiles(R)), block(256);
-    if (NG == 0 || g_variant == 0) hipLaunchKernelGGL((k_bin_hist<S, NG, 0>), grid, block, 0, st, X, R, N, ldx, H, counts);
-    else hipLaunchKernelGGL((k_bin_hist<S, NG, 1>), grid, block, 0, st, X, R, N, ldx, H, counts);
+    hipLaunchKernelGGL((k_bin_hist<S, NG>), dim3(grid_for_tiles(R)), dim3(256), 0, st, X, R, N, ldx, H, counts);
 }
 
 template <int S>
@@ -249,6 +281,7 @@ int bin_hist_impl(const int8_t* X8, int64_t R, int32_t N, int64_t ldx, int32_t S
     if (N > 65535) return fail(EPG_ERR_UNSUPPORTED, "bin_hist: N=%d > 65535 (uint16 per-bin counts)", N);
     if (R == 0) return EPG_OK;
     if (!X8) return fail(EPG_ERR_INVALID_ARG, "bin_hist: X is NULL");
+    if (H && (reinterpret_cast<uintptr_t>(H) & 15)) return fail(EPG_ERR_INVALID_ARG, "bin_hist: H must be 16-byte aligned");
     const char* X = reinterpret_cast<const char*>(X8);
     u64* cnt = reinterpret_cast<u64*>(counts);
     const long Rf = fast_rows(R, N, ldx);
@@ -275,10 +308,7 @@ int bin_hist_impl(const int8_t* X8, int64_t R, int32_t N, int64_t ldx, int32_t S
 
 template <int S, int NG, typename OT>
 static void launch_score_s1(const char* X, long R, int N, long ldx, const OT* T, OT* out, hipStream_t st) {
-    if (g_variant == 1 && NG > 0)
-        hipLaunchKernelGGL((k_score_s1<S, NG, OT, true>), dim3(grid_for_tiles(R)), dim3(256), 0, st, X, R, N, ldx, T, out);
-    else
-        hipLaunchKernelGGL((k_score_s1<S, NG, OT, false>), dim3(grid_for_tiles(R)), dim3(256), 0, st, X, R, N, ldx, T, out);
+    hipLaunchKernelGGL((k_score_s1<S, NG, OT>), dim3(grid_for_tiles(R)), dim3(256), 0, st, X, R, N, ldx, T, out);
 }
 
 template <typename OT>
@@ -320,12 +350,17 @@ int score_s1_from_hist_impl(const uint16_t* H, int64_t R, int32_t N, int32_t S, 
     if (R == 0) return EPG_OK;
     if (!H || !q || !ws) return fail(EPG_ERR_INVALID_ARG, "score_s1_from_binhist: NULL argument");
     if (ws_bytes < s1_table_bytes(N, S)) return fail(EPG_ERR_WORKSPACE, "score_s1: workspace %lld < %lld bytes", (long long)ws_bytes, (long long)s1_table_bytes(N, S));
-    if ((reinterpret_cast<uintptr_t>(H) & 15) != 0) return fail(EPG_ERR_INVALID_ARG, "score_s1_from_binhist: H must be 16-byte aligned");
+    if ((reinterpret_cast<uintptr_t>(H) & 7) != 0) return fail(EPG_ERR_INVALID_ARG, "score_s1_from_binhist: H must be 8-byte aligned");
+    if ((out32 && (reinterpret_cast<uintptr_t>(out32) & 15)) || (out64 && (reinterpret_cast<uintptr_t>(out64) & 15)))
+        return fail(EPG_ERR_INVALID_ARG, "score_s1_from_binhist: outputs must be 16-byte aligned");
     double* T64; float* T32;
     int rc = build_s1_table(q, N, S, ws, &T64, &T32, st);
     if (rc) return rc;
     const long total = (long)R * S;
-    const int blocks = (int)((total / 8 + 256) / 256);
+    long nb = (total / 4 + 1023) / 1024;
+    if (nb > num_cus() * 16L) nb = num_cus() * 16L;
+    if (nb < 1) nb = 1;
+    const int blocks = (int)nb;
     if (out32) hipLaunchKernelGGL((k_score_s1_from_hist<float>), dim3(blocks), dim3(256), 0, st, H, total, S, T32, out32);
     if (out64) hipLaunchKernelGGL((k_score_s1_from_hist<double>), dim3(blocks), dim3(256), 0, st, H, total, S, T64, out64);
     EPG_LAUNCH_CHECK("k_score_s1_from_hist");
@@ -338,6 +373,8 @@ int score_s1_impl(const int8_t* X8, int64_t R, int32_t N, int64_t ldx, int32_t S
     if (S > 31) return fail(EPG_ERR_UNSUPPORTED, "score_s1: S=%d > 31 not supported by this build", S);
     if (R == 0) return EPG_OK;
     if (!X8 || !q || !ws) return fail(EPG_ERR_INVALID_ARG, "score_s1: NULL argument");
+    if ((out32 && (reinterpret_cast<uintptr_t>(out32) & 15)) || (out64 && (reinterpret_cast<uintptr_t>(out64) & 15)))
+        return fail(EPG_ERR_INVALID_ARG, "score_s1: outputs must be 16-byte aligned");
     const long Rf = fast_rows(R, N, ldx);
     const bool fused = S == 18 && Rf == R;
     if (!fused) {

@@ -55,6 +55,11 @@ for rnd in range(a.rounds + 1):
             t = timed(lambda: engine.bin_hist(X, N, S, counts=counts, H=H))
             if rnd:
                 res.setdefault((cfg, "bin_hist"), []).append(t)
+        if "nowrite" in a.what:
+            counts.zero_()
+            t = timed(lambda: engine.bin_hist(X, N, S, counts=counts, want_hist=False))
+            if rnd:
+                res.setdefault((cfg, "hist_noH"), []).append(t)
         if "score" in a.what:
             t = timed(lambda: engine.score_s1(X, N, S, q, out32=out32, ws=ws))
             if rnd:
