@@ -24,39 +24,53 @@ constexpr int S3_TB = 64;             // b biosamples per block (= lanes of a wa
 constexpr int S3_SLICE = 65535;       // bins per slice: packed uint16 counters cannot overflow
 constexpr int S3_LDS_BUDGET = 150 * 1024;
 
-__global__ __launch_bounds__(256) void k_s3_hist(const char* __restrict__ X, long R, int N, long ldx, int S, int TA,
-                                                  int n_btiles, int* __restrict__ counts) {
+constexpr int S3H_THREADS = 1024;     // 16 waves per block: the block owns the CU's LDS, so occupancy must come from its size
+constexpr int S3H_UNROLL = 4;         // bins per wave iteration (independent loads in flight)
+
+__global__ __launch_bounds__(S3H_THREADS) void k_s3_hist(const char* __restrict__ X, long R, int N, long ldx, int S, int TA,
+                                                          int n_btiles, int* __restrict__ counts) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     u32* hist = reinterpret_cast<u32*>(smem);
     const int SS = S * S;
     const int words = (TA * S3_TB * SS + 1) / 2;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    constexpr int NW = S3H_THREADS / 64;
     const long tile = blockIdx.x;                 // (a-tile, b-tile)
     const int a0 = (int)(tile / n_btiles) * TA;
     const int b = (int)(tile % n_btiles) * S3_TB + lane;
     const long r0 = (long)blockIdx.y * S3_SLICE;
     const long r1 = r0 + S3_SLICE < R ? r0 + S3_SLICE : R;
 
-    for (int w = threadIdx.x; w < words; w += 256) hist[w] = 0;
+    for (int w = threadIdx.x; w < words; w += S3H_THREADS) hist[w] = 0;
     __syncthreads();
 
     const bool b_ok = b < N;
-    for (long row = r0 + wave; row < r1; row += 4) {
-        const char* rp = X + row * ldx;
-        const int xb = b_ok ? (int)(unsigned char)rp[b] : 255;
-        if (xb < S) {
-            for (int ta = 0; ta < TA; ++ta) {
+    const int bcl = b_ok ? b : 0;
+    for (long rb = r0 + (long)wave * S3H_UNROLL; rb < r1; rb += (long)NW * S3H_UNROLL) {
+        int xb[S3H_UNROLL], xa[S3H_UNROLL][4];
+#pragma unroll
+        for (int u = 0; u < S3H_UNROLL; ++u) {
+            const long row = rb + u < r1 ? rb + u : r1 - 1;        // clamp: loads stay in bounds, masked below
+            const char* rp = X + row * ldx;
+            xb[u] = (int)(unsigned char)rp[bcl];
+#pragma unroll
+            for (int ta = 0; ta < 4; ++ta) xa[u][ta] = (int)(unsigned char)rp[a0 + ta < N ? a0 + ta : 0];
+        }
+#pragma unroll
+        for (int u = 0; u < S3H_UNROLL; ++u) {
+            if (rb + u >= r1 || !b_ok || xb[u] >= S) continue;
+#pragma unroll
+            for (int ta = 0; ta < 4; ++ta) {
                 const int a = a0 + ta;
-                if (a >= N || a == b) continue;
-                const int xa = (int)(unsigned char)rp[a];
-                if (xa >= S) continue;
-                const int idx = (ta * S3_TB + lane) * SS + xa * S + xb;
+                if (ta >= TA || a >= N || a == b || xa[u][ta] >= S) continue;
+                const int idx = (ta * S3_TB + lane) * SS + xa[u][ta] * S + xb[u];
                 atomicAdd(&hist[idx >> 1], 1u << (16 * (idx & 1)));
             }
         }
     }
     __syncthreads();
-    for (int w = threadIdx.x; w < words; w += 256) {
+    for (int w = threadIdx.x; w < words; w += S3H_THREADS) {
         const u32 v = hist[w];
         if (!v) continue;
 #pragma unroll
@@ -97,7 +111,9 @@ __global__ void k_s3_table(const float* __restrict__ q, int N, int S, float* __r
 
 constexpr int S3_SCORE_SLICE = 8192;
 
-__global__ __launch_bounds__(256) void k_s3_score(const char* __restrict__ X, long R, int N, long ldx, int S,
+constexpr int S3S_THREADS = 512;
+
+__global__ __launch_bounds__(S3S_THREADS) void k_s3_score(const char* __restrict__ X, long R, int N, long ldx, int S,
                                                    const float* __restrict__ T2, double* __restrict__ out64) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* tile = reinterpret_cast<float*>(smem);                                        // [N*S]
@@ -112,7 +128,7 @@ __global__ __launch_bounds__(256) void k_s3_score(const char* __restrict__ X, lo
     if (threadIdx.x == 0) present = 0;
     __syncthreads();
     u32 mine = 0;
-    for (int k = threadIdx.x; k < nb; k += 256) {
+    for (int k = threadIdx.x; k < nb; k += S3S_THREADS) {
         const unsigned char v = (unsigned char)X[(r0 + k) * ldx + b];
         col[k] = v;
         if (v < S) mine |= 1u << v;
@@ -125,10 +141,11 @@ __global__ __launch_bounds__(256) void k_s3_score(const char* __restrict__ X, lo
         if (!((have >> s) & 1u)) continue;       // block-uniform
         __syncthreads();                           // previous tile fully consumed
         const float* src = T2 + ((long)b * S + s) * N * S;
-        for (int e = threadIdx.x; e < N * S; e += 256) tile[e] = src[e];
+        for (int e = threadIdx.x; e < N * S; e += S3S_THREADS) tile[e] = src[e];
         __syncthreads();
-        // each wave scans a quarter of the slice, 64 bins at a time
-        const int per = (nb + 3) / 4;
+        // each wave scans its share of the slice, 64 bins at a time
+        constexpr int NW = S3S_THREADS / 64;
+        const int per = (nb + NW - 1) / NW;
         const int k0 = wave * per, k1 = (k0 + per) < nb ? (k0 + per) : nb;
         for (int kb = k0; kb < k1; kb += 64) {
             const int k = kb + lane;
@@ -177,7 +194,7 @@ int hist_s3_impl(const int8_t* X8, int64_t R, int32_t N, int64_t ldx, int32_t S,
     if (nslices > 65535) return fail(EPG_ERR_UNSUPPORTED, "hist_s3: R=%lld too large for one call (max %lld bins)", (long long)R, 65535LL * S3_SLICE);
     const size_t shmem = (size_t)((TA * S3_TB * S * S + 1) / 2) * 4;
     EPG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_s3_hist), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-    hipLaunchKernelGGL(k_s3_hist, dim3((unsigned)(n_atiles * n_btiles), (unsigned)nslices), dim3(256), shmem, st,
+    hipLaunchKernelGGL(k_s3_hist, dim3((unsigned)(n_atiles * n_btiles), (unsigned)nslices), dim3(S3H_THREADS), shmem, st,
                        reinterpret_cast<const char*>(X8), (long)R, N, (long)ldx, S, TA, n_btiles, counts);
     EPG_LAUNCH_CHECK("k_s3_hist");
     return EPG_OK;
@@ -203,7 +220,7 @@ int score_s3_impl(const int8_t* X8, int64_t R, int32_t N, int64_t ldx, int32_t S
     const long nslices = (R + S3_SCORE_SLICE - 1) / S3_SCORE_SLICE;
     if (nslices * N > 0x7fffffffL) return fail(EPG_ERR_UNSUPPORTED, "score_s3: R*N too large for one call");
     EPG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_s3_score), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-    hipLaunchKernelGGL(k_s3_score, dim3((unsigned)(nslices * N)), dim3(256), shmem, st, reinterpret_cast<const char*>(X8), (long)R, N,
+    hipLaunchKernelGGL(k_s3_score, dim3((unsigned)(nslices * N)), dim3(S3S_THREADS), shmem, st, reinterpret_cast<const char*>(X8), (long)R, N,
                        (long)ldx, S, T2, acc);
     EPG_LAUNCH_CHECK("k_s3_score");
     if (out32) {

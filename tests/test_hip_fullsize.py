@@ -1,0 +1,79 @@
+"""GPU tests at BASELINE.json's full size (15 M bins x 833 biosamples x 18 states, synthetic, generated on device):
+size-independent properties instead of an oracle comparison (the oracle would need hours).  torch reductions are the
+independent checker."""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+
+pytestmark = pytest.mark.gpu
+S, N, R = 18, 833, 15_000_000
+
+
+@pytest.fixture(scope="module")
+def world():
+    import bench
+    from epilogos_amd import engine
+    engine.require_gpu()
+    X = engine.alloc_states(R, N)
+    bench.generate_shard(torch, X, N, S, 0)
+    H, counts = engine.bin_hist(X, N, S)
+    torch.cuda.synchronize()
+    return engine, X, H, counts
+
+
+def test_every_state_byte_is_counted_once(world):
+    eng, X, H, counts = world
+    assert int(counts.sum().item()) == R * N                         # nothing lost, nothing double counted
+    rows = H.to(torch.int32).sum(dim=1)
+    assert int(rows.min().item()) == N and int(rows.max().item()) == N    # every bin's histogram sums to N
+    colsum = H.to(torch.int64).sum(dim=0)                            # independent reduction of the cached histograms
+    assert torch.equal(colsum, counts)
+    # checksum of checksums against torch's own count of each state in the padded matrix
+    for s in (0, 5, 17):
+        assert int((X[:, :N] == s).sum().item()) == int(counts[s].item())
+
+
+def test_counts_are_additive_over_bin_ranges(world):
+    """The multi-GPU partition rule: counts of contiguous ranges add up to the whole (helpers.splitRows, 8 ranks)."""
+    eng, X, H, counts = world
+    from epilogos_amd.helpers import splitRows
+    acc = torch.zeros(S, dtype=torch.int64, device="cuda")
+    for lo, hi in splitRows(R, 8):
+        Hs, _ = eng.bin_hist(X[lo:hi], N, S, counts=acc)
+        if lo in (0, splitRows(R, 8)[5][0]):
+            assert torch.equal(Hs, H[lo:hi])                          # a shard's histograms are the slice of the whole
+    assert torch.equal(acc, counts)
+
+
+def test_s1_scores_full_size(world):
+    eng, X, H, counts = world
+    q = eng.normalise(counts)
+    assert abs(float(q.sum().item()) - 1.0) < 1e-6
+    a32, _ = eng.score_s1_from_binhist(H, N, S, q)
+    b32, _ = eng.score_s1(X, N, S, q)
+    assert torch.equal(a32, b32)                                     # cached-histogram and fused routes: identical bits
+    assert bool(torch.isfinite(a32).all())
+    # KL property: sum_s p_s log2(p_s/q_s) >= 0 for every bin (float32 rounding of each term allowed)
+    assert float(a32.sum(dim=1).min().item()) > -1e-5
+    # spot check 4096 scattered bins against the float64 definition evaluated with torch
+    idx = torch.arange(0, R, R // 4096, device="cuda")[:4096]
+    p = H[idx].to(torch.float64) / N
+    qq = q.to(torch.float64)
+    ref = torch.where(p > 0, p * torch.log2(p / qq), torch.zeros_like(p))
+    torch.testing.assert_close(a32[idx].to(torch.float64), ref, rtol=1e-6, atol=1e-7)
+
+
+def test_s2_counts_full_size(world):
+    eng, X, H, counts = world
+    c2 = eng.hist_s2_from_binhist(H, S)
+    assert int(c2.sum().item()) == R * N * (N - 1)                   # ordered pairs of distinct biosamples per bin
+    c2m = c2.view(S, S)
+    assert torch.equal(c2m, c2m.t())                                 # symmetric
+    # row sums: sum_j C[i,j] = (N-1) * sum_b h_i
+    assert torch.equal(c2m.sum(dim=1), counts * (N - 1))
+    q2 = eng.normalise(c2)
+    sub = H[:200_000]
+    o32, o64 = eng.score_s2_from_binhist(sub, N, S, q2, want32=True, want64=True)
+    assert bool(torch.isfinite(o64).all())
+    assert float(o64.sum(dim=1).min().item()) > -1e-9                # a KL divergence per bin
