@@ -56,12 +56,17 @@ def cpu_baseline(n_biosamples, n_states, target_seconds=12.0):
                       "workers" % (bins, secs, sample, n_biosamples, cores)}
 
 
-def generate_shard(torch, X, n_biosamples, n_states, bin0):
+def generate_shard(torch, X, n_biosamples, n_states, bin0, dist="chr1"):
     """Fill X[:, :N] with synthetic states for global bins [bin0, bin0 + R): global chunk k of 2^20 bins is drawn
-    from torch.Generator seeded 1234 + k in fixed sub-blocks, so the matrix does not depend on the GPU count."""
+    from torch.Generator seeded 1234 + k in fixed sub-blocks, so the matrix does not depend on the GPU count.
+    dist: "chr1" = i.i.d. empirical chr1 state frequencies (the headline workload); "uniform" = uniform
+    states (contention-free control); "correlated" = each bin copies its predecessor with probability 0.83 and 41 % of
+    bins are forced all-quiescent (the stress shape for shared-counter histograms)."""
     R = X.shape[0]
     dev = X.device
     p = FREQS[:n_states] / FREQS[:n_states].sum()
+    if dist == "uniform":
+        p = np.full(n_states, 1.0 / n_states)
     bounds = torch.tensor(np.cumsum(p)[:-1], dtype=torch.float32, device=dev)
     X.fill_(-1)
     gen = torch.Generator(device=dev)
@@ -77,6 +82,18 @@ def generate_shard(torch, X, n_biosamples, n_states, bin0):
             st = torch.bucketize(u[lo - g0:hi - g0], bounds, right=True).to(torch.int8)
             X[lo - bin0:hi - bin0, :n_biosamples] = st
             del u, st
+    if dist == "correlated":
+        gen.manual_seed(99 + bin0)
+        step = 1 << 20
+        for r0 in range(0, R, step):
+            r1 = min(r0 + step, R)
+            r = torch.rand(r1 - r0, generator=gen, device=dev)
+            quiescent = r < 0.41
+            X[r0:r1][quiescent, :n_biosamples] = n_states - 1
+            copy = (r >= 0.41) & (r < 0.41 + 0.83 * 0.59)
+            idx = torch.nonzero(copy, as_tuple=False).flatten() + r0
+            idx = idx[idx > 0]
+            X[idx, :n_biosamples] = X[idx - 1, :n_biosamples]    # copies the (already final) predecessor of most bins
 
 
 def main():
@@ -89,6 +106,7 @@ def main():
     ap.add_argument("--states", type=int, default=18)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--packed", action="store_true", help="row pitch = biosamples (unaligned rows) instead of 16-byte padded")
+    ap.add_argument("--dist", choices=["chr1", "uniform", "correlated"], default="chr1", help="synthetic state distribution")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -120,7 +138,7 @@ def main():
         X = flat[:R * N].view(R, N)
     else:
         X = engine.alloc_states(R, N, device=dev)
-    generate_shard(torch, X, N, S, rank * R)
+    generate_shard(torch, X, N, S, rank * R, dist=args.dist)
     H = torch.empty((R, S), dtype=torch.int16, device=dev)
     counts = torch.zeros(S, dtype=torch.int64, device=dev)
     q = torch.empty(S, dtype=torch.float32, device=dev)
@@ -189,7 +207,7 @@ def main():
             "dtype": "u8", "data": "synthetic",
             "config": {"workload": "S1 saliency, whole-genome scale: %d bins x %d biosamples x %d states per GPU, "
                                    "expected pass + count all-reduce + normalise + score pass per step" % (R, N, S),
-                       "bins_per_gpu": R, "biosamples": N, "states": S, "saliency": 1,
+                       "bins_per_gpu": R, "biosamples": N, "states": S, "saliency": 1, "state_distribution": args.dist,
                        "row_pitch_bytes": int(X.stride(0)),
                        "partition": "contiguous bin ranges per GPU (helpers.splitRows rule), one RCCL all-reduce of int64[%d]" % S},
             "roofline": {"bound": "hbm", "kernel": "k_bin_hist", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
