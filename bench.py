@@ -107,6 +107,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--packed", action="store_true", help="row pitch = biosamples (unaligned rows) instead of 16-byte padded")
     ap.add_argument("--dist", choices=["chr1", "uniform", "correlated"], default="chr1", help="synthetic state distribution")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to test the "
+                                                      "multi-rank path on a box with one GPU, ranks then share cuda:0)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -126,11 +128,16 @@ def main():
     import torch.distributed as dist
     from epilogos_amd import engine
     engine.require_gpu()
+    if args.backend != "nccl":
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend=args.backend)
 
     # ---- resident inputs and preallocated outputs
     if args.packed:

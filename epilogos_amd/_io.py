@@ -1,0 +1,130 @@
+"""ctypes binding of include/epilogos_io.h (native TSV parser + score writer, host side)."""
+import ctypes as C
+import io
+
+import numpy as np
+
+from . import build as _build
+
+_lib = None
+
+
+class EpilogosIOError(RuntimeError):
+    pass
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = _build.IO_LIB_PATH
+    if not path.exists():
+        raise EpilogosIOError("%s is missing: build it with `python -m epilogos_amd.build`" % path)
+    lib = C.CDLL(str(path))
+    p, i64, i32 = C.c_void_p, C.c_int64, C.c_int32
+    lib.epgio_last_error.restype = C.c_char_p
+    lib.epgio_count_rows.restype = i64
+    lib.epgio_count_rows.argtypes = [C.c_char_p]
+    lib.epgio_open_table.restype = p
+    lib.epgio_open_table.argtypes = [C.c_char_p, i64, i64, i32]
+    lib.epgio_table_rows.restype = i64
+    lib.epgio_table_rows.argtypes = [p]
+    lib.epgio_table_cols.restype = i32
+    lib.epgio_table_cols.argtypes = [p]
+    lib.epgio_table_copy_states.restype = C.c_int
+    lib.epgio_table_copy_states.argtypes = [p, p, i64]
+    lib.epgio_table_locations.restype = p
+    lib.epgio_table_locations.argtypes = [p, C.POINTER(p)]
+    lib.epgio_close_table.restype = None
+    lib.epgio_close_table.argtypes = [p]
+    lib.epgio_write_scores.restype = C.c_int
+    lib.epgio_write_scores.argtypes = [C.c_char_p, p, p, p, i64, i32, i32, i32]
+    lib.epgio_format_f5.restype = i64
+    lib.epgio_format_f5.argtypes = [p, i64, C.c_char, p, i64]
+    _lib = lib
+    return lib
+
+
+def _err():
+    return load().epgio_last_error().decode(errors="replace")
+
+
+def count_rows(path):
+    n = load().epgio_count_rows(str(path).encode())
+    if n < 0:
+        raise EpilogosIOError(_err())
+    return int(n)
+
+
+class Locations:
+    """First three columns of every row as the file wrote them: a byte blob ("chr\\tstart\\tend\\n" per row) + offsets."""
+
+    def __init__(self, blob, offsets):
+        self.blob = blob            # np.uint8 [total]
+        self.offsets = offsets      # np.int64 [rows + 1]
+
+    def __len__(self):
+        return len(self.offsets) - 1
+
+    def slice(self, lo, hi):
+        off = self.offsets[lo:hi + 1]
+        return Locations(self.blob[off[0]:off[-1]], (off - off[0]).astype(np.int64))
+
+    def to_object_array(self):
+        """[rows, 3] object array like the reference's locationArr (pandas-parsed: scores.py:161)."""
+        import pandas as pd
+        if len(self) == 0:
+            return np.empty((0, 3), dtype=object)
+        return pd.read_table(io.BytesIO(self.blob.tobytes()), header=None, sep="\t").to_numpy()
+
+    @staticmethod
+    def from_object_array(loc):
+        rows = ["{}\t{}\t{}\n".format(r[0], r[1], r[2]).encode() for r in loc]
+        off = np.zeros(len(rows) + 1, dtype=np.int64)
+        np.cumsum([len(r) for r in rows], out=off[1:])
+        return Locations(np.frombuffer(b"".join(rows), dtype=np.uint8).copy(), off)
+
+
+def read_table(path, rows=None, threads=0, ldx=None):
+    """Parse rows [lo, hi) of a TSV(.gz) matrix file.  Returns (int8 states [R, ldx or N], Locations)."""
+    lib = load()
+    lo, hi = (0, -1) if rows is None else rows
+    h = lib.epgio_open_table(str(path).encode(), lo, hi, threads)
+    if not h:
+        raise EpilogosIOError(_err())
+    try:
+        R, N = lib.epgio_table_rows(h), lib.epgio_table_cols(h)
+        width = N if ldx is None else ldx
+        states = np.empty((R, width), dtype=np.int8)
+        if lib.epgio_table_copy_states(h, states.ctypes.data, width) != 0:
+            raise EpilogosIOError(_err())
+        offp = C.c_void_p()
+        locp = lib.epgio_table_locations(h, C.byref(offp))
+        off = np.ctypeslib.as_array(C.cast(offp, C.POINTER(C.c_int64)), shape=(R + 1,)).copy()
+        blob = (np.ctypeslib.as_array(C.cast(locp, C.POINTER(C.c_uint8)), shape=(int(off[-1]),)).copy()
+                if R else np.zeros(0, dtype=np.uint8))
+    finally:
+        lib.epgio_close_table(h)
+    return states, Locations(blob, off)
+
+
+def write_scores(path, locations, scores, threads=0, gzip_level=6):
+    scores = np.ascontiguousarray(scores, dtype=np.float32)
+    R, S = scores.shape
+    if len(locations) != R:
+        raise ValueError("locations and scores disagree on the number of rows")
+    blob = np.ascontiguousarray(locations.blob)
+    off = np.ascontiguousarray(locations.offsets, dtype=np.int64)
+    rc = load().epgio_write_scores(str(path).encode(), blob.ctypes.data, off.ctypes.data, scores.ctypes.data, R, S,
+                                   threads, gzip_level)
+    if rc != 0:
+        raise EpilogosIOError(_err())
+
+
+def format_f5(values, sep="\t"):
+    v = np.ascontiguousarray(values, dtype=np.float32).reshape(-1)
+    buf = np.empty(48 * v.size + 1, dtype=np.uint8)
+    n = load().epgio_format_f5(v.ctypes.data, v.size, sep.encode(), buf.ctypes.data, buf.size)
+    if n < 0:
+        raise EpilogosIOError(_err())
+    return buf[:n].tobytes()

@@ -29,6 +29,38 @@ def is_stale():
     return any(d.stat().st_mtime > t for d in deps)
 
 
+IO_LIB_PATH = LIB_DIR / "libepilogos_io.so"
+IO_SOURCE = CSRC / "epg_io.cpp"
+IO_HEADER = ROOT / "include" / "epilogos_io.h"
+
+
+def io_is_stale():
+    if not IO_LIB_PATH.exists():
+        return True
+    t = IO_LIB_PATH.stat().st_mtime
+    return IO_SOURCE.stat().st_mtime > t or IO_HEADER.stat().st_mtime > t
+
+
+def build_io_library(force=False, verbose=False):
+    """Host-side native TSV parser / score writer (g++, zlib, pthreads)."""
+    if not force and not io_is_stale():
+        return IO_LIB_PATH
+    LIB_DIR.mkdir(parents=True, exist_ok=True)
+    cxx = shutil.which("g++") or shutil.which("c++")
+    if cxx is None:
+        raise RuntimeError("g++ not found: cannot build libepilogos_io.so")
+    tmp = LIB_DIR / (IO_LIB_PATH.name + ".tmp.%d" % os.getpid())
+    cmd = [cxx, "-O3", "-std=c++17", "-fPIC", "-shared", "-pthread", "-I" + str(ROOT / "include"), str(IO_SOURCE),
+           "-lz", "-o", str(tmp)]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise RuntimeError("g++ failed:\n" + res.stdout + res.stderr)
+    os.replace(tmp, IO_LIB_PATH)
+    return IO_LIB_PATH
+
+
 def build_library(force=False, verbose=False, extra_flags=()):
     """Compile every HIP source into one shared library.  Returns the path."""
     if not force and not is_stale():
@@ -49,3 +81,4 @@ def build_library(force=False, verbose=False, extra_flags=()):
 
 if __name__ == "__main__":
     print(build_library(force=True, verbose=True))
+    print(build_io_library(force=True, verbose=True))

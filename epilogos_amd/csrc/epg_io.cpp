@@ -1,0 +1,353 @@
+// libepilogos_io.so -- native TSV(.gz) parser and "%.5f"/gzip writer (host C++17, zlib + std::thread).
+// Contract: include/epilogos_io.h.
+#include "epilogos_io.h"
+
+#include <zlib.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return -1;
+}
+
+bool ends_with_gz(const char* path) {
+    const size_t n = strlen(path);
+    return n >= 2 && path[n - 2] == 'g' && path[n - 1] == 'z';   // the reference's test: name.endswith("gz")
+}
+
+int n_threads(int32_t req) {
+    if (req > 0) return req;
+    const unsigned hc = std::thread::hardware_concurrency();
+    return hc ? (int)std::min(hc, 64u) : 4;
+}
+
+// whole (decompressed) file in memory; gzread also passes plain files through unchanged
+bool slurp(const char* path, std::vector<char>& buf) {
+    gzFile f = gzopen(path, "rb");
+    if (!f) { fail("cannot open %s", path); return false; }
+    gzbuffer(f, 1 << 20);
+    size_t used = 0;
+    buf.resize(1 << 24);
+    for (;;) {
+        if (buf.size() - used < (1 << 22)) buf.resize(buf.size() * 2);
+        const int got = gzread(f, buf.data() + used, (unsigned)std::min<size_t>(buf.size() - used, 1u << 30));
+        if (got < 0) { int e; fail("read error in %s: %s", path, gzerror(f, &e)); gzclose(f); return false; }
+        if (got == 0) break;
+        used += (size_t)got;
+    }
+    gzclose(f);
+    buf.resize(used);
+    return true;
+}
+
+}  // namespace
+
+struct epgio_table {
+    int64_t rows = 0;
+    int32_t cols = 0;
+    std::vector<int8_t> states;     // [rows * cols]
+    std::vector<char> loc;          // concatenated "chr\tstart\tend"
+    std::vector<int64_t> loc_off;   // [rows + 1]
+};
+
+extern "C" {
+
+const char* epgio_last_error(void) { return g_err; }
+
+int64_t epgio_count_rows(const char* path) {
+    gzFile f = gzopen(path, "rb");
+    if (!f) return fail("cannot open %s", path);
+    gzbuffer(f, 1 << 20);
+    std::vector<char> buf(1 << 22);
+    int64_t total = 0;
+    for (;;) {
+        const int got = gzread(f, buf.data(), (unsigned)buf.size());
+        if (got < 0) { gzclose(f); return fail("read error in %s", path); }
+        if (got == 0) break;
+        const char* p = buf.data();
+        const char* e = p + got;
+        while ((p = (const char*)memchr(p, '\n', (size_t)(e - p)))) { ++total; ++p; }
+    }
+    gzclose(f);
+    (void)ends_with_gz;
+    return total;
+}
+
+epgio_table* epgio_open_table(const char* path, int64_t row_lo, int64_t row_hi, int32_t threads) {
+    std::vector<char> buf;
+    if (!slurp(path, buf)) return nullptr;
+    const char* base = buf.data();
+    const char* end = base + buf.size();
+    // complete lines only (the reference counts newlines, helpers.py:94: a dangling last line does not exist)
+    const char* last_nl = nullptr;
+    for (const char* p = end; p > base;) { --p; if (*p == '\n') { last_nl = p; break; } }
+    if (!last_nl) { auto* t = new epgio_table(); t->loc_off.assign(1, 0); return t; }
+    end = last_nl + 1;
+
+    const int T = n_threads(threads);
+    // segment borders on line starts
+    std::vector<const char*> seg(T + 1);
+    seg[0] = base;
+    for (int i = 1; i < T; ++i) {
+        const char* p = base + (size_t)((end - base) / T) * i;
+        if (p < seg[i - 1]) p = seg[i - 1];
+        const char* nl = (const char*)memchr(p, '\n', (size_t)(end - p));
+        seg[i] = nl ? nl + 1 : end;
+    }
+    seg[T] = end;
+    std::vector<int64_t> seg_rows(T, 0);
+    {
+        std::vector<std::thread> th;
+        for (int i = 0; i < T; ++i)
+            th.emplace_back([&, i] {
+                int64_t n = 0;
+                const char* p = seg[i];
+                while (p < seg[i + 1] && (p = (const char*)memchr(p, '\n', (size_t)(seg[i + 1] - p)))) { ++n; ++p; }
+                seg_rows[i] = n;
+            });
+        for (auto& t : th) t.join();
+    }
+    std::vector<int64_t> seg_first(T + 1, 0);
+    for (int i = 0; i < T; ++i) seg_first[i + 1] = seg_first[i] + seg_rows[i];
+    const int64_t total = seg_first[T];
+    if (row_hi < 0 || row_hi > total) row_hi = total;
+    if (row_lo < 0) row_lo = 0;
+    if (row_lo > row_hi) row_lo = row_hi;
+
+    // number of state columns from the first line
+    int32_t cols = 0;
+    {
+        const char* nl = (const char*)memchr(base, '\n', (size_t)(end - base));
+        int tabs = 0;
+        for (const char* p = base; p < nl; ++p) tabs += *p == '\t';
+        cols = tabs - 2;
+        if (cols < 1) { fail("%s: expected at least 4 tab-separated columns, found %d", path, tabs + 1); return nullptr; }
+    }
+    auto* t = new epgio_table();
+    t->rows = row_hi - row_lo;
+    t->cols = cols;
+    t->states.resize((size_t)t->rows * cols);
+    t->loc_off.assign((size_t)t->rows + 1, 0);
+
+    // pass 1: location text lengths; pass 2 (after prefix sum): states + location text.  Both per segment.
+    std::vector<int> err(T, 0);
+    std::vector<int64_t> bad_row(T, -1);
+    auto for_rows = [&](int i, auto&& fn) {
+        const char* p = seg[i];
+        int64_t r = seg_first[i];
+        while (p < seg[i + 1]) {
+            const char* nl = (const char*)memchr(p, '\n', (size_t)(seg[i + 1] - p));
+            if (r >= row_hi) break;
+            if (r >= row_lo) fn(r - row_lo, p, nl);
+            p = nl + 1;
+            ++r;
+        }
+    };
+    {
+        std::vector<std::thread> th;
+        for (int i = 0; i < T; ++i)
+            th.emplace_back([&, i] {
+                for_rows(i, [&](int64_t r, const char* p, const char* nl) {
+                    int tabs = 0;
+                    const char* q = p;
+                    for (; q < nl; ++q)
+                        if (*q == '\t' && ++tabs == 3) break;
+                    t->loc_off[(size_t)r + 1] = q - p + 1; // length (+ the '\n' that terminates the row's text) for now
+                });
+            });
+        for (auto& x : th) x.join();
+    }
+    for (int64_t r = 0; r < t->rows; ++r) t->loc_off[(size_t)r + 1] += t->loc_off[(size_t)r];
+    t->loc.resize((size_t)t->loc_off[(size_t)t->rows]);
+    {
+        std::vector<std::thread> th;
+        for (int i = 0; i < T; ++i)
+            th.emplace_back([&, i] {
+                for_rows(i, [&](int64_t r, const char* p, const char* nl) {
+                    const int64_t len = t->loc_off[(size_t)r + 1] - t->loc_off[(size_t)r] - 1;
+                    memcpy(t->loc.data() + t->loc_off[(size_t)r], p, (size_t)len);
+                    t->loc[(size_t)(t->loc_off[(size_t)r] + len)] = '\n';
+                    const char* q = p + len;
+                    int8_t* out = t->states.data() + (size_t)r * cols;
+                    int c = 0;
+                    while (q < nl && c < cols) {
+                        ++q;                                // the tab before the value
+                        int v = 0;
+                        bool neg = false, any = false;
+                        if (q < nl && *q == '-') { neg = true; ++q; }
+                        while (q < nl && *q >= '0' && *q <= '9') { v = v * 10 + (*q - '0'); ++q; any = true; if (v > 100000) break; }
+                        if (q < nl && *q == '\r') ++q;
+                        if (!any || (q < nl && *q != '\t')) { err[i] = 1; if (bad_row[i] < 0) bad_row[i] = r; return; }
+                        v = (neg ? -v : v) - 1;             // file states are 1-based (helpers.py:155)
+                        out[c++] = (int8_t)(v < -128 ? -128 : (v > 127 ? 127 : v));
+                    }
+                    if (c != cols || q != nl) { err[i] = 1; if (bad_row[i] < 0) bad_row[i] = r; }
+                });
+            });
+        for (auto& x : th) x.join();
+    }
+    for (int i = 0; i < T; ++i)
+        if (err[i]) {
+            fail("%s: malformed line at row %lld (expected %d integer state columns)", path, (long long)(bad_row[i] + row_lo), cols);
+            delete t;
+            return nullptr;
+        }
+    return t;
+}
+
+int64_t epgio_table_rows(const epgio_table* t) { return t ? t->rows : fail("null table"); }
+int32_t epgio_table_cols(const epgio_table* t) { return t ? t->cols : fail("null table"); }
+
+int epgio_table_copy_states(const epgio_table* t, int8_t* out, int64_t ldx) {
+    if (!t || !out || ldx < t->cols) return fail("copy_states: bad argument");
+    for (int64_t r = 0; r < t->rows; ++r) {
+        memcpy(out + r * ldx, t->states.data() + (size_t)r * t->cols, (size_t)t->cols);
+        if (ldx > t->cols) memset(out + r * ldx + t->cols, 0xff, (size_t)(ldx - t->cols));
+    }
+    return 0;
+}
+
+const char* epgio_table_locations(const epgio_table* t, const int64_t** offsets) {
+    if (!t) { fail("null table"); return nullptr; }
+    if (offsets) *offsets = t->loc_off.data();
+    return t->loc.data();
+}
+
+void epgio_close_table(epgio_table* t) { delete t; }
+
+}  // extern "C"
+
+namespace {
+
+// Exact "%.5f" of a float32: round-half-even of the exact binary value times 1e5 (what Python's float formatting does
+// for float(v)), sign kept for -0.0 and for negatives that round to zero.
+inline char* fmt_f5(float f, char* o) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    const bool neg = u >> 31;
+    const int ex = (int)((u >> 23) & 0xff);
+    const uint32_t man = u & 0x7fffffu;
+    if (ex == 255) {
+        if (man) { memcpy(o, "nan", 3); return o + 3; }
+        if (neg) *o++ = '-';
+        memcpy(o, "inf", 3);
+        return o + 3;
+    }
+    const uint64_t m = ex ? (man | 0x800000u) : man;
+    const int e = ex ? ex - 150 : -149;
+    unsigned __int128 q;
+    if (e >= 0) {
+        if (e > 80) { return o + sprintf(o, "%.5f", (double)f); }
+        q = ((unsigned __int128)(m * 100000ull)) << e;
+    } else {
+        const int sh = -e;
+        const uint64_t num = m * 100000ull;                 // < 2^41
+        if (sh >= 64) {
+            q = 0;                                          // num < 2^41 <= half of 2^sh: rounds to 0
+        } else {
+            uint64_t qq = num >> sh;
+            const uint64_t rem = num & ((1ull << sh) - 1), half = 1ull << (sh - 1);
+            if (rem > half || (rem == half && (qq & 1))) ++qq;
+            q = qq;
+        }
+    }
+    if (neg) *o++ = '-';
+    const uint64_t frac = (uint64_t)(q % 100000u);
+    unsigned __int128 ip = q / 100000u;
+    char tmp[48];
+    int n = 0;
+    if (ip == 0) tmp[n++] = '0';
+    while (ip) { tmp[n++] = (char)('0' + (int)(ip % 10)); ip /= 10; }
+    while (n) *o++ = tmp[--n];
+    *o++ = '.';
+    o[4] = (char)('0' + frac % 10); o[3] = (char)('0' + frac / 10 % 10); o[2] = (char)('0' + frac / 100 % 10);
+    o[1] = (char)('0' + frac / 1000 % 10); o[0] = (char)('0' + frac / 10000 % 10);
+    return o + 5;
+}
+
+bool gzip_member(const std::vector<char>& in, int level, std::vector<unsigned char>& out) {
+    z_stream zs;
+    memset(&zs, 0, sizeof(zs));
+    if (deflateInit2(&zs, level, Z_DEFLATED, 15 + 16, 8, Z_DEFAULT_STRATEGY) != Z_OK) return false;
+    out.resize(deflateBound(&zs, (uLong)in.size()) + 64);
+    zs.next_in = (Bytef*)in.data();
+    zs.avail_in = (uInt)in.size();
+    zs.next_out = out.data();
+    zs.avail_out = (uInt)out.size();
+    const int rc = deflate(&zs, Z_FINISH);
+    out.resize(zs.total_out);
+    deflateEnd(&zs);
+    return rc == Z_STREAM_END;
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t epgio_format_f5(const float* v, int64_t n, char sep, char* buf, int64_t cap) {
+    if (cap < 48 * n) return fail("format_f5: buffer too small");
+    char* o = buf;
+    for (int64_t i = 0; i < n; ++i) { o = fmt_f5(v[i], o); *o++ = sep; }
+    return o - buf;
+}
+
+int epgio_write_scores(const char* path, const char* loc, const int64_t* loc_off, const float* scores, int64_t R, int32_t S,
+                       int32_t threads, int32_t gzip_level) {
+    if (!path || (R > 0 && (!loc || !loc_off || !scores)) || S < 1) return fail("write_scores: bad argument");
+    if (gzip_level < 1 || gzip_level > 9) gzip_level = 6;
+    FILE* f = fopen(path, "wb");
+    if (!f) return fail("cannot create %s", path);
+    const int T = n_threads(threads);
+    const int64_t CH = 32768;                                   // rows per gzip member
+    const int64_t nchunks = (R + CH - 1) / CH;
+    if (R == 0) {                                               // an empty gzip stream, like gzip.open(..).close()
+        std::vector<unsigned char> z;
+        gzip_member(std::vector<char>(), gzip_level, z);
+        fwrite(z.data(), 1, z.size(), f);
+    }
+    bool ok = true;
+    for (int64_t c0 = 0; c0 < nchunks && ok; c0 += T) {
+        const int nb = (int)std::min<int64_t>(T, nchunks - c0);
+        std::vector<std::vector<unsigned char>> z(nb);
+        std::vector<int> good(nb, 0);
+        std::vector<std::thread> th;
+        for (int k = 0; k < nb; ++k)
+            th.emplace_back([&, k] {
+                const int64_t r0 = (c0 + k) * CH, r1 = std::min(R, r0 + CH);
+                std::vector<char> txt((size_t)((loc_off[r1] - loc_off[r0]) + (r1 - r0) * (2 + 48 * (int64_t)S)));
+                char* o = txt.data();
+                for (int64_t r = r0; r < r1; ++r) {
+                    const int64_t len = loc_off[r + 1] - loc_off[r] - 1;   // without the row's '\n'
+                    memcpy(o, loc + loc_off[r], (size_t)len);
+                    o += len;
+                    const float* row = scores + r * S;
+                    for (int s = 0; s < S; ++s) { *o++ = '\t'; o = fmt_f5(row[s], o); }
+                    *o++ = '\n';
+                }
+                txt.resize((size_t)(o - txt.data()));
+                good[k] = gzip_member(txt, gzip_level, z[k]);
+            });
+        for (auto& x : th) x.join();
+        for (int k = 0; k < nb && ok; ++k) {
+            if (!good[k] || fwrite(z[k].data(), 1, z[k].size(), f) != z[k].size()) ok = false;
+        }
+    }
+    if (fclose(f) != 0) ok = false;
+    return ok ? 0 : fail("write error on %s", path);
+}
+
+}  // extern "C"

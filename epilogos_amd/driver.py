@@ -8,7 +8,6 @@ counts global, every rank normalises identically, pass 2 scores locally with no 
 sums make the result independent of G and of the reduction order.  Outputs keep the reference's names: every rank
 writes gzip members for its bin ranges and rank 0 concatenates them per chromosome (a multi-member gzip file is
 a valid gzip file)."""
-import gzip
 import os
 import shutil
 from pathlib import Path
@@ -16,8 +15,8 @@ from pathlib import Path
 import numpy as np
 
 from . import backend as _backend
-from .helpers import countRows, fileStem, readLocations, readStates, splitRows
-from .scores import formatScores
+from .helpers import countRows, fileStem, readLocations, readStates, readTable, splitRows
+from .scores import writeScores
 
 
 def plan_partition(rows_per_file, world):
@@ -70,10 +69,13 @@ def run_single_group(files, numStates, saliency, outputDir, fileTag, verbose=Fal
     my_parts = plan_partition(rows, d.world)[d.rank]
 
     # STEP 1: local counts over my bin ranges
-    counts, chunks = None, []
-    for (fi, lo, hi) in my_parts:
-        x = readStates(file1Path=files[fi], rowsToCalc=(lo, hi), verbose=verbose)
+    counts, chunks, locs = None, [], []
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=max(1, min(8, len(my_parts)))) as pool:   # gz inflate is serial per file
+        tables = list(pool.map(lambda part: readTable(files[part[0]], (part[1], part[2])), my_parts))
+    for (fi, lo, hi), (x, loc) in zip(my_parts, tables):
         chunks.append(x)
+        locs.append(loc)
         c = be.expected_counts(x, numStates, saliency)
         counts = c if counts is None else counts + c
     if counts is None:   # a rank without bins still takes part in the collective
@@ -88,13 +90,11 @@ def run_single_group(files, numStates, saliency, outputDir, fileTag, verbose=Fal
         np.save(outputDir / "exp_freq_{}.npy".format(fileTag), q, allow_pickle=False)
 
     # STEP 3: local scores, written as gzip members per (file, range)
-    for (fi, lo, hi), x in zip(my_parts, chunks):
+    for (fi, lo, hi), x, loc in zip(my_parts, chunks, locs):
         sc = be.scores(x, numStates, saliency, q)
-        loc = readLocations(files[fi], (lo, hi))
         stem = fileStem(files[fi])
         part = outputDir / ".part_scores_{}_{}_{:012d}.gz".format(fileTag, stem, lo)
-        with gzip.open(part, "wt") as g:
-            g.write(formatScores(sc, loc))
+        writeScores(sc, part, loc)
         np.save(outputDir / ".part_scores_{}_{}_{:012d}.npy".format(fileTag, stem, lo), sc, allow_pickle=False)
     d.barrier()
     if d.rank == 0:

@@ -2,11 +2,12 @@
 (getNumStates :9-17, strToBool :47-60, countRows :80-99, splitRows :102-120, readStates :123-194), minus the pieces that
 belong to ROI/plotting.  States come back as int8 (0-based) instead of the reference's int64: that is the layout the
 GPU kernels stream."""
-import gzip
 from pathlib import Path
 
 import numpy as np
 import pandas as pd
+
+from . import _io
 
 
 def getNumStates(stateFile):
@@ -25,17 +26,8 @@ def strToBool(string):
 
 def countRows(dataFilePath):
     """Number of newline characters in a (gz) file (reference helpers.py:80-99).  Like the reference, a final line
-    without a trailing newline is not counted (quirk Q6)."""
-    dataFilePath = Path(dataFilePath)
-    opener = gzip.open if dataFilePath.name.endswith("gz") else open
-    total = 0
-    with opener(dataFilePath, "rb") as f:
-        while True:
-            block = f.read(1 << 20)
-            if not block:
-                break
-            total += block.count(b"\n")
-    return total
+    without a trailing newline is not counted (quirk Q6).  Native (zlib) reader."""
+    return _io.count_rows(Path(dataFilePath))
 
 
 def splitRows(totalRows, numProcesses):
@@ -43,18 +35,18 @@ def splitRows(totalRows, numProcesses):
     return [(i * totalRows // numProcesses, (i + 1) * totalRows // numProcesses) for i in range(numProcesses)]
 
 
+def readTable(path, rowsToCalc=None):
+    """Rows [lo, hi) of a matrix file through the native multi-threaded parser: int8 0-based states
+    [rows, N] and the rows' first three columns as written (a _io.Locations)."""
+    states, loc = _io.read_table(Path(path), rowsToCalc)
+    return states, loc
+
+
 def _read_int8(path, rowsToCalc):
-    path = Path(path)
-    ncols = pd.read_table(path, nrows=1, header=None, sep="\t").shape[1]
-    nrows = rowsToCalc[1] - rowsToCalc[0]
-    if nrows <= 0:
+    if rowsToCalc[1] - rowsToCalc[0] <= 0:
+        ncols = pd.read_table(Path(path), nrows=1, header=None, sep="\t").shape[1]
         return np.zeros((0, ncols - 3), dtype=np.int8)
-    df = pd.read_table(path, usecols=range(3, ncols), skiprows=rowsToCalc[0], nrows=nrows, header=None, sep="\t",
-                       dtype=np.int16)
-    arr = df.to_numpy(dtype=np.int16) - 1          # file states are 1-based (reference helpers.py:154-155)
-    if arr.size and (arr.min() < -128 or arr.max() > 127):
-        raise ValueError("state value out of int8 range in {}".format(path))
-    return arr.astype(np.int8)
+    return readTable(path, rowsToCalc)[0]
 
 
 def readStates(file1Path=Path("null"), file2Path=Path("null"), rowsToCalc=(0, 0), expBool=True, verbose=True,
@@ -78,11 +70,9 @@ def readStates(file1Path=Path("null"), file2Path=Path("null"), rowsToCalc=(0, 0)
 
 
 def readLocations(filePath, rowsToCalc=None):
-    """First three columns (chromosome, start, end), echoed verbatim into the outputs (reference scores.py:161)."""
-    kw = {}
-    if rowsToCalc is not None:
-        kw = dict(skiprows=rowsToCalc[0], nrows=rowsToCalc[1] - rowsToCalc[0])
-    return pd.read_table(Path(filePath), header=None, sep="\t", usecols=[0, 1, 2], **kw).to_numpy()
+    """First three columns (chromosome, start, end) as an object array like the reference's locationArr
+    (scores.py:161)."""
+    return readTable(filePath, rowsToCalc)[1].to_object_array()
 
 
 def fileStem(path):

@@ -3,15 +3,15 @@ epilogos/scores.py (main :14-56, calculateScores :116-169, calculateScoresPairwi
   single: scores_{tag}_{stem}.txt.gz and temp_scores_{tag}_{stem}.npz {chrName, scoreArr float32, locationArr object}
   paired: pairwiseDelta_{tag}_{stem}.txt.gz, temp_nullDistances_{tag}_{stem}.npz, temp_quiescence_{tag}_{stem}.npz
 All arithmetic runs on the GPU through the C ABI."""
-import gzip
 from pathlib import Path
 from sys import argv
 from time import time
 
 import numpy as np
 
+from . import _io
 from . import backend as _backend
-from .helpers import countRows, fileStem, readLocations, readStates, strToBool
+from .helpers import countRows, fileStem, readStates, readTable, strToBool
 
 NULL_SEED = None   # paired nulls are unseeded in the reference (helpers.py:183); set an int for reproducible runs
 
@@ -35,10 +35,10 @@ def calculateScores(saliency, file1Path, totalRows, numStates, outputDirPath, ex
     if saliency not in (1, 2, 3):
         raise ValueError("Please ensure that saliency metric is either 1, 2, or 3")
     expFreqArr = np.load(expFreqPath, allow_pickle=False)
-    dataArr = readStates(file1Path=file1Path, rowsToCalc=(0, totalRows), verbose=verbose)
+    dataArr, locations = readTable(file1Path, (0, totalRows))
     scoreArr = _backend.get().scores(dataArr, numStates, saliency, expFreqArr)
-    locationArr = readLocations(file1Path)[:totalRows]
-    writeScores(scoreArr, outputDirPath / "scores_{}_{}.txt.gz".format(fileTag, filename), locationArr)
+    writeScores(scoreArr, outputDirPath / "scores_{}_{}.txt.gz".format(fileTag, filename), locations)
+    locationArr = locations.to_object_array()
     chrName = locationArr[0, 0]
     np.savez_compressed(outputDirPath / "temp_scores_{}_{}.npz".format(fileTag, filename), chrName=np.array([chrName]),
                         scoreArr=scoreArr, locationArr=locationArr)
@@ -50,7 +50,7 @@ def calculateScoresPairwise(saliency, file1Path, file2Path, totalRows, numStates
         raise ValueError("Please ensure that saliency metric is either 1 or 2 for Pairwise Epilogos")
     be = _backend.get()
     expFreqArr = np.load(expFreqPath, allow_pickle=False)
-    file1Arr = readStates(file1Path=file1Path, rowsToCalc=(0, totalRows), verbose=verbose)
+    file1Arr, locations = readTable(file1Path, (0, totalRows))
     file2Arr = readStates(file1Path=file2Path, rowsToCalc=(0, totalRows), verbose=verbose)
     n1, n2 = file1Arr.shape[1], file2Arr.shape[1]
     perms1, perms2 = n1 * (n1 - 1), n2 * (n2 - 1)
@@ -62,31 +62,22 @@ def calculateScoresPairwise(saliency, file1Path, file2Path, totalRows, numStates
     _, nullDistancesArr = be.pair_finish(null1, null2)
     quiescenceArr = be.quiescent(file1Arr, file2Arr, quiescentState)
 
-    locationArr = readLocations(file1Path)[:totalRows]
-    writeScores(realDiffArr, outputDirPath / "pairwiseDelta_{}_{}.txt.gz".format(fileTag, filename), locationArr)
-    chrName = locationArr[0, 0]
+    writeScores(realDiffArr, outputDirPath / "pairwiseDelta_{}_{}.txt.gz".format(fileTag, filename), locations)
+    chrName = locations.slice(0, 1).to_object_array()[0, 0]
     np.savez_compressed(outputDirPath / "temp_nullDistances_{}_{}.npz".format(fileTag, filename),
                         chrName=np.array([chrName]), nullDistances=nullDistancesArr)
     np.savez_compressed(outputDirPath / "temp_quiescence_{}_{}.npz".format(fileTag, filename),
                         chrName=np.array([chrName]), quiescenceArr=quiescenceArr)
 
 
-def formatScores(dataArr, locationArr):
-    """Text of the reference's writeScores (scores.py:530-532): 'chr\\tstart\\tend\\t' + '%.5f' values, tab separated."""
-    dataArr = np.asarray(dataArr, dtype=np.float32)
-    cells = np.char.mod("%.5f", dataArr.astype(np.float64))   # float32 -> float64 is exact: same digits as format()
-    out = []
-    for i in range(dataArr.shape[0]):
-        loc = locationArr[i]
-        out.append("{}\t{}\t{}\t{}\n".format(loc[0], loc[1], loc[2], "\t".join(cells[i])))
-    return "".join(out)
-
-
-def writeScores(dataArr, outputTxtPath, locationArr, chunk=200000):
-    """gzip text file, one line per bin (reference scores.py:509-536)."""
-    with gzip.open(outputTxtPath, "wt") as outputTxt:
-        for r0 in range(0, dataArr.shape[0], chunk):
-            outputTxt.write(formatScores(dataArr[r0:r0 + chunk], locationArr[r0:r0 + chunk]))
+def writeScores(dataArr, outputTxtPath, locationArr, gzip_level=6):
+    """gzip text file, one line per bin: 'chr\\tstart\\tend\\t' + '%.5f' values (reference scores.py:509-536).
+    Native writer: exact '%.5f' of the float32 values, one gzip member per 32768 rows compressed in
+    parallel; the decompressed bytes equal the reference's.  locationArr: a _io.Locations (verbatim input columns) or
+    the reference's [rows, 3] object array."""
+    if not isinstance(locationArr, _io.Locations):
+        locationArr = _io.Locations.from_object_array(locationArr)
+    _io.write_scores(outputTxtPath, locationArr, np.asarray(dataArr, dtype=np.float32), gzip_level=gzip_level)
 
 
 if __name__ == "__main__":

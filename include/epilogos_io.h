@@ -1,0 +1,60 @@
+/*
+ * epilogos_io.h -- C ABI of libepilogos_io.so: native input codec and output writer of the scoring path
+ * (SURVEY.md section 8, rows f1 and f2).  Host-side C++ (no GPU): what the reference does with pandas / str.format /
+ * single-threaded gzip in
+ *     epilogos/helpers.py:80-99    countRows            -> epgio_count_rows
+ *     epilogos/helpers.py:152-155  readStates (parse)   -> epgio_open_table / epgio_table_copy_states
+ *     epilogos/scores.py:161       locationArr          -> epgio_table_locations
+ *     epilogos/scores.py:509-536   writeScores          -> epgio_write_scores
+ *
+ * Input format (reference README.md:127-134): tab-separated, no header, optionally gzip; columns 1-3 = chromosome,
+ * start, end (echoed verbatim to the outputs), columns 4.. = one integer state per biosample, 1-based.
+ * Output format (scores.py:530-531): "chr\tstart\tend\t" + S values formatted "%.5f" of the float32, tab separated,
+ * one line per bin, gzip.  The writer emits one gzip member per chunk of rows (a multi-member gzip file is a valid
+ * gzip file); the decompressed bytes are identical to the reference's.
+ *
+ * All functions are thread-safe with respect to different handles/paths.  Errors: negative return (or NULL) and
+ * epgio_last_error() (thread-local).
+ */
+#ifndef EPILOGOS_IO_H
+#define EPILOGOS_IO_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct epgio_table epgio_table;
+
+const char* epgio_last_error(void);
+
+/* Number of '\n' characters in the (gz) file -- like the reference, a last line without newline is not counted. */
+int64_t epgio_count_rows(const char* path);
+
+/* Parse rows [row_lo, row_hi) (row_hi < 0: to the end of the file) with `threads` parser threads (0 = all cores).
+ * Returns a handle owning the parsed table, or NULL. */
+epgio_table* epgio_open_table(const char* path, int64_t row_lo, int64_t row_hi, int32_t threads);
+int64_t epgio_table_rows(const epgio_table* t);
+int32_t epgio_table_cols(const epgio_table* t);          /* number of state columns N */
+/* Copy the 0-based int8 states (file value - 1) into out[r * ldx + c]; bytes c >= N of a row are set to -1. */
+int epgio_table_copy_states(const epgio_table* t, int8_t* out, int64_t ldx);
+/* Verbatim text of the first three columns of every row, each terminated by '\n' ("chr\tstart\tend\n"),
+ * concatenated; offsets[r]..offsets[r+1] delimit row r (newline included).  Valid until epgio_close_table. */
+const char* epgio_table_locations(const epgio_table* t, const int64_t** offsets);
+void epgio_close_table(epgio_table* t);
+
+/* Write R lines: location text of row r (loc + loc_off[r] .. loc_off[r+1], its trailing '\n' dropped) + '\t' + S
+ * "%.5f" values + '\n'.
+ * gzip_level 1..9 (the reference's gzip.open default is 9; 6 is the usual speed/size trade-off), threads 0 = all. */
+int epgio_write_scores(const char* path, const char* loc, const int64_t* loc_off, const float* scores, int64_t R,
+                       int32_t S, int32_t threads, int32_t gzip_level);
+
+/* Format n float32 values exactly like Python's "%.5f" % float(v) (correctly rounded, "-0.00000" kept), each followed
+ * by `sep`; returns the number of bytes written to buf (cap must be >= 48*n).  Exposed for tests. */
+int64_t epgio_format_f5(const float* v, int64_t n, char sep, char* buf, int64_t cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EPILOGOS_IO_H */

@@ -66,3 +66,18 @@ def test_engine_refuses_to_run_without_gpu():
         pytest.skip("GPU present")
     with pytest.raises(_abi.EpilogosHipError):
         engine.require_gpu()
+
+
+def test_io_library_exports_its_header():
+    import re
+    from pathlib import Path
+    from epilogos_amd import _io
+    if build.io_is_stale():
+        build.build_io_library()
+    lib = _io.load()
+    hdr = (Path(__file__).resolve().parents[1] / "include" / "epilogos_io.h").read_text()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    names = sorted(set(re.findall(r"\b(epgio_[a-z0-9_]+)\s*\(", hdr)))
+    assert len(names) >= 9
+    for n in names:
+        assert hasattr(lib, n), n

@@ -1,0 +1,110 @@
+"""CPU tests of the native input codec and score writer (libepilogos_io.so) against pandas / Python formatting and the
+reference's golden text."""
+import gzip
+import struct
+
+import numpy as np
+import pandas as pd
+import pytest
+
+from epilogos_amd import _io, helpers
+from tests.test_host_logic import write_tsv
+
+S = 18
+
+
+def _pandas_states(path, lo, hi):
+    ncols = pd.read_table(path, nrows=1, header=None, sep="\t").shape[1]
+    df = pd.read_table(path, usecols=range(3, ncols), skiprows=lo, nrows=hi - lo, header=None, sep="\t")
+    return (df.to_numpy(dtype=int) - 1).astype(np.int8)
+
+
+@pytest.mark.parametrize("suffix", [".txt", ".txt.gz"])
+def test_parser_matches_pandas(tmp_path, suffix):
+    rng = np.random.default_rng(5)
+    x = rng.integers(0, S, size=(5003, 37)).astype(np.int8)
+    f = tmp_path / ("matrix_chr7" + suffix)
+    write_tsv(f, x, chrom="chr7", start0=1000)
+    assert helpers.countRows(f) == 5003
+    st, loc = _io.read_table(f)
+    assert st.dtype == np.int8 and np.array_equal(st, x)
+    assert np.array_equal(st, _pandas_states(f, 0, 5003))
+    la = loc.to_object_array()
+    ref = pd.read_table(f, header=None, sep="\t", usecols=[0, 1, 2]).to_numpy()
+    assert la.shape == (5003, 3) and (la == ref).all()
+    for lo, hi in ((0, 1), (17, 4100), (5002, 5003), (100, 100)):
+        st, loc = _io.read_table(f, (lo, hi), threads=3)
+        assert np.array_equal(st, x[lo:hi]) and len(loc) == hi - lo
+    st, _ = _io.read_table(f, (4000, 99999), threads=1)        # hi clamps to the file
+    assert np.array_equal(st, x[4000:])
+    st, _ = _io.read_table(f, ldx=48)                            # padded rows: pad bytes are -1
+    assert st.shape == (5003, 48) and np.array_equal(st[:, :37], x) and (st[:, 37:] == -1).all()
+
+
+def test_parser_edge_cases(tmp_path):
+    x = np.arange(12, dtype=np.int8).reshape(3, 4) % S
+    write_tsv(tmp_path / "nonl.txt", x, trailing_newline=False)
+    st, loc = _io.read_table(tmp_path / "nonl.txt")
+    assert st.shape == (2, 4)                                    # quirk Q6: the unterminated last line does not exist
+    (tmp_path / "bad.txt").write_text("chr1\t0\t200\t1\t2\nchr1\t200\t400\t1\n")
+    with pytest.raises(_io.EpilogosIOError):
+        _io.read_table(tmp_path / "bad.txt")
+    (tmp_path / "alpha.txt").write_text("chr1\t0\t200\t1\tx\n")
+    with pytest.raises(_io.EpilogosIOError):
+        _io.read_table(tmp_path / "alpha.txt")
+    with pytest.raises(_io.EpilogosIOError):
+        _io.read_table(tmp_path / "missing.txt")
+    (tmp_path / "zero.txt").write_text("chrX\t0\t200\t0\t19\n")     # 0 -> -1 and 19 -> 18: kept, rejected downstream
+    st, _ = _io.read_table(tmp_path / "zero.txt")
+    assert st.tolist() == [[-1, 18]]
+    (tmp_path / "crlf.txt").write_text("chr1\t0\t200\t3\t4\r\nchr1\t200\t400\t5\t6\r\n")
+    st, _ = _io.read_table(tmp_path / "crlf.txt")
+    assert st.tolist() == [[2, 3], [4, 5]]
+
+
+def test_writer_reproduces_reference_bytes(tmp_path, golden_real, golden_edge):
+    g = golden_real
+    R = g["x"].shape[0]
+    f = tmp_path / "in.txt"
+    write_tsv(f, g["x"], start0=int(g["start0"]))
+    _, loc = _io.read_table(f)
+    out = tmp_path / "scores.txt.gz"
+    _io.write_scores(out, loc, g["s1_f32"], threads=3)
+    with gzip.open(out, "rb") as fh:
+        assert fh.read() == g["s1_text"].tobytes()              # the reference's writeScores output, byte for byte
+    # object-array locations (the reference's locationArr) and the '-0.00000' case
+    from epilogos_amd.scores import writeScores
+    writeScores(golden_edge["fmt_vals"], tmp_path / "fmt.txt.gz", np.array([["chrX", 200, 400]], dtype=object))
+    with gzip.open(tmp_path / "fmt.txt.gz", "rb") as fh:
+        assert fh.read() == golden_edge["fmt_text"].tobytes()
+    _io.write_scores(tmp_path / "empty.txt.gz", _io.Locations(np.zeros(0, np.uint8), np.zeros(1, np.int64)),
+                     np.zeros((0, S), np.float32))
+    with gzip.open(tmp_path / "empty.txt.gz", "rb") as fh:
+        assert fh.read() == b""
+
+
+def test_many_gzip_members(tmp_path):
+    R = 70000                                                    # > 2 members of 32768 rows
+    rng = np.random.default_rng(1)
+    sc = rng.normal(size=(R, 3)).astype(np.float32)
+    loc = _io.Locations.from_object_array([["chr2", 200 * i, 200 * i + 200] for i in range(R)])
+    _io.write_scores(tmp_path / "m.txt.gz", loc, sc, threads=4)
+    with gzip.open(tmp_path / "m.txt.gz", "rt") as fh:
+        lines = fh.read().split("\n")
+    assert len(lines) == R + 1 and lines[-1] == ""
+    assert lines[12345] == "chr2\t%d\t%d\t" % (200 * 12345, 200 * 12345 + 200) + "\t".join("%.5f" % float(v) for v in sc[12345])
+
+
+def test_format_f5_is_pythons_percent_5f():
+    rng = np.random.default_rng(0)
+    bits = rng.integers(0, 2 ** 32, size=400000, dtype=np.uint64).astype(np.uint32)
+    vals = bits.view(np.float32)
+    special = np.array([0.0, -0.0, 1e-7, -1e-7, 5e-6, -5e-6, 4.9999998e-6, 5.0000002e-6, 1.5e-5, 2.5e-5, 0.5, 1.0, -1.0, 11.999996,
+                        2.675, 3.0769148, 123456.789, 1e10, 3.4e38, -3.4e38, 1e-45, np.inf, -np.inf, np.nan, 0.000015, 0.000025,
+                        0.125, 0.3125e-4, 8388608.5, 16777216.0], dtype=np.float32)
+    scores_like = (rng.random(200000) * 12 - 0.5).astype(np.float32)
+    for arr in (special, vals[:200000], scores_like):
+        got = _io.format_f5(arr, sep="\n").decode().split("\n")[:-1]
+        want = ["%.5f" % float(v) for v in arr]
+        bad = [(float(a), g, w) for a, g, w in zip(arr, got, want) if g != w]
+        assert not bad, bad[:5]
