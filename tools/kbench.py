@@ -60,7 +60,11 @@ for rnd in range(a.rounds + 1):
             t = timed(lambda: engine.bin_hist(X, N, S, counts=counts, want_hist=False))
             if rnd:
                 res.setdefault((cfg, "hist_noH"), []).append(t)
-        if "score" in a.what:
+        if "fromhist" in a.what:
+            t = timed(lambda: engine.score_s1_from_binhist(H, N, S, q, out32=out32, ws=ws))
+            if rnd:
+                res.setdefault((cfg, "score_fromH"), []).append(t)
+        if "score" in a.what.split(","):
             t = timed(lambda: engine.score_s1(X, N, S, q, out32=out32, ws=ws))
             if rnd:
                 res.setdefault((cfg, "score_s1"), []).append(t)
