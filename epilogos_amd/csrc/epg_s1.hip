@@ -264,6 +264,7 @@ static void dispatch_bin_hist_ng(const char* X, long R, int N, long ldx, u16* H,
         case 5: launch_bin_hist<S, 5>(X, R, N, ldx, H, counts, st); break;
         case 6: launch_bin_hist<S, 6>(X, R, N, ldx, H, counts, st); break;
         case 7: launch_bin_hist<S, 7>(X, R, N, ldx, H, counts, st); break;
+        case 8: launch_bin_hist<S, 8>(X, R, N, ldx, H, counts, st); break;
         default: launch_bin_hist<S, 0>(X, R, N, ldx, H, counts, st); break;
     }
 }
@@ -288,8 +289,8 @@ int bin_hist_impl(const int8_t* X8, int64_t R, int32_t N, int64_t ldx, int32_t S
     if (Rf > 0) {
         switch (S) {
             case 18: dispatch_bin_hist_ng<18>(X, Rf, N, ldx, H, cnt, st); break;
-            case 15: launch_bin_hist<15, 0>(X, Rf, N, ldx, H, cnt, st); break;
-            case 25: launch_bin_hist<25, 0>(X, Rf, N, ldx, H, cnt, st); break;
+            case 15: dispatch_bin_hist_ng<15>(X, Rf, N, ldx, H, cnt, st); break;   // the reference's other ChromHMM models
+            case 25: dispatch_bin_hist_ng<25>(X, Rf, N, ldx, H, cnt, st); break;
             default: {
                 // generic: count all 31 decodable states into a scratch-free path is not possible with a
                 // different row width, so fall back to the safe kernel for unusual S
@@ -323,6 +324,7 @@ static bool dispatch_score_s1(const char* X, long R, int N, long ldx, int S, con
         case 5: launch_score_s1<18, 5, OT>(X, R, N, ldx, T, out, st); break;
         case 6: launch_score_s1<18, 6, OT>(X, R, N, ldx, T, out, st); break;
         case 7: launch_score_s1<18, 7, OT>(X, R, N, ldx, T, out, st); break;
+        case 8: launch_score_s1<18, 8, OT>(X, R, N, ldx, T, out, st); break;
         default: launch_score_s1<18, 0, OT>(X, R, N, ldx, T, out, st); break;
     }
     return true;

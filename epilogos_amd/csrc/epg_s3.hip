@@ -41,6 +41,9 @@ __global__ __launch_bounds__(S3H_THREADS) void k_s3_hist(const char* __restrict_
     const int b = (int)(tile % n_btiles) * S3_TB + lane;
     const long r0 = (long)blockIdx.y * S3_SLICE;
     const long r1 = r0 + S3_SLICE < R ? r0 + S3_SLICE : R;
+    // symmetry: C[b,a,j,i] == C[a,b,i,j].  Only pairs a < b are counted; the flush writes both entries.  A tile whose
+    // a range lies entirely at or above its b range has no such pair.
+    if (a0 >= (int)(tile % n_btiles) * S3_TB + S3_TB - 1) return;
 
     for (int w = threadIdx.x; w < words; w += S3H_THREADS) hist[w] = 0;
     __syncthreads();
@@ -63,7 +66,7 @@ __global__ __launch_bounds__(S3H_THREADS) void k_s3_hist(const char* __restrict_
 #pragma unroll
             for (int ta = 0; ta < 4; ++ta) {
                 const int a = a0 + ta;
-                if (ta >= TA || a >= N || a == b || xa[u][ta] >= S) continue;
+                if (ta >= TA || a >= b || xa[u][ta] >= S) continue;          // a < b only (b < N is b_ok)
                 const int idx = (ta * S3_TB + lane) * SS + xa[u][ta] * S + xb[u];
                 atomicAdd(&hist[idx >> 1], 1u << (16 * (idx & 1)));
             }
@@ -82,7 +85,9 @@ __global__ __launch_bounds__(S3H_THREADS) void k_s3_hist(const char* __restrict_
             const int rem = idx - ta * S3_TB * SS;
             const int bl = rem / SS, ij = rem - bl * SS;
             const long a = a0 + ta, bb = (long)(tile % n_btiles) * S3_TB + bl;
+            const int i = ij / S, j = ij - i * S;
             atomicAdd(&counts[((a * N + bb) * SS) + ij], (int)c);
+            atomicAdd(&counts[((bb * N + a) * SS) + j * S + i], (int)c);      // the mirrored pair (b, a)
         }
     }
 }

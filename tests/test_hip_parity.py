@@ -72,6 +72,20 @@ def test_bin_hist_other_state_models(eng, S_):
     assert np.array_equal(_np(counts), h_ref.sum(axis=0))
 
 
+@pytest.mark.parametrize("S_,N", [(15, 127), (15, 833), (25, 200), (25, 1000), (18, 1000), (18, 1024), (18, 1025)])
+def test_bin_hist_fast_paths_of_other_models(eng, S_, N):
+    """15- and 25-state ChromHMM models (reference data/state_metadata) and N in (896, 1024] take templated kernels."""
+    x = synth_states(300, N, S=S_, seed=S_ + N, uniform=True)
+    X = eng.states_to_device(x)
+    H, counts = eng.bin_hist(X, N, S_)
+    h_ref = onp.bin_hist(x, S_)
+    assert np.array_equal(eng.hist_to_numpy(H).astype(np.int64), h_ref)
+    assert np.array_equal(_np(counts), h_ref.sum(axis=0))
+    q = onp.normalise(h_ref.sum(axis=0))
+    o32, o64 = eng.score_s1(X, N, S_, torch.from_numpy(q).cuda(), want32=True, want64=True)
+    np.testing.assert_allclose(_np(o64), onp.score_s1(x, q, S_), rtol=RTOL_TIGHT, atol=1e-15)
+
+
 def test_bin_hist_ignores_invalid_states(eng):
     x = synth_states(100, 50, seed=5)
     x[3, 7] = -1      # a 0 in the input file
