@@ -114,21 +114,27 @@ __global__ void k_s3_table(const float* __restrict__ q, int N, int S, float* __r
     T2[e] = v;
 }
 
-constexpr int S3_SCORE_SLICE = 8192;
-
+constexpr int S3_SCORE_SLICE = 4096;
 constexpr int S3S_THREADS = 512;
 
+// One lane = one bin.  For the block's biosample b and every state s present in the slice's column b: stage the
+// tile T2[b][s][:][:] in LDS, compact the bins with x_b == s into a list, and let each lane walk its bin's row
+// (16-byte loads, next chunk prefetched) gathering tile[a][x_a] for all a -- no cross-lane reduction, 64 bins per
+// wave in flight.  Four float partial sums per 16-state chunk are folded into a float64 accumulator (each float sum
+// has 4 terms, so the float64 total carries ~1e-7 relative error, far inside the 2e-6 test bound).
 __global__ __launch_bounds__(S3S_THREADS) void k_s3_score(const char* __restrict__ X, long R, int N, long ldx, int S,
-                                                   const float* __restrict__ T2, double* __restrict__ out64) {
+                                                           const float* __restrict__ T2, double* __restrict__ out64) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* tile = reinterpret_cast<float*>(smem);                                        // [N*S]
-    unsigned char* col = reinterpret_cast<unsigned char*>(smem) + (size_t)N * S * 4;     // [S3_SCORE_SLICE]
+    float* tile = reinterpret_cast<float*>(smem);                                              // [N*S]
+    unsigned short* list = reinterpret_cast<unsigned short*>(smem + (size_t)N * S * 4);         // [S3_SCORE_SLICE]
+    unsigned char* col = reinterpret_cast<unsigned char*>(list + S3_SCORE_SLICE);               // [S3_SCORE_SLICE]
     __shared__ u32 present;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __shared__ u32 nlist;
     const int b = blockIdx.x % N;                 // b fastest: blocks of one slice run together (rows stay in L2)
     const long slice = blockIdx.x / N;
     const long r0 = slice * S3_SCORE_SLICE;
     const int nb = (int)((R - r0) < S3_SCORE_SLICE ? (R - r0) : S3_SCORE_SLICE);
+    const int nchunks = (N + 15) >> 4;
 
     if (threadIdx.x == 0) present = 0;
     __syncthreads();
@@ -144,31 +150,52 @@ __global__ __launch_bounds__(S3S_THREADS) void k_s3_score(const char* __restrict
 
     for (int s = 0; s < S; ++s) {
         if (!((have >> s) & 1u)) continue;       // block-uniform
-        __syncthreads();                           // previous tile fully consumed
+        __syncthreads();                           // previous tile and list fully consumed
+        if (threadIdx.x == 0) nlist = 0;
         const float* src = T2 + ((long)b * S + s) * N * S;
         for (int e = threadIdx.x; e < N * S; e += S3S_THREADS) tile[e] = src[e];
         __syncthreads();
-        // each wave scans its share of the slice, 64 bins at a time
-        constexpr int NW = S3S_THREADS / 64;
-        const int per = (nb + NW - 1) / NW;
-        const int k0 = wave * per, k1 = (k0 + per) < nb ? (k0 + per) : nb;
-        for (int kb = k0; kb < k1; kb += 64) {
-            const int k = kb + lane;
-            const bool hit = k < k1 && col[k] == (unsigned char)s;
-            unsigned long long m = __ballot(hit);
-            while (m) {
-                const int bit = __ffsll((long long)m) - 1;
-                m &= m - 1;
-                const long row = r0 + kb + bit;
-                const char* rp = X + row * ldx;
-                double acc = 0.0;
-                for (int a = lane; a < N; a += 64) {
-                    const int xa = (int)(unsigned char)rp[a];
-                    if (xa < S) acc += (double)tile[a * S + xa];
+        for (int k = threadIdx.x; k < nb; k += S3S_THREADS)
+            if (col[k] == (unsigned char)s) list[atomicAdd(&nlist, 1u)] = (unsigned short)k;
+        __syncthreads();
+        const int n = (int)nlist;
+        for (int t = threadIdx.x; t < n; t += S3S_THREADS) {
+            const long row = r0 + list[t];
+            const char* rp = X + row * ldx;
+            double acc = 0.0;
+            // a 16-byte chunk may run past N: into row padding or the next row (masked by the a < N test below); only
+            // the matrix's very last row of a tightly packed matrix must not be over-read
+            const bool tail_unsafe = row == R - 1 && ldx < 16L * nchunks;
+            auto load_chunk = [&](int c) -> uint4 {
+                if (c == nchunks - 1 && tail_unsafe) {
+                    u32 w4[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+                    for (int a = 16 * c; a < N; ++a) {
+                        const int o = a - 16 * c;
+                        w4[o >> 2] = (w4[o >> 2] & ~(0xffu << (8 * (o & 3)))) | ((u32)(unsigned char)rp[a] << (8 * (o & 3)));
+                    }
+                    return make_uint4(w4[0], w4[1], w4[2], w4[3]);
                 }
-                for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
-                if (lane == 0) atomicAdd(&out64[row * S + s], acc);
+                return ld16(rp + 16 * c);
+            };
+            uint4 cur = load_chunk(0);
+            for (int c = 0; c < nchunks; ++c) {
+                const uint4 nxt = c + 1 < nchunks ? load_chunk(c + 1) : cur;
+                const u32 w[4] = {cur.x, cur.y, cur.z, cur.w};
+                const int abase = 16 * c;
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    float part = 0.f;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int a = abase + 4 * d + k;
+                        const u32 x = (w[d] >> (8 * k)) & 0xffu;
+                        if (a < N && x < (u32)S) part += tile[a * S + (int)x];
+                    }
+                    acc += (double)part;
+                }
+                cur = nxt;
             }
+            atomicAdd(&out64[row * S + s], acc);
         }
     }
 }
@@ -211,7 +238,7 @@ int score_s3_impl(const int8_t* X8, int64_t R, int32_t N, int64_t ldx, int32_t S
     if (S > 31) return fail(EPG_ERR_UNSUPPORTED, "score_s3: S=%d > 31 not supported by this build", S);
     if (R == 0) return EPG_OK;
     if (!X8 || !q || !ws) return fail(EPG_ERR_INVALID_ARG, "score_s3: NULL argument");
-    const size_t shmem = (size_t)N * S * 4 + S3_SCORE_SLICE;
+    const size_t shmem = (size_t)N * S * 4 + (size_t)S3_SCORE_SLICE * 3;
     if (shmem > 160 * 1024 - 64) return fail(EPG_ERR_UNSUPPORTED, "score_s3: N*S = %d exceeds the LDS tile (N*S*4 + 8 KB <= 160 KB)", N * S);
     const int64_t tb = s3_table_bytes(N, S);
     const int64_t need = tb + (out64 ? 0 : align_up(R * S * 8, 256));
