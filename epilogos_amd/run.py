@@ -1,9 +1,10 @@
 """`epilogos` command line for the MI355X engine: the option surface of the reference's epilogos/run.py
 (click options :18-73, checkFlags :328-375, checkArguments :378-451, fileTag/paths :158-165) for STEP 1-3.
 The per-chromosome SLURM submission (run.py:454-585) is replaced by a bin-range partition across the GPUs of the
-node (one process per GPU under torch.distributed.run; a single process when WORLD_SIZE is unset).  STEP 4 (regions
-of interest, p-values, plots) is outside this engine's scope: its inputs (scores_*.txt.gz, temp_scores_*.npz,
-pairwiseDelta_*, temp_nullDistances_*, temp_quiescence_*, exp_freq_*.npy) are written exactly as the reference does."""
+node (one process per GPU under torch.distributed.run; a single process when WORLD_SIZE is unset).  Single mode
+also runs STEP 4 (regionsOfInterest_*.txt, epilogos_amd/roiSingle.py).  The paired STEP 4 (p-values, plots) is outside
+this engine's scope: its inputs (pairwiseDelta_*, temp_nullDistances_*, temp_quiescence_*, exp_freq_*.npy) are written
+exactly as the reference does."""
 import os
 import re
 import sys
@@ -74,7 +75,7 @@ def checkArguments(mode, saliency, inputDirPath, inputDirPath2, outputDirPath, n
 @click.option("-v", "--version", "version", is_flag=True, help="Print the version and exit")
 @click.option("-p", "--partition", "partition", type=str, help="SLURM-only flag; accepted and ignored")
 @click.option("-n", "--null-distribution", "pvalBool", is_flag=True, help="STEP 4 flag; accepted and ignored")
-@click.option("-w", "--roi-width", "roiWidth", type=int, default=0, help="STEP 4 flag; accepted and ignored")
+@click.option("-w", "--roi-width", "roiWidth", type=int, default=0, help="Bins per region of interest [default: 50 in single mode]")
 @click.option("-f", "--file-tag", "fileTag", type=str, default="null",
               help="Tag appended to output filenames [default: input-directory_saliency]")
 @click.option("--exp-freq-mem", "expFreqMem", type=int, default=20000, help="SLURM-only; ignored")
@@ -141,6 +142,10 @@ def main(mode, commandLineBool, inputDirectory, inputDirectory1, inputDirectory2
         from .driver import run_single_group
         say("\nSTEP 1-3: background counts -> all-reduce -> scores (bin-range partition over %d GPU(s))" % world)
         run_single_group(files, numStates, saliency, outputDirPath, fileTag, verbose=False, device=device)
+        if rank == 0:
+            say("\nSTEP 4: Finding regions of interest", flush=True)
+            from .roiSingle import main as roiSingle
+            roiSingle(outputDirPath, stateInfo, fileTag, storedExpPath, roiWidth if roiWidth else 50, False)
     else:
         if world > 1:
             raise click.UsageError("paired mode runs on one GPU in this build")
@@ -162,8 +167,9 @@ def main(mode, commandLineBool, inputDirectory, inputDirectory1, inputDirectory2
         for file, file2 in pairs:
             scores_mod.main(file, file2, numStates, saliency, outputDirPath, storedExpPath, fileTag, numProcesses,
                             quiescentState, groupSize, False)
-    say("\nSTEP 4 (regions of interest / p-values / figures) is not part of the GPU engine; its inputs are in",
-        outputDirPath)
+    if mode == "paired":
+        say("\nSTEP 4 of paired mode (p-values / regions of interest / figures) is not part of this engine; its inputs are in",
+            outputDirPath)
     if world > 1:
         import torch.distributed as dist
         dist.destroy_process_group()

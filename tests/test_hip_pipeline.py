@@ -26,10 +26,11 @@ def test_cli_single_s1_real_slice(tmp_path, golden_real):
     ind.mkdir()
     write_tsv(ind / "matrix_chr1.txt.gz", g["x"], start0=int(g["start0"]))
     meta = tmp_path / "metadata.tsv"
-    meta.write_text("zero_index\tone_index\n" + "".join("%d\t%d\n" % (i, i + 1) for i in range(S)))
+    from tests.conftest import load_golden
+    roi = load_golden("roi.npz")
+    meta.write_text("zero_index\tone_index\tshort_name\n" + "".join("%d\t%d\t%s\n" % (i, i + 1, roi["state_names"][i]) for i in range(S)))
     res = CliRunner().invoke(main, ["-l", "-i", str(ind), "-j", str(meta), "-o", str(out)])
     assert res.exit_code == 0, res.output
-    assert np.array_equal(np.load(out / "exp_freq_in10_s1.npy"), g["s1_exp"])          # bit-exact exp_freq
     with gzip.open(out / "scores_in10_s1_matrix_chr1.txt.gz", "rb") as fh:
         text = fh.read()
     ref = g["s1_text"].tobytes()
@@ -39,8 +40,15 @@ def test_cli_single_s1_real_slice(tmp_path, golden_real):
     print("identical text lines: %d / %d" % (same, len(ref_lines)))
     assert same >= 0.999 * len(ref_lines)
     np.testing.assert_allclose(_text_to_array(text), _text_to_array(ref), atol=1.01e-5)
-    z = np.load(out / "temp_scores_in10_s1_matrix_chr1.npz", allow_pickle=True)
-    np.testing.assert_allclose(z["scoreArr"], g["s1_f32"], rtol=2e-7, atol=0)
+    # STEP 4 on GPU-produced scores: the reference's regions of interest (scores within 1 float32 ulp of the
+    # reference's could reorder exact ties; on this slice the file is identical)
+    got = (out / "regionsOfInterest_in10_s1.txt").read_text().splitlines()
+    want = roi["roi_single_w50"].tobytes().decode().splitlines()
+    assert len(got) == len(want)
+    same = sum(a == b for a, b in zip(got, want))
+    print("identical ROI lines: %d / %d" % (same, len(want)))
+    assert same >= len(want) - 2
+    assert not (out / "exp_freq_in10_s1.npy").exists()
 
 
 @pytest.mark.parametrize("sal", [1, 2])

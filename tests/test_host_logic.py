@@ -36,7 +36,9 @@ def fake_backend():
 @pytest.fixture()
 def state_info(tmp_path):
     p = tmp_path / "metadata.tsv"
-    p.write_text("zero_index\tone_index\tshort_name\n" + "".join("%d\t%d\tS%d\n" % (i, i + 1, i) for i in range(S)))
+    from tests.conftest import load_golden
+    names = load_golden("roi.npz")["state_names"]
+    p.write_text("zero_index\tone_index\tshort_name\n" + "".join("%d\t%d\t%s\n" % (i, i + 1, names[i]) for i in range(S)))
     return p
 
 
@@ -216,7 +218,10 @@ def test_cli_single_mode(tmp_path, golden_real, fake_backend, state_info):
     res = CliRunner().invoke(main, ["-l", "-i", str(ind), "-j", str(state_info), "-o", str(out), "-c", "8"])
     assert res.exit_code == 0, res.output
     assert _decompressed(out / "scores_in10_s1_matrix_chr1.txt.gz") == g["s1_text"].tobytes()   # default tag: {dir}_s{sal}
-    assert np.array_equal(np.load(out / "exp_freq_in10_s1.npy"), g["s1_exp"])
+    # STEP 4 ran: the reference's regions of interest, and its clean-up of exp_freq / temp_scores (quirk Q4)
+    from tests.conftest import load_golden
+    assert (out / "regionsOfInterest_in10_s1.txt").read_bytes() == load_golden("roi.npz")["roi_single_w50"].tobytes()
+    assert not (out / "exp_freq_in10_s1.npy").exists() and not list(out.glob("temp_scores_*"))
     res = CliRunner().invoke(main, ["-i", str(ind), "-j", str(state_info), "-o", str(out), "-s", "3", "-m", "paired",
                                     "-a", str(ind), "-b", str(ind)])
     assert res.exit_code == 0 and "ERROR" in res.output                                     # -i with paired mode
