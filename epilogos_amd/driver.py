@@ -115,3 +115,70 @@ def run_single_group(files, numStates, saliency, outputDir, fileTag, verbose=Fal
                                 scoreArr=np.concatenate(arrs, axis=0), locationArr=loc)
     d.barrier()
     return q
+
+
+def run_paired_groups(files1, files2, numStates, saliency, outputDir, fileTag, quiescentState, groupSize, nullSeed,
+                      verbose=False, backend=None, device=None):
+    """STEP 1-3 of paired mode (reference run.py:205-221,258-279 + scores.py:172-256) over the bin-range partition.
+    Background counts are taken over the column concatenation [A|B] (helpers.py:173), all-reduced once; each rank then
+    scores A, B and the two shuffled null groups of its bins.  The null shuffle is keyed by (seed, global bin index), so
+    the outputs do not depend on the number of GPUs."""
+    be = backend if backend is not None else _backend.get()
+    d = _Dist()
+    files1, files2 = [Path(f) for f in files1], [Path(f) for f in files2]
+    outputDir = Path(outputDir)
+    rows = [countRows(f) for f in files1]
+    my_parts = plan_partition(rows, d.world)[d.rank]
+    file_start = np.concatenate([[0], np.cumsum(rows)]).astype(np.int64)
+
+    counts, chunks = None, []
+    for (fi, lo, hi) in my_parts:
+        xa, loc = readTable(files1[fi], (lo, hi))
+        xb, _ = readTable(files2[fi], (lo, hi))
+        if xb.shape[0] != xa.shape[0]:
+            raise ValueError("paired inputs differ in length: {} vs {}".format(files1[fi], files2[fi]))
+        chunks.append((xa, xb, loc))
+        c = be.expected_counts(np.concatenate((xa, xb), axis=1), numStates, saliency)
+        counts = c if counts is None else counts + c
+    if counts is None:
+        counts = np.zeros((numStates,) if saliency == 1 else (numStates, numStates), dtype=np.int64)
+    counts = d.all_reduce_counts(counts, device=device)
+    q = be.normalise(counts)
+    if d.rank == 0:
+        np.save(outputDir / "exp_freq_{}.npy".format(fileTag), q, allow_pickle=False)
+
+    for (fi, lo, hi), (xa, xb, loc) in zip(my_parts, chunks):
+        n1, n2 = xa.shape[1], xb.shape[1]
+        s1 = be.scores(xa, numStates, saliency, q, perms=n1 * (n1 - 1))
+        s2 = be.scores(xb, numStates, saliency, q, perms=n2 * (n2 - 1))
+        na, nb = be.null_scores(xa, xb, numStates, saliency, q, groupSize, nullSeed, row0=int(file_start[fi] + lo))
+        delta, _ = be.pair_finish(s1, s2)
+        _, dist = be.pair_finish(na, nb)
+        quies = be.quiescent(xa, xb, quiescentState)
+        stem = fileStem(files1[fi])
+        writeScores(delta, outputDir / ".part_pairwiseDelta_{}_{}_{:012d}.gz".format(fileTag, stem, lo), loc)
+        np.save(outputDir / ".part_null_{}_{}_{:012d}.npy".format(fileTag, stem, lo), dist, allow_pickle=False)
+        np.save(outputDir / ".part_quies_{}_{}_{:012d}.npy".format(fileTag, stem, lo), quies, allow_pickle=False)
+    d.barrier()
+    if d.rank == 0:
+        for f in files1:
+            stem = fileStem(f)
+            with open(outputDir / "pairwiseDelta_{}_{}.txt.gz".format(fileTag, stem), "wb") as out:
+                for p in sorted(outputDir.glob(".part_pairwiseDelta_{}_{}_*.gz".format(fileTag, stem))):
+                    with open(p, "rb") as src:
+                        shutil.copyfileobj(src, out)
+                    os.remove(p)
+            parts = {}
+            for kind in ("null", "quies"):
+                arrs = []
+                for p in sorted(outputDir.glob(".part_{}_{}_{}_*.npy".format(kind, fileTag, stem))):
+                    arrs.append(np.load(p))
+                    os.remove(p)
+                parts[kind] = np.concatenate(arrs) if arrs else np.zeros(0)
+            chrName = readLocations(f, (0, 1))[0, 0]
+            np.savez_compressed(outputDir / "temp_nullDistances_{}_{}.npz".format(fileTag, stem), chrName=np.array([chrName]),
+                                nullDistances=parts["null"])
+            np.savez_compressed(outputDir / "temp_quiescence_{}_{}.npz".format(fileTag, stem), chrName=np.array([chrName]),
+                                quiescenceArr=parts["quies"].astype(bool))
+    d.barrier()
+    return q

@@ -147,26 +147,27 @@ def main(mode, commandLineBool, inputDirectory, inputDirectory1, inputDirectory2
             from .roiSingle import main as roiSingle
             roiSingle(outputDirPath, stateInfo, fileTag, storedExpPath, roiWidth if roiWidth else 50, False)
     else:
-        if world > 1:
-            raise click.UsageError("paired mode runs on one GPU in this build")
-        from . import scores as scores_mod
-        from .expected import main as expected
-        from .expectedCombination import main as expectedCombination
-        scores_mod.NULL_SEED = nullSeed
-        say("\nSTEP 1: Per data file background frequency calculation")
-        pairs = []
+        from .driver import run_paired_groups
+        files2 = []
         for file in files:
             if not list(inputDirPath2.glob(file.name)):
-                raise FileNotFoundError("File not found: {}".format(str(inputDirPath2 / file.name)))
-            pairs.append((file, next(inputDirPath2.glob(file.name))))
-        for file, file2 in pairs:
-            expected(file, file2, numStates, saliency, outputDirPath, fileTag, numProcesses, False)
-        say("\nSTEP 2: Background frequency combination")
-        expectedCombination(outputDirPath, storedExpPath, fileTag, False)
-        say("\nSTEP 3: Score calculation")
-        for file, file2 in pairs:
-            scores_mod.main(file, file2, numStates, saliency, outputDirPath, storedExpPath, fileTag, numProcesses,
-                            quiescentState, groupSize, False)
+                raise FileNotFoundError("File not found: {}".format(str(inputDirPath2 / file.name))
+                                        + " Please ensure corresponding files within input directories 1 and 2 have the same name")
+            files2.append(next(inputDirPath2.glob(file.name)))
+        if nullSeed is None:
+            import numpy as np
+            seed = np.array([int(np.random.SeedSequence().generate_state(1)[0])], dtype=np.int64)
+            if world > 1:                                        # every rank must shuffle with the same seed
+                import torch
+                import torch.distributed as dist
+                t = torch.from_numpy(seed)
+                t = t.to(device) if device is not None else t
+                dist.broadcast(t, src=0)
+                seed = t.cpu().numpy()
+            nullSeed = int(seed[0])
+        say("\nSTEP 1-3: background counts over [A|B] -> all-reduce -> scores, null groups, deltas (%d GPU(s))" % world)
+        run_paired_groups(files, files2, numStates, saliency, outputDirPath, fileTag, quiescentState, groupSize, nullSeed,
+                          verbose=False, device=device)
     if mode == "paired":
         say("\nSTEP 4 of paired mode (p-values / regions of interest / figures) is not part of this engine; its inputs are in",
             outputDirPath)

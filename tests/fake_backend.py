@@ -34,7 +34,10 @@ class OracleBackend:
 
     def null_scores(self, xa, xb, S, saliency, q, groupSize, seed, row0=0):
         comb = np.concatenate([xa, xb], axis=1)
-        sh = onp.shuffle_rows(comb, np.random.default_rng(seed).random(comb.shape))
+        # keyed by (seed, global row) like the engine's Philox shuffle: independent of how bins are split over ranks
+        rand = np.stack([np.random.default_rng([seed, row0 + r]).random(comb.shape[1]) for r in range(comb.shape[0])]) \
+            if comb.shape[0] else np.zeros(comb.shape)
+        sh = onp.shuffle_rows(comb, rand)
         ga, gb = (xa.shape[1], xb.shape[1]) if groupSize == -1 else (groupSize, groupSize)
         na, nb = sh[:, :ga], sh[:, ga:ga + gb]
         if saliency == 1:

@@ -14,7 +14,11 @@ ind, out = Path(sys.argv[1]), Path(sys.argv[2])
 world = int(os.environ.get("WORLD_SIZE", "1"))
 if world > 1:
     dist.init_process_group(backend="gloo")
-files = sorted(ind.glob("*"))
-driver.run_single_group(files, 18, 1, out, "t_s1", backend=OracleBackend())
+if (ind / "A").is_dir():                                     # paired layout: in/A/*.txt and in/B/*.txt
+    fa, fb = sorted((ind / "A").glob("*")), sorted((ind / "B").glob("*"))
+    driver.run_paired_groups(fa, fb, 18, 1, out, "t_s1", 17, -1, 4242, backend=OracleBackend())
+else:
+    files = sorted(ind.glob("*"))
+    driver.run_single_group(files, 18, 1, out, "t_s1", backend=OracleBackend())
 if world > 1:
     dist.destroy_process_group()

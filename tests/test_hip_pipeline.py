@@ -68,3 +68,34 @@ def test_stage_drivers_hip(tmp_path, golden_real, sal):
     scores.main(f, "null", S, sal, out, out / ("exp_freq_%s.npy" % tag), tag, 1, S - 1, -1, False)
     z = np.load(out / ("temp_scores_%s_matrix_chr1.npz" % tag), allow_pickle=True)
     np.testing.assert_allclose(z["scoreArr"], g["s%d_f32" % sal], rtol=3e-7, atol=1e-12)
+
+
+def test_cli_paired_s1(tmp_path, golden_pair):
+    """`epilogos -m paired` through the partitioned driver with the HIP backend (one rank)."""
+    from click.testing import CliRunner
+    from epilogos_amd.run import main
+    from tests.conftest import load_golden
+    g = golden_pair
+    a, b, out = tmp_path / "male", tmp_path / "female", tmp_path / "out"
+    a.mkdir(); b.mkdir()
+    write_tsv(a / "matrix_chr1.txt.gz", g["xa"]); write_tsv(b / "matrix_chr1.txt.gz", g["xb"])
+    meta = tmp_path / "metadata.tsv"
+    names = load_golden("roi.npz")["state_names"]
+    meta.write_text("zero_index\tone_index\tshort_name\n" + "".join("%d\t%d\t%s\n" % (i, i + 1, names[i]) for i in range(S)))
+    args = ["-l", "-m", "paired", "-a", str(a), "-b", str(b), "-j", str(meta), "-o", str(out), "--null-seed", "5"]
+    res = CliRunner().invoke(main, args)
+    assert res.exit_code == 0, res.output
+    tag = "male_female_s1"                                           # reference run.py:161-162
+    assert np.array_equal(np.load(out / ("exp_freq_%s.npy" % tag)), g["s1_exp"])
+    with gzip.open(out / ("pairwiseDelta_%s_matrix_chr1.txt.gz" % tag), "rb") as fh:
+        delta = _text_to_array(fh.read())
+    np.testing.assert_allclose(delta, g["s1_delta"], atol=1.01e-5)
+    assert np.array_equal(np.load(out / ("temp_quiescence_%s_matrix_chr1.npz" % tag))["quiescenceArr"], g["s1_quiescent"])
+    nd1 = np.load(out / ("temp_nullDistances_%s_matrix_chr1.npz" % tag))["nullDistances"]
+    # same seed -> same null draws; -q 0 switches the quiescence filter off (run.py:113)
+    out2 = tmp_path / "out2"
+    res = CliRunner().invoke(main, args[:-4] + ["-o", str(out2), "--null-seed", "5", "-q", "0"])
+    assert res.exit_code == 0, res.output
+    nd2 = np.load(out2 / ("temp_nullDistances_%s_matrix_chr1.npz" % tag))["nullDistances"]
+    assert np.array_equal(nd1, nd2)
+    assert not np.load(out2 / ("temp_quiescence_%s_matrix_chr1.npz" % tag))["quiescenceArr"].any()

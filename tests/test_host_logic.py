@@ -208,6 +208,35 @@ def test_two_rank_gloo_matches_single_process(tmp_path, golden_real):
     assert _decompressed(outs[2] / "scores_t_s1_matrix_chr1.txt.gz") == b"\n".join(ref_lines[:1500]) + b"\n"
 
 
+def test_two_rank_gloo_paired_matches_single_process(tmp_path, golden_pair):
+    g = golden_pair
+    ind = tmp_path / "in"
+    (ind / "A").mkdir(parents=True); (ind / "B").mkdir()
+    for name, lo, hi in (("matrix_chr1.txt", 0, 1100), ("matrix_chr2.txt", 1100, 2048)):
+        write_tsv(ind / "A" / name, g["xa"][lo:hi], chrom=name[7:-4])
+        write_tsv(ind / "B" / name, g["xb"][lo:hi], chrom=name[7:-4])
+    outs = {}
+    for world in (1, 2):
+        out = tmp_path / ("out%d" % world)
+        out.mkdir()
+        port = str(29600 + os.getpid() % 300 + world)
+        env = dict(os.environ, PYTHONPATH=str(ROOT), MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+               "--master-addr", "127.0.0.1", "--master-port", port, str(ROOT / "tests" / "gloo_worker.py"), str(ind), str(out)]
+        res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+        assert res.returncode == 0, res.stdout + res.stderr
+        outs[world] = out
+    for stem in ("matrix_chr1", "matrix_chr2"):
+        assert _decompressed(outs[1] / ("pairwiseDelta_t_s1_%s.txt.gz" % stem)) == _decompressed(outs[2] / ("pairwiseDelta_t_s1_%s.txt.gz" % stem))
+        for kind, key in (("temp_nullDistances", "nullDistances"), ("temp_quiescence", "quiescenceArr")):
+            a = np.load(outs[1] / ("%s_t_s1_%s.npz" % (kind, stem)))
+            b = np.load(outs[2] / ("%s_t_s1_%s.npz" % (kind, stem)))
+            assert np.array_equal(a[key], b[key]) and a["chrName"][0] == b["chrName"][0] == stem[7:]
+    assert np.array_equal(np.load(outs[2] / "exp_freq_t_s1.npy"), g["s1_exp"])
+    q = np.concatenate([np.load(outs[2] / ("temp_quiescence_t_s1_%s.npz" % s))["quiescenceArr"] for s in ("matrix_chr1", "matrix_chr2")])
+    assert np.array_equal(q, g["s1_quiescent"])
+
+
 def test_cli_single_mode(tmp_path, golden_real, fake_backend, state_info):
     from click.testing import CliRunner
     from epilogos_amd.run import main
