@@ -116,6 +116,7 @@ __global__ void k_s3_table(const float* __restrict__ q, int N, int S, float* __r
 
 constexpr int S3_SCORE_SLICE = 4096;
 constexpr int S3S_THREADS = 512;
+constexpr int S3S_MAX_LANES_PER_BIN = 64;
 
 // One lane = one bin.  For the block's biosample b and every state s present in the slice's column b: stage the
 // tile T2[b][s][:][:] in LDS, compact the bins with x_b == s into a list, and let each lane walk its bin's row
@@ -153,14 +154,51 @@ __global__ __launch_bounds__(S3S_THREADS) void k_s3_score(const char* __restrict
         __syncthreads();                           // previous tile and list fully consumed
         if (threadIdx.x == 0) nlist = 0;
         const float* src = T2 + ((long)b * S + s) * N * S;
-        for (int e = threadIdx.x; e < N * S; e += S3S_THREADS) tile[e] = src[e];
+        // tile: 16-byte loads, all of a thread's loads in flight at once (a scalar-load loop costs one L2 round trip
+        // per 512 floats and dominated the pass); T2 tiles are 16-byte aligned when N*S is a multiple of 4
+        const int n4 = ((N * S) & 3) == 0 ? (N * S) >> 2 : 0;
+        {
+            const float4* src4 = reinterpret_cast<const float4*>(src);
+            float4* tile4 = reinterpret_cast<float4*>(tile);
+            constexpr int U = 8;
+            for (int e0 = threadIdx.x; e0 < n4; e0 += S3S_THREADS * U) {
+                float4 v[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+                    if (e0 + u * S3S_THREADS < n4) v[u] = src4[e0 + u * S3S_THREADS];
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+                    if (e0 + u * S3S_THREADS < n4) tile4[e0 + u * S3S_THREADS] = v[u];
+            }
+            for (int e = 4 * n4 + threadIdx.x; e < N * S; e += S3S_THREADS) tile[e] = src[e];
+        }
         __syncthreads();
-        for (int k = threadIdx.x; k < nb; k += S3S_THREADS)
-            if (col[k] == (unsigned char)s) list[atomicAdd(&nlist, 1u)] = (unsigned short)k;
+        // compact the bins with x_b == s: one LDS atomic per wave (ballot + lane prefix), not one per bin
+        for (int k0 = 0; k0 < nb; k0 += S3S_THREADS) {
+            const int k = k0 + threadIdx.x;
+            const bool hit = k < nb && col[k] == (unsigned char)s;
+            const unsigned long long m = __ballot(hit);
+            const int lane = threadIdx.x & 63;
+            u32 base = 0;
+            if (lane == 0 && m) base = atomicAdd(&nlist, (u32)__popcll(m));
+            base = __shfl(base, 0);
+            if (hit) list[base + __popcll(m & ((1ull << lane) - 1))] = (unsigned short)k;
+        }
         __syncthreads();
         const int n = (int)nlist;
-        for (int t = threadIdx.x; t < n; t += S3S_THREADS) {
-            const long row = r0 + list[t];
+        // a quad per bin: quad lane j walks chunks j, j+4, ... of the bin's row, four chunks in flight; the walk is a
+        // chain of dependent L2 round trips, so four lanes per bin cut its length four-fold and keep the rare states'
+        // passes (a handful of bins) from idling the block
+        // lanes per bin: as many as keep the block full in ONE round (a rare state's handful of bins gets 16-64 lanes
+        // each and one short dependent-load chain; the dominant state gets 1-4 lanes per bin and several rounds)
+        int G = 1;
+        while (G < S3S_MAX_LANES_PER_BIN && 2 * G * n <= S3S_THREADS) G <<= 1;
+        if (G < 4 && n > 0) G = 4;
+        const int BPR = S3S_THREADS / G;                               // bins per round
+        const int j = threadIdx.x & (G - 1);
+        for (int t = threadIdx.x / G; t < ((n + BPR - 1) / BPR) * BPR; t += BPR) {
+            const bool live = t < n;
+            const long row = r0 + (live ? list[t] : list[0]);
             const char* rp = X + row * ldx;
             double acc = 0.0;
             // a 16-byte chunk may run past N: into row padding or the next row (masked by the a < N test below); only
@@ -177,25 +215,34 @@ __global__ __launch_bounds__(S3S_THREADS) void k_s3_score(const char* __restrict
                 }
                 return ld16(rp + 16 * c);
             };
-            uint4 cur = load_chunk(0);
-            for (int c = 0; c < nchunks; ++c) {
-                const uint4 nxt = c + 1 < nchunks ? load_chunk(c + 1) : cur;
-                const u32 w[4] = {cur.x, cur.y, cur.z, cur.w};
-                const int abase = 16 * c;
+            constexpr int PF = 4;
+            uint4 ring[PF];
 #pragma unroll
-                for (int d = 0; d < 4; ++d) {
-                    float part = 0.f;
+            for (int p = 0; p < PF; ++p) ring[p] = (live && j + G * p < nchunks) ? load_chunk(j + G * p) : make_uint4(~0u, ~0u, ~0u, ~0u);
+            for (int c0 = j; c0 < nchunks && live; c0 += G * PF) {
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const int a = abase + 4 * d + k;
-                        const u32 x = (w[d] >> (8 * k)) & 0xffu;
-                        if (a < N && x < (u32)S) part += tile[a * S + (int)x];
+                for (int p = 0; p < PF; ++p) {
+                    const int c = c0 + G * p;
+                    if (c >= nchunks) break;
+                    const uint4 cur = ring[p];
+                    if (c + G * PF < nchunks) ring[p] = load_chunk(c + G * PF);
+                    const u32 w[4] = {cur.x, cur.y, cur.z, cur.w};
+                    const int abase = 16 * c;
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) {
+                        float part = 0.f;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const int a = abase + 4 * d + k;
+                            const u32 x = (w[d] >> (8 * k)) & 0xffu;
+                            if (a < N && x < (u32)S) part += tile[a * S + (int)x];
+                        }
+                        acc += (double)part;
                     }
-                    acc += (double)part;
                 }
-                cur = nxt;
             }
-            atomicAdd(&out64[row * S + s], acc);
+            for (int off = 1; off < G; off <<= 1) acc += __shfl_xor(acc, off);
+            if (live && j == 0) atomicAdd(&out64[row * S + s], acc);
         }
     }
 }
