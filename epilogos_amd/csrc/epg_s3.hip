@@ -18,6 +18,8 @@
 //   the float64 score.  The diagonal a == b contributes 0 because q[a,a,:,:] == 0 (kl masks q == 0).
 #include "epg_common.h"
 
+#include <stdlib.h>
+
 namespace epg {
 
 constexpr int S3_TB = 64;             // b biosamples per block (= lanes of a wave)
@@ -268,14 +270,27 @@ static int s3_ta(int S) {
     return ta;
 }
 
-int64_t s3_table_bytes(int N, int S) { return align_up((int64_t)N * N * S * S * 4, 256); }
-int64_t s3_ws_bytes(int64_t R, int N, int S) { return s3_table_bytes(N, S) + align_up(R * S * 8, 256); }
+int64_t s3_mfma_ws_bytes(int64_t R, int N);
+int hist_s3_mfma(const char* X, int64_t R, int32_t N, int64_t ldx, int32_t S, int32_t* counts, void* ws, hipStream_t st);
 
-int hist_s3_impl(const int8_t* X8, int64_t R, int32_t N, int64_t ldx, int32_t S, int32_t* counts, void*, int64_t, hipStream_t st) {
+int64_t s3_table_bytes(int N, int S) { return align_up((int64_t)N * N * S * S * 4, 256); }
+int64_t s3_ws_bytes(int64_t R, int N, int S) {
+    const int64_t score = s3_table_bytes(N, S) + align_up(R * S * 8, 256);     // table + float64 accumulator
+    const int64_t hist = s3_mfma_ws_bytes(R, N);                               // transposed state matrix
+    return score > hist ? score : hist;
+}
+
+int hist_s3_impl(const int8_t* X8, int64_t R, int32_t N, int64_t ldx, int32_t S, int32_t* counts, void* ws, int64_t ws_bytes,
+                 hipStream_t st) {
     if (R < 0 || N < 2 || ldx < N || S < 1) return fail(EPG_ERR_INVALID_ARG, "hist_s3: bad shape R=%lld N=%d ldx=%lld S=%d", (long long)R, N, (long long)ldx, S);
     if (S > 31) return fail(EPG_ERR_UNSUPPORTED, "hist_s3: S=%d > 31 not supported by this build", S);
     if (R == 0) return EPG_OK;
     if (!X8 || !counts) return fail(EPG_ERR_INVALID_ARG, "hist_s3: NULL argument");
+    // matrix-core path when the caller gave room for the transposed matrix (S <= 30: padding rows use pattern 30);
+    // EPG_S3_HIST=lds forces the LDS-atomic kernel (A/B measurements, and the fallback for S = 31 / no workspace)
+    static const bool force_lds = [] { const char* e = getenv("EPG_S3_HIST"); return e && e[0] == 'l'; }();
+    if (!force_lds && S <= 30 && ws && ws_bytes >= s3_mfma_ws_bytes(R, N))
+        return hist_s3_mfma(reinterpret_cast<const char*>(X8), R, N, ldx, S, counts, ws, st);
     const int TA = s3_ta(S);
     if (TA < 1) return fail(EPG_ERR_UNSUPPORTED, "hist_s3: S=%d needs more LDS than a CU has", S);
     const int n_atiles = (N + TA - 1) / TA, n_btiles = (N + S3_TB - 1) / S3_TB;

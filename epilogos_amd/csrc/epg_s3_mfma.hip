@@ -1,0 +1,189 @@
+// S3 expected pass as an int8 matrix-core contraction (gfx950 v_mfma_i32_32x32x32_i8).
+//
+// C[a,b,i,j] = #{bins : x[a] == i and x[b] == j} is G = E^T E for the one-hot expansion E[bin, (sample, state)]
+// (reference expected.py:183-200 increments exactly these cells, one bin at a time).  This is a genuine dense
+// contraction -- K = all bins, M = N = biosamples*states = 14 994 at N = 833 -- and the one place on this path where
+// the matrix cores are the right tool (SURVEY 7 "S3"); everything else is histogram/elementwise work.
+//
+//  * k_transpose_states writes XT[sample][bin] (bins padded to a multiple of 32 with 0xFF, states outside [0,S) turned
+//    into 0xFF) so that a lane's MFMA operand -- 16 consecutive bins of ONE (sample, state) row -- is one 16-byte load.
+//  * k_s3_hist_mfma: one wave per pair of 96-row blocks (3x3 tiles of 32x32, 144 accumulator registers).  The one-hot
+//    operand is never materialised in memory: lane l of tile t owns row m = 32t + (l & 31) = (sample, state) and
+//    turns its 16 state bytes into 0/1 bytes with a SWAR equality test against its own state (6 VALU per dword).
+//    A and B operands come from the same routine, so both see bins in the same byte order and the K sum pairs them.
+//  * symmetry: only block pairs bm <= bn are computed; off-diagonal blocks also write the mirrored cells
+//    C[b,a,j,i].  The diagonal a == b is skipped (it stays 0 like the reference's).  int32 accumulation: exact.
+#include "epg_common.h"
+
+namespace epg {
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+
+constexpr int MF_T = 3;               // tiles per block side
+constexpr int MF_ROWS = 32 * MF_T;    // (sample, state) rows per block
+
+__global__ __launch_bounds__(256) void k_transpose_states(const char* __restrict__ X, long R, int N, long ldx, int S,
+                                                           char* __restrict__ XT, long Rp) {
+    __shared__ unsigned char tile[64][65];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const long b0 = (long)blockIdx.x * 64;
+    const int s0 = blockIdx.y * 64;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const long bin = b0 + ty + 4 * i;
+        const int smp = s0 + tx;
+        unsigned char v = 0xff;
+        if (bin < R && smp < N) {
+            v = (unsigned char)X[bin * ldx + smp];
+            if (v >= S) v = 0xff;
+        }
+        tile[ty + 4 * i][tx] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int smp = s0 + ty + 4 * i;
+        const long bin = b0 + tx;
+        if (smp < N && bin < Rp) XT[(long)smp * Rp + bin] = (char)tile[tx][ty + 4 * i];
+    }
+}
+
+__device__ __forceinline__ u32 eq_bytes(u32 w, u32 pat) {
+    const u32 t = (w & 0x1f1f1f1fu) ^ pat;                        // 0xFF (not a state) -> 31, never a pattern
+    const u32 nz = (t + 0x7f7f7f7fu) & 0x80808080u;               // bit 7 of a byte set <=> byte != pattern
+    return (nz >> 7) ^ 0x01010101u;                               // 1 where equal
+}
+
+__device__ __forceinline__ v4i onehot16(const uint4 raw, u32 pat) {
+    v4i r;
+    r.x = (int)eq_bytes(raw.x, pat);
+    r.y = (int)eq_bytes(raw.y, pat);
+    r.z = (int)eq_bytes(raw.z, pat);
+    r.w = (int)eq_bytes(raw.w, pat);
+    return r;
+}
+
+__global__ __launch_bounds__(64, 2) void k_s3_hist_mfma(const char* __restrict__ XT, long Rp, long ksplit_len, int N, int S,
+                                                      int nblk, int* __restrict__ counts) {
+    const int lane = threadIdx.x;
+    const int NS = N * S;
+    // block pair (bm <= bn) from the linear index over the upper triangle
+    int p = blockIdx.x, bm = 0;
+    while (p >= nblk - bm) { p -= nblk - bm; ++bm; }
+    const int bn = bm + p;
+    const long kbeg = (long)blockIdx.y * ksplit_len;
+    const long kend = kbeg + ksplit_len < Rp ? kbeg + ksplit_len : Rp;
+
+    long offA[MF_T], offB[MF_T];
+    u32 patA[MF_T], patB[MF_T];
+#pragma unroll
+    for (int t = 0; t < MF_T; ++t) {
+        const int m = (bm * MF_T + t) * 32 + (lane & 31);
+        const int n = (bn * MF_T + t) * 32 + (lane & 31);
+        const int am = m < NS ? m / S : 0, im = m < NS ? m % S : 30;      // rows past N*S match nothing (S <= 30)
+        const int an = n < NS ? n / S : 0, in_ = n < NS ? n % S : 30;
+        offA[t] = (long)am * Rp + 16 * (lane >> 5);
+        offB[t] = (long)an * Rp + 16 * (lane >> 5);
+        patA[t] = (u32)im * 0x01010101u;
+        patB[t] = (u32)in_ * 0x01010101u;
+    }
+    v16i acc[MF_T][MF_T];
+#pragma unroll
+    for (int a = 0; a < MF_T; ++a)
+#pragma unroll
+        for (int b = 0; b < MF_T; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0;
+
+    // software pipeline: while the nine MFMAs of step k run on the matrix pipe, the VALU builds the one-hot operands
+    // of step k+1 and the loads of step k+2 are in flight.  sched_group_barrier interleaves one MFMA with 16 VALU so
+    // that both pipes stay busy; two waves per SIMD (226 registers) cover most of the remaining load latency.
+    // (Measured alternatives: a 6-deep register ring at one wave per SIMD, 182 ms per 1 M bins against 145 ms; a 2-deep
+    // ring at two waves spills to scratch.)
+    uint4 ra[MF_T], rb[MF_T];
+    v4i fa[MF_T], fb[MF_T];
+#pragma unroll
+    for (int t = 0; t < MF_T; ++t) {
+        fa[t] = onehot16(*reinterpret_cast<const uint4*>(XT + offA[t] + kbeg), patA[t]);
+        fb[t] = onehot16(*reinterpret_cast<const uint4*>(XT + offB[t] + kbeg), patB[t]);
+    }
+    {
+        const long k1 = kbeg + 32 < kend ? kbeg + 32 : kbeg;
+#pragma unroll
+        for (int t = 0; t < MF_T; ++t) {
+            ra[t] = *reinterpret_cast<const uint4*>(XT + offA[t] + k1);
+            rb[t] = *reinterpret_cast<const uint4*>(XT + offB[t] + k1);
+        }
+    }
+    for (long k0 = kbeg; k0 < kend; k0 += 32) {
+        v4i na[MF_T], nb[MF_T];
+#pragma unroll
+        for (int t = 0; t < MF_T; ++t) {
+            na[t] = onehot16(ra[t], patA[t]);
+            nb[t] = onehot16(rb[t], patB[t]);
+        }
+        const long k2 = k0 + 64 < kend ? k0 + 64 : k0;
+#pragma unroll
+        for (int t = 0; t < MF_T; ++t) {
+            ra[t] = *reinterpret_cast<const uint4*>(XT + offA[t] + k2);
+            rb[t] = *reinterpret_cast<const uint4*>(XT + offB[t] + k2);
+        }
+#pragma unroll
+        for (int a = 0; a < MF_T; ++a)
+#pragma unroll
+            for (int b = 0; b < MF_T; ++b) acc[a][b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[a], fb[b], acc[a][b], 0, 0, 0);
+#pragma unroll
+        for (int g = 0; g < MF_T * MF_T; ++g) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);    // one MFMA
+            __builtin_amdgcn_sched_group_barrier(0x002, 16, 0);   // sixteen VALU
+        }
+#pragma unroll
+        for (int t = 0; t < MF_T; ++t) { fa[t] = na[t]; fb[t] = nb[t]; }
+    }
+
+    // C/D layout of a 32x32 MFMA: column = lane & 31, row = (r & 3) + 8*(r >> 2) + 4*(lane >> 5)
+    const long SS = (long)S * S;
+#pragma unroll
+    for (int ta = 0; ta < MF_T; ++ta)
+#pragma unroll
+        for (int tb = 0; tb < MF_T; ++tb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int v = acc[ta][tb][r];
+                if (!v) continue;
+                const int m = (bm * MF_T + ta) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const int n = (bn * MF_T + tb) * 32 + (lane & 31);
+                if (m >= NS || n >= NS) continue;
+                const int a = m / S, i = m - a * S, b = n / S, j = n - b * S;
+                if (a == b) continue;
+                atomicAdd(&counts[((long)a * N + b) * SS + i * S + j], v);
+                if (bm != bn) atomicAdd(&counts[((long)b * N + a) * SS + j * S + i], v);
+            }
+}
+
+int64_t s3_mfma_ws_bytes(int64_t R, int N) { return align_up((int64_t)N * align_up(R, 32) + 64, 256); }
+
+int hist_s3_mfma(const char* X, int64_t R, int32_t N, int64_t ldx, int32_t S, int32_t* counts, void* ws, hipStream_t st) {
+    const long Rp = align_up(R, 32);
+    char* XT = reinterpret_cast<char*>(ws);
+    hipLaunchKernelGGL(k_transpose_states, dim3((unsigned)((Rp + 63) / 64), (unsigned)((N + 63) / 64)), dim3(256), 0, st, X, (long)R, N,
+                       (long)ldx, S, XT, Rp);
+    EPG_LAUNCH_CHECK("k_transpose_states");
+    const int nblk = (N * S + MF_ROWS - 1) / MF_ROWS;
+    const long npairs = (long)nblk * (nblk + 1) / 2;
+    // split K so that there are a few tasks per wave slot (2 waves per SIMD); int32 atomics combine the splits
+    const long slots = (long)num_cus() * 8;
+    long splits = (4 * slots + npairs - 1) / npairs;
+    const long ksteps = Rp / 32;
+    if (splits > ksteps) splits = ksteps;
+    if (splits < 1) splits = 1;
+    if (splits > 65535) splits = 65535;
+    const long ksplit_len = ((ksteps + splits - 1) / splits) * 32;
+    const long nsplit = (Rp + ksplit_len - 1) / ksplit_len;
+    hipLaunchKernelGGL(k_s3_hist_mfma, dim3((unsigned)npairs, (unsigned)nsplit), dim3(64), 0, st, XT, Rp, ksplit_len, N, S, nblk, counts);
+    EPG_LAUNCH_CHECK("k_s3_hist_mfma");
+    return EPG_OK;
+}
+
+}  // namespace epg
