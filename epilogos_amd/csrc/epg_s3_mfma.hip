@@ -5,8 +5,8 @@
 // contraction -- K = all bins, M = N = biosamples*states = 14 994 at N = 833 -- and the one place on this path where
 // the matrix cores are the right tool (SURVEY 7 "S3"); everything else is histogram/elementwise work.
 //
-//  * k_transpose_states writes XT[sample][bin] (bins padded to a multiple of 32 with 0xFF, states outside [0,S) turned
-//    into 0xFF) so that a lane's MFMA operand -- 16 consecutive bins of ONE (sample, state) row -- is one 16-byte load.
+//  * k_transpose_states writes XT[sample][bin] (bins padded to a multiple of 32 with 31, states outside [0,S) turned
+//    into 31) so that a lane's MFMA operand -- 16 consecutive bins of ONE (sample, state) row -- is one 16-byte load.
 //  * k_s3_hist_mfma: one wave per pair of 96-row blocks (3x3 tiles of 32x32, 144 accumulator registers).  The one-hot
 //    operand is never materialised in memory: lane l of tile t owns row m = 32t + (l & 31) = (sample, state) and
 //    turns its 16 state bytes into 0/1 bytes with a SWAR equality test against its own state (6 VALU per dword).
@@ -33,10 +33,10 @@ __global__ __launch_bounds__(256) void k_transpose_states(const char* __restrict
     for (int i = 0; i < 16; ++i) {
         const long bin = b0 + ty + 4 * i;
         const int smp = s0 + tx;
-        unsigned char v = 0xff;
+        unsigned char v = 31;                         // "not a state": bins past R, states outside [0, S)
         if (bin < R && smp < N) {
             v = (unsigned char)X[bin * ldx + smp];
-            if (v >= S) v = 0xff;
+            if (v >= S) v = 31;
         }
         tile[ty + 4 * i][tx] = v;
     }
@@ -49,10 +49,11 @@ __global__ __launch_bounds__(256) void k_transpose_states(const char* __restrict
     }
 }
 
+// bytes of w are in [0, 31] (XT is sanitised), pat = the lane's state in every byte (<= 30): four full-rate VALU
 __device__ __forceinline__ u32 eq_bytes(u32 w, u32 pat) {
-    const u32 t = (w & 0x1f1f1f1fu) ^ pat;                        // 0xFF (not a state) -> 31, never a pattern
-    const u32 nz = (t + 0x7f7f7f7fu) & 0x80808080u;               // bit 7 of a byte set <=> byte != pattern
-    return (nz >> 7) ^ 0x01010101u;                               // 1 where equal
+    const u32 t = w ^ pat;                                        // 0 where equal, < 32 elsewhere
+    const u32 u = t + 0x7f7f7f7fu;                                // bit 7 of a byte set <=> byte != pattern (no carries)
+    return ~(u >> 7) & 0x01010101u;                               // 1 where equal
 }
 
 __device__ __forceinline__ v4i onehot16(const uint4 raw, u32 pat) {
@@ -136,10 +137,10 @@ __global__ __launch_bounds__(64, 2) void k_s3_hist_mfma(const char* __restrict__
 #pragma unroll
         for (int g = 0; g < MF_T * MF_T; ++g) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);    // one MFMA
-            __builtin_amdgcn_sched_group_barrier(0x002, 16, 0);   // sixteen VALU
+            __builtin_amdgcn_sched_group_barrier(0x002, 14, 0);   // its share of the VALU that builds the next operands
         }
 #pragma unroll
-        for (int t = 0; t < MF_T; ++t) { fa[t] = na[t]; fb[t] = nb[t]; }
+        for (int t = 0; t < MF_T; ++t) { fa[t] = na[t]; fb[t] = nb[t]; }   // (a copy-free two-step unroll spills)
     }
 
     // C/D layout of a 32x32 MFMA: column = lane & 31, row = (r & 3) + 8*(r >> 2) + 4*(lane >> 5)
