@@ -122,7 +122,10 @@ def main():
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(N, S)          # before any GPU initialisation: it forks
+        try:
+            cpu = cpu_baseline(N, S)      # before any GPU initialisation: it forks
+        except Exception as e:            # a host without fork / enough memory must not take the GPU measurement down
+            cpu = {"value": None, "unit": "Mbins/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (e,)}
 
     import torch
     import torch.distributed as dist

@@ -254,3 +254,33 @@ def test_cli_single_mode(tmp_path, golden_real, fake_backend, state_info):
     res = CliRunner().invoke(main, ["-i", str(ind), "-j", str(state_info), "-o", str(out), "-s", "3", "-m", "paired",
                                     "-a", str(ind), "-b", str(ind)])
     assert res.exit_code == 0 and "ERROR" in res.output                                     # -i with paired mode
+
+
+def test_cli_argument_errors(tmp_path, state_info, fake_backend):
+    """Error behaviour of the reference's checkFlags / checkArguments (run.py:328-451) for the STEP 1-3 flags."""
+    from click.testing import CliRunner
+    from epilogos_amd.run import main
+    ind = tmp_path / "in"
+    ind.mkdir()
+    write_tsv(ind / "m.txt", np.zeros((4, 3), dtype=np.int8))
+    run = lambda *a: CliRunner().invoke(main, list(a))
+    assert "required" in run("-l", "-o", str(tmp_path / "o"), "-j", str(state_info)).output          # no -i
+    assert "required" in run("-l", "-i", str(ind), "-j", str(state_info)).output                      # no -o
+    assert "required" in run("-l", "-i", str(ind), "-o", str(tmp_path / "o")).output                   # no -j
+    r = run("-l", "-i", str(ind), "-o", str(tmp_path / "o"), "-j", str(state_info), "-s", "4")
+    assert isinstance(r.exception, ValueError)
+    r = run("-l", "-m", "paired", "-a", str(ind), "-b", str(ind), "-o", str(tmp_path / "o"), "-j", str(state_info), "-s", "3")
+    assert isinstance(r.exception, ValueError)                                                          # paired supports S1/S2
+    r = run("-l", "-i", str(tmp_path / "missing"), "-o", str(tmp_path / "o"), "-j", str(state_info))
+    assert isinstance(r.exception, FileNotFoundError)
+    empty = tmp_path / "empty"
+    empty.mkdir()
+    r = run("-l", "-i", str(empty), "-o", str(tmp_path / "o"), "-j", str(state_info))
+    assert isinstance(r.exception, OSError)
+    assert "same as the input" in run("-l", "-i", str(ind), "-o", str(ind), "-j", str(state_info)).output
+    assert "Version" in run("-v").output
+    b = tmp_path / "b"
+    b.mkdir()
+    write_tsv(b / "other.txt", np.zeros((4, 3), dtype=np.int8))
+    r = run("-l", "-m", "paired", "-a", str(ind), "-b", str(b), "-o", str(tmp_path / "o2"), "-j", str(state_info))
+    assert isinstance(r.exception, FileNotFoundError)                                                   # no same-named file in -b
