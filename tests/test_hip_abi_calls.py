@@ -1,0 +1,107 @@
+"""GPU: every entry point of include/epilogos_amd.h is called at least once straight through ctypes (no engine
+helpers), including the error paths a caller can hit."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+
+from oracle import oracle_np as onp
+from tests.conftest import synth_states
+
+pytestmark = pytest.mark.gpu
+S = 18
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+@pytest.fixture(scope="module")
+def abi():
+    from epilogos_amd import _abi, engine
+    engine.require_gpu()
+    return _abi
+
+
+def test_direct_calls_match_oracle(abi):
+    from epilogos_amd import engine
+    R, N = 700, 41
+    x = synth_states(R, N, seed=2)
+    X = engine.states_to_device(x)
+    ldx = X.stride(0)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    assert abi.call("epg_version") == 1 and abi.call("epg_device_cus") > 0
+    # S1 / S2 / S3 expected through the X-taking entry points
+    c1 = torch.zeros(S, dtype=torch.int64, device="cuda")
+    abi.call("epg_hist_s1", _p(X), R, N, ldx, S, _p(c1), st)
+    assert np.array_equal(c1.cpu().numpy(), onp.expected_s1(x, S))
+    ws = torch.empty(abi.call("epg_ws_bytes", 2, R, N, S), dtype=torch.uint8, device="cuda")
+    c2 = torch.zeros(S * S, dtype=torch.int64, device="cuda")
+    abi.call("epg_hist_s2", _p(X), R, N, ldx, S, _p(c2), _p(ws), ws.numel(), st)
+    assert np.array_equal(c2.cpu().numpy().reshape(S, S), onp.expected_s2(x, S))
+    ws3 = torch.empty(abi.call("epg_ws_bytes", 3, R, N, S), dtype=torch.uint8, device="cuda")
+    c3 = torch.zeros(N * N * S * S, dtype=torch.int32, device="cuda")
+    abi.call("epg_hist_s3", _p(X), R, N, ldx, S, _p(c3), _p(ws3), ws3.numel(), st)      # matrix-core path
+    c3b = torch.zeros_like(c3)
+    abi.call("epg_hist_s3", _p(X), R, N, ldx, S, _p(c3b), None, 0, st)                   # LDS-atomic path (no workspace)
+    ref3 = onp.expected_s3(x, S)
+    assert np.array_equal(c3.cpu().numpy().reshape(ref3.shape), ref3) and torch.equal(c3, c3b)
+    # normalise
+    q1 = torch.empty(S, dtype=torch.float32, device="cuda")
+    wsn = torch.empty(256, dtype=torch.uint8, device="cuda")
+    abi.call("epg_normalise_i64", _p(c1), S, _p(q1), _p(wsn), 256, st)
+    assert np.array_equal(q1.cpu().numpy(), onp.normalise(onp.expected_s1(x, S)))
+    q3 = torch.empty(c3.numel(), dtype=torch.float32, device="cuda")
+    abi.call("epg_normalise_i32", _p(c3), c3.numel(), _p(q3), _p(wsn), 256, st)
+    assert np.array_equal(q3.cpu().numpy().reshape(ref3.shape), onp.normalise(ref3))
+    # workspace too small / bad arguments are reported, not executed
+    with pytest.raises(abi.EpilogosHipError) as e:
+        abi.call("epg_score_s1", _p(X), R, N, ldx, S, _p(q1), None, _p(torch.empty((R, S), device="cuda")), _p(wsn), 16, st)
+    assert e.value.code == -4
+    with pytest.raises(abi.EpilogosHipError) as e:
+        abi.call("epg_bin_hist", _p(X), R, N, N - 1, S, None, _p(c1), st)
+    assert e.value.code == -1
+    with pytest.raises(abi.EpilogosHipError) as e:
+        abi.call("epg_bin_hist", _p(X), R, N, ldx, 40, None, _p(c1), st)
+    assert e.value.code == -2
+
+
+def test_group_size_option_of_the_null_shuffle(abi):
+    """-g/--group-size: the null halves have `g` columns each (helpers.py:190-194); S2 keeps the real groups' P (Q9)."""
+    from epilogos_amd import backend
+    be = backend.HipBackend()
+    xa, xb = synth_states(500, 12, seed=1), synth_states(500, 9, seed=2)
+    q1 = onp.normalise(onp.expected_s1(np.concatenate([xa, xb], axis=1), S))
+    na, nb = be.null_scores(xa, xb, S, 1, q1, 6, seed=3)
+    assert na.shape == (500, S) and np.isfinite(na).all() and np.isfinite(nb).all()
+    HA, HB = be.engine.null_hist(be.to_device(xa), 12, be.to_device(xb), 9, S, 6, 6, 3)
+    ref = onp.kl(be.engine.hist_to_numpy(HA).astype(np.float64) / 6, q1[None, :]).astype(np.float32)
+    np.testing.assert_allclose(na, ref, rtol=2e-7, atol=0)
+    q2 = onp.normalise(onp.expected_s2(np.concatenate([xa, xb], axis=1), S))
+    na2, _ = be.null_scores(xa, xb, S, 2, q2, 6, seed=3)
+    h = be.engine.hist_to_numpy(HA).astype(np.int64)
+    num = h[:, :, None] * h[:, None, :]
+    idx = np.arange(S)
+    num[:, idx, idx] = h * (h - 1)
+    ref2 = onp.kl(num / (12 * 11), q2[None]).sum(axis=1)
+    np.testing.assert_allclose(na2, ref2.astype(np.float32), rtol=1e-5, atol=1e-9)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_bin_hist_random_geometry(abi, seed):
+    """Random R, N, row pitch and base misalignment against the oracle."""
+    from epilogos_amd import engine
+    rng = np.random.default_rng(seed)
+    R, N = int(rng.integers(1, 400)), int(rng.integers(1, 1300))
+    pitch = N + int(rng.integers(0, 40))
+    off = int(rng.integers(0, 16))
+    x = rng.integers(0, S, size=(R, N)).astype(np.int8)
+    flat = torch.full((R * pitch + off + 64,), -1, dtype=torch.int8, device="cuda")
+    view = flat[off:off + R * pitch].view(R, pitch)
+    view[:, :N] = torch.from_numpy(x).cuda()
+    H, counts = engine.bin_hist(view, N, S)
+    h = onp.bin_hist(x, S)
+    assert np.array_equal(engine.hist_to_numpy(H).astype(np.int64), h), (R, N, pitch, off)
+    assert np.array_equal(counts.cpu().numpy(), h.sum(axis=0))
