@@ -77,6 +77,16 @@ def test_s3_score_golden(eng, golden_s3, golden_real, golden_edge):
     _s3_score_check(eng, golden_edge["n2_x"], golden_edge["n2_s3_exp"], golden_edge["n2_s3_f32"])
 
 
+@pytest.mark.parametrize("N", [33, 65])
+def test_s3_score_tile_not_multiple_of_four(eng, N):
+    """N*S % 4 != 0: the LDS tile is loaded with scalar loads, and R is not a multiple of the MFMA K step."""
+    x = synth_states(211, N, seed=N)
+    c = onp.expected_s3(x, S)
+    _, got = _s3_counts(eng, x)
+    assert np.array_equal(got, c)
+    _s3_score_check(eng, x, onp.normalise(c))
+
+
 def test_s3_score_random(eng):
     x = synth_states(9000, 70, seed=3)             # more than one slice of 8192 bins
     q = onp.normalise(onp.expected_s3(x, S))
