@@ -126,13 +126,16 @@ def main(mode, commandLineBool, inputDirectory, inputDirectory1, inputDirectory2
     world = int(os.environ.get("WORLD_SIZE", "1"))
     import torch
     device = None
+    # EPILOGOS_DIST_BACKEND=gloo lets several ranks share one GPU (testing the multi-rank path on a 1-GPU box)
+    dist_backend = os.environ.get("EPILOGOS_DIST_BACKEND", "")
     if torch.cuda.is_available():
-        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+        torch.cuda.set_device(local % torch.cuda.device_count() if dist_backend else local)
         device = torch.device("cuda", torch.cuda.current_device())
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl" if device is not None else "gloo")
+        dist.init_process_group(backend=dist_backend or ("nccl" if device is not None else "gloo"))
     rank = int(os.environ.get("RANK", "0"))
     say = print if rank == 0 else (lambda *a, **k: None)
 

@@ -99,3 +99,40 @@ def test_cli_paired_s1(tmp_path, golden_pair):
     nd2 = np.load(out2 / ("temp_nullDistances_%s_matrix_chr1.npz" % tag))["nullDistances"]
     assert np.array_equal(nd1, nd2)
     assert not np.load(out2 / ("temp_quiescence_%s_matrix_chr1.npz" % tag))["quiescenceArr"].any()
+
+
+def test_two_ranks_on_one_gpu_match_one_rank(tmp_path, golden_real):
+    """The real HIP backend under torch.distributed.run with two ranks (gloo transport, both on cuda:0): partition,
+    device-side count all-reduce and per-rank gzip members give the same files as a single rank."""
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+    from tests.conftest import load_golden
+    root = Path(__file__).resolve().parents[1]
+    g = golden_real
+    ind = tmp_path / "in"
+    ind.mkdir()
+    write_tsv(ind / "matrix_chr1.txt.gz", g["x"][:1300], chrom="chr1", start0=int(g["start0"]))
+    write_tsv(ind / "matrix_chr2.txt.gz", g["x"][1300:], chrom="chr2")
+    meta = tmp_path / "metadata.tsv"
+    names = load_golden("roi.npz")["state_names"]
+    meta.write_text("zero_index\tone_index\tshort_name\n" + "".join("%d\t%d\t%s\n" % (i, i + 1, names[i]) for i in range(S)))
+    outs = {}
+    for world in (1, 2):
+        out = tmp_path / ("out%d" % world)
+        port = str(29700 + os.getpid() % 200 + world)
+        env = dict(os.environ, PYTHONPATH=str(root), EPILOGOS_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr",
+               "127.0.0.1", "--master-port", port, "-m", "epilogos_amd.run", "-l", "-i", str(ind), "-j", str(meta), "-o", str(out),
+               "-s", "2", "-f", "t"]
+        res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=str(root))
+        assert res.returncode == 0, res.stdout + res.stderr
+        outs[world] = out
+    for name in ("scores_t_matrix_chr1.txt.gz", "scores_t_matrix_chr2.txt.gz"):
+        with gzip.open(outs[1] / name, "rb") as a, gzip.open(outs[2] / name, "rb") as b:
+            assert a.read() == b.read()
+    assert (outs[1] / "regionsOfInterest_t.txt").read_bytes() == (outs[2] / "regionsOfInterest_t.txt").read_bytes()
+    with gzip.open(outs[2] / "scores_t_matrix_chr1.txt.gz", "rb") as fh:
+        got = _text_to_array(fh.read())
+    np.testing.assert_allclose(got, g["s2_f32"][:1300], atol=1.01e-5)          # and they are the reference's S2 scores
