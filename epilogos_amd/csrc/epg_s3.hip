@@ -104,158 +104,127 @@ __global__ __launch_bounds__(S3H_THREADS) void k_s3_hist(const char* __restrict_
     }
 }
 
-// T2[b][j][a][i] = float32 kl(float32(1)/P, q[a,b,i,j]); float32 arithmetic like scores.py:479-480.
-__global__ void k_s3_table(const float* __restrict__ q, int N, int S, float* __restrict__ T2) {
+// T[a][b][i][j] = float32 kl(float32(1)/P, q[a,b,i,j]); float32 arithmetic like scores.py:479-480.  Same layout as q.
+__global__ void k_s3_table(const float* __restrict__ q, int N, int S, float* __restrict__ T) {
     const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const long total = (long)N * N * S * S;
     if (e >= total) return;
-    // e indexes T2: ((b*S + j)*N + a)*S + i
-    const int i = (int)(e % S);
-    long t = e / S;
-    const int a = (int)(t % N);
-    t /= N;
-    const int j = (int)(t % S);
-    const int b = (int)(t / S);
-    const float qv = q[(((long)a * N + b) * S + i) * S + j];
+    const float qv = q[e];
     const float obs = 1.0f / (float)((long)N * (N - 1));
     float v = 0.0f;
     if (qv != 0.0f) {
         const float r = obs / qv;
         if (r > 0.0f) v = obs * log2f(r);
     }
-    T2[e] = v;
+    T[e] = v;
 }
 
-constexpr int S3_SCORE_SLICE = 4096;
-constexpr int S3S_THREADS = 512;
-constexpr int S3S_MAX_LANES_PER_BIN = 64;
+// ---------------------------------------------------------------------------------------------------------------
+// S3 score, a-streaming form.  score[bin, x_b] += sum_{a != b} T[a, b, x_a, x_b]  for every biosample b.
+// A block owns one b and a slice of S3S_THREADS*16 bins; every thread owns 16 consecutive bins: their x_b (16 bytes of
+// XT[b], loop invariant) and 16 accumulators.  The block then streams over a: per a one 16-byte load of XT[a] per
+// thread (1 KiB per wave, fully coalesced) and 16 gathers from the 18x18 table T[a][b] staged in LDS, padded and
+// transposed to [x_b][32] so that "not a state" (31 in the sanitised XT) reads a zero and needs no branch.
+// No per-state passes, no bin lists, no cross-lane reduction, no dependent-load chains (the loads of the next a do not
+// depend on anything).  Tables are staged S3S_ACH biosamples at a time (one barrier per S3S_ACH values of a).
+// Partial sums of S3S_ACH float terms are folded into float64 accumulators (error ~1e-7 relative).
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int S3S_THREADS = 256;
+constexpr int S3S_BPT = 16;                       // bins per thread
+constexpr int S3S_SLICE = S3S_THREADS * S3S_BPT;  // 4096 bins per block
+constexpr int S3S_ACH = 4;                        // biosamples a per staging phase
+constexpr int S3S_LD = 33;                        // floats per table row: odd, so rows of different x_b start on different banks
 
-// One lane = one bin.  For the block's biosample b and every state s present in the slice's column b: stage the
-// tile T2[b][s][:][:] in LDS, compact the bins with x_b == s into a list, and let each lane walk its bin's row
-// (16-byte loads, next chunk prefetched) gathering tile[a][x_a] for all a -- no cross-lane reduction, 64 bins per
-// wave in flight.  Four float partial sums per 16-state chunk are folded into a float64 accumulator (each float sum
-// has 4 terms, so the float64 total carries ~1e-7 relative error, far inside the 2e-6 test bound).
-__global__ __launch_bounds__(S3S_THREADS) void k_s3_score(const char* __restrict__ X, long R, int N, long ldx, int S,
-                                                           const float* __restrict__ T2, double* __restrict__ out64) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* tile = reinterpret_cast<float*>(smem);                                              // [N*S]
-    unsigned short* list = reinterpret_cast<unsigned short*>(smem + (size_t)N * S * 4);         // [S3_SCORE_SLICE]
-    unsigned char* col = reinterpret_cast<unsigned char*>(list + S3_SCORE_SLICE);               // [S3_SCORE_SLICE]
-    __shared__ u32 present;
-    __shared__ u32 nlist;
-    const int b = blockIdx.x % N;                 // b fastest: blocks of one slice run together (rows stay in L2)
-    const long slice = blockIdx.x / N;
-    const long r0 = slice * S3_SCORE_SLICE;
-    const int nb = (int)((R - r0) < S3_SCORE_SLICE ? (R - r0) : S3_SCORE_SLICE);
-    const int nchunks = (N + 15) >> 4;
+__global__ __launch_bounds__(S3S_THREADS) void k_s3_score(const char* __restrict__ XT, long Rp, long R, int N, int S,
+                                                           const float* __restrict__ T, double* __restrict__ out64) {
+    __shared__ float tab[2][S3S_ACH][32][S3S_LD];  // [phase][a][x_b][x_a], zero outside S x S
+    const int b = blockIdx.x % N;                 // b fastest: the N blocks of a slice share its XT rows in L2
+    const long r0 = (long)(blockIdx.x / N) * S3S_SLICE + (long)threadIdx.x * S3S_BPT;
+    const int SS = S * S;
 
-    if (threadIdx.x == 0) present = 0;
-    __syncthreads();
-    u32 mine = 0;
-    for (int k = threadIdx.x; k < nb; k += S3S_THREADS) {
-        const unsigned char v = (unsigned char)X[(r0 + k) * ldx + b];
-        col[k] = v;
-        if (v < S) mine |= 1u << v;
+    // zero the padding once (both phases); the S x S part is rewritten every phase
+    for (int e = threadIdx.x; e < 2 * S3S_ACH * 32 * S3S_LD; e += S3S_THREADS) (&tab[0][0][0][0])[e] = 0.f;
+    // this thread's 16 bins: x_b (bytes) and the LDS row offsets x_b * 32 floats
+    uint4 xbv = make_uint4(0x1f1f1f1fu, 0x1f1f1f1fu, 0x1f1f1f1fu, 0x1f1f1f1fu);
+    if (r0 < Rp) xbv = *reinterpret_cast<const uint4*>(XT + (long)b * Rp + r0);
+    const u32 xbw[4] = {xbv.x, xbv.y, xbv.z, xbv.w};
+    u32 rowoff[S3S_BPT];                            // byte offset of tab[..][a][x_b][0]
+#pragma unroll
+    for (int u = 0; u < S3S_BPT; ++u) rowoff[u] = ((xbw[u >> 2] >> (8 * (u & 3))) & 0xffu) * (u32)S3S_LD * 4u;
+    double acc[S3S_BPT];
+#pragma unroll
+    for (int u = 0; u < S3S_BPT; ++u) acc[u] = 0.0;
+
+    // staging map of this thread, computed once (the integer divisions cost as much as a whole phase of gathers):
+    // element e = tid + k*THREADS of a phase's S3S_ACH*S*S table values -> source offset and padded/transposed LDS slot
+    constexpr int STG = (S3S_ACH * 31 * 31 + S3S_THREADS - 1) / S3S_THREADS;
+    long soff[STG];
+    int doff[STG], sai[STG];
+#pragma unroll
+    for (int k = 0; k < STG; ++k) {
+        const int e = threadIdx.x + k * S3S_THREADS;
+        const int ai = e / SS, ij = e - ai * SS;
+        const int i = ij / S, j = ij - i * S;
+        sai[k] = e < S3S_ACH * SS ? ai : -1;
+        soff[k] = (long)ai * N * SS + ij;
+        doff[k] = (ai * 32 + j) * S3S_LD + i;
     }
-    if (mine) atomicOr(&present, mine);
+    auto stage = [&](int phase, int a0) {           // tables T[a0 .. a0+ACH) [b] -> tab[phase], transposed + padded
+        const float* src = T + ((long)a0 * N + b) * SS;
+        float* dst = &tab[phase][0][0][0];
+        float v[STG];
+#pragma unroll
+        for (int k = 0; k < STG; ++k) {
+            const int a = a0 + sai[k];
+            v[k] = (sai[k] >= 0 && a < N && a != b) ? src[soff[k]] : 0.f;      // a == b contributes nothing
+        }
+#pragma unroll
+        for (int k = 0; k < STG; ++k)
+            if (sai[k] >= 0) dst[doff[k]] = v[k];
+    };
     __syncthreads();
-    const u32 have = present;
-
-    for (int s = 0; s < S; ++s) {
-        if (!((have >> s) & 1u)) continue;       // block-uniform
-        __syncthreads();                           // previous tile and list fully consumed
-        if (threadIdx.x == 0) nlist = 0;
-        const float* src = T2 + ((long)b * S + s) * N * S;
-        // tile: 16-byte loads, all of a thread's loads in flight at once (a scalar-load loop costs one L2 round trip
-        // per 512 floats and dominated the pass); T2 tiles are 16-byte aligned when N*S is a multiple of 4
-        const int n4 = ((N * S) & 3) == 0 ? (N * S) >> 2 : 0;
-        {
-            const float4* src4 = reinterpret_cast<const float4*>(src);
-            float4* tile4 = reinterpret_cast<float4*>(tile);
-            constexpr int U = 8;
-            for (int e0 = threadIdx.x; e0 < n4; e0 += S3S_THREADS * U) {
-                float4 v[U];
+    stage(0, 0);
+    __syncthreads();
+    auto load_phase = [&](int a0, uint4 (&raw)[S3S_ACH]) {
 #pragma unroll
-                for (int u = 0; u < U; ++u)
-                    if (e0 + u * S3S_THREADS < n4) v[u] = src4[e0 + u * S3S_THREADS];
+        for (int ai = 0; ai < S3S_ACH; ++ai)
+            raw[ai] = (a0 + ai < N && r0 < Rp) ? *reinterpret_cast<const uint4*>(XT + (long)(a0 + ai) * Rp + r0) : xbv;
+    };
+    const char* t0 = reinterpret_cast<const char*>(&tab[0][0][0][0]);
+    uint4 raw[S3S_ACH], nraw[S3S_ACH];
+    load_phase(0, raw);
+    int phase = 0;
+    for (int a0 = 0; a0 < N; a0 += S3S_ACH, phase ^= 1) {
+        load_phase(a0 + S3S_ACH, nraw);                                  // next phase's state bytes: in flight during this one
+        if (a0 + S3S_ACH < N) stage(phase ^ 1, a0 + S3S_ACH);          // next tables while this phase is consumed
+        float part[S3S_BPT];
+        u32 rbase[S3S_BPT];                       // LDS byte address of this phase's row x_b of table 0
+        const u32 pbase = (u32)(reinterpret_cast<const char*>(&tab[phase][0][0][0]) - t0);
 #pragma unroll
-                for (int u = 0; u < U; ++u)
-                    if (e0 + u * S3S_THREADS < n4) tile4[e0 + u * S3S_THREADS] = v[u];
+        for (int u = 0; u < S3S_BPT; ++u) { part[u] = 0.f; rbase[u] = rowoff[u] + pbase; }
+        const int na = N - a0 < S3S_ACH ? N - a0 : S3S_ACH;
+#pragma unroll
+        for (int ai = 0; ai < S3S_ACH; ++ai) {
+            if (ai >= na) break;                  // wave-uniform
+            const u32 w[4] = {raw[ai].x, raw[ai].y, raw[ai].z, raw[ai].w};
+#pragma unroll
+            for (int u = 0; u < S3S_BPT; ++u) {
+                const u32 xa4 = ((w[u >> 2] >> (8 * (u & 3))) & 0xffu) << 2;
+                // table ai of the phase sits at a compile-time offset: folded into the ds_read immediate
+                part[u] += *reinterpret_cast<const float*>(t0 + (rbase[u] + xa4) + ai * (32 * S3S_LD * 4));
             }
-            for (int e = 4 * n4 + threadIdx.x; e < N * S; e += S3S_THREADS) tile[e] = src[e];
         }
+#pragma unroll
+        for (int u = 0; u < S3S_BPT; ++u) acc[u] += (double)part[u];
+#pragma unroll
+        for (int ai = 0; ai < S3S_ACH; ++ai) raw[ai] = nraw[ai];
         __syncthreads();
-        // compact the bins with x_b == s: one LDS atomic per wave (ballot + lane prefix), not one per bin
-        for (int k0 = 0; k0 < nb; k0 += S3S_THREADS) {
-            const int k = k0 + threadIdx.x;
-            const bool hit = k < nb && col[k] == (unsigned char)s;
-            const unsigned long long m = __ballot(hit);
-            const int lane = threadIdx.x & 63;
-            u32 base = 0;
-            if (lane == 0 && m) base = atomicAdd(&nlist, (u32)__popcll(m));
-            base = __shfl(base, 0);
-            if (hit) list[base + __popcll(m & ((1ull << lane) - 1))] = (unsigned short)k;
-        }
-        __syncthreads();
-        const int n = (int)nlist;
-        // a quad per bin: quad lane j walks chunks j, j+4, ... of the bin's row, four chunks in flight; the walk is a
-        // chain of dependent L2 round trips, so four lanes per bin cut its length four-fold and keep the rare states'
-        // passes (a handful of bins) from idling the block
-        // lanes per bin: as many as keep the block full in ONE round (a rare state's handful of bins gets 16-64 lanes
-        // each and one short dependent-load chain; the dominant state gets 1-4 lanes per bin and several rounds)
-        int G = 1;
-        while (G < S3S_MAX_LANES_PER_BIN && 2 * G * n <= S3S_THREADS) G <<= 1;
-        if (G < 4 && n > 0) G = 4;
-        const int BPR = S3S_THREADS / G;                               // bins per round
-        const int j = threadIdx.x & (G - 1);
-        for (int t = threadIdx.x / G; t < ((n + BPR - 1) / BPR) * BPR; t += BPR) {
-            const bool live = t < n;
-            const long row = r0 + (live ? list[t] : list[0]);
-            const char* rp = X + row * ldx;
-            double acc = 0.0;
-            // a 16-byte chunk may run past N: into row padding or the next row (masked by the a < N test below); only
-            // the matrix's very last row of a tightly packed matrix must not be over-read
-            const bool tail_unsafe = row == R - 1 && ldx < 16L * nchunks;
-            auto load_chunk = [&](int c) -> uint4 {
-                if (c == nchunks - 1 && tail_unsafe) {
-                    u32 w4[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
-                    for (int a = 16 * c; a < N; ++a) {
-                        const int o = a - 16 * c;
-                        w4[o >> 2] = (w4[o >> 2] & ~(0xffu << (8 * (o & 3)))) | ((u32)(unsigned char)rp[a] << (8 * (o & 3)));
-                    }
-                    return make_uint4(w4[0], w4[1], w4[2], w4[3]);
-                }
-                return ld16(rp + 16 * c);
-            };
-            constexpr int PF = 4;
-            uint4 ring[PF];
+    }
 #pragma unroll
-            for (int p = 0; p < PF; ++p) ring[p] = (live && j + G * p < nchunks) ? load_chunk(j + G * p) : make_uint4(~0u, ~0u, ~0u, ~0u);
-            for (int c0 = j; c0 < nchunks && live; c0 += G * PF) {
-#pragma unroll
-                for (int p = 0; p < PF; ++p) {
-                    const int c = c0 + G * p;
-                    if (c >= nchunks) break;
-                    const uint4 cur = ring[p];
-                    if (c + G * PF < nchunks) ring[p] = load_chunk(c + G * PF);
-                    const u32 w[4] = {cur.x, cur.y, cur.z, cur.w};
-                    const int abase = 16 * c;
-#pragma unroll
-                    for (int d = 0; d < 4; ++d) {
-                        float part = 0.f;
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) {
-                            const int a = abase + 4 * d + k;
-                            const u32 x = (w[d] >> (8 * k)) & 0xffu;
-                            if (a < N && x < (u32)S) part += tile[a * S + (int)x];
-                        }
-                        acc += (double)part;
-                    }
-                }
-            }
-            for (int off = 1; off < G; off <<= 1) acc += __shfl_xor(acc, off);
-            if (live && j == 0) atomicAdd(&out64[row * S + s], acc);
-        }
+    for (int u = 0; u < S3S_BPT; ++u) {
+        const long row = r0 + u;
+        const u32 xb = (xbw[u >> 2] >> (8 * (u & 3))) & 0xffu;
+        if (row < R && xb < (u32)S) atomicAdd(&out64[row * S + xb], acc[u]);
     }
 }
 
@@ -271,13 +240,13 @@ static int s3_ta(int S) {
 }
 
 int64_t s3_mfma_ws_bytes(int64_t R, int N);
+int transpose_states(const char* X, int64_t R, int32_t N, int64_t ldx, int32_t S, char* XT, int64_t Rp, hipStream_t st);
 int hist_s3_mfma(const char* X, int64_t R, int32_t N, int64_t ldx, int32_t S, int32_t* counts, void* ws, hipStream_t st);
 
 int64_t s3_table_bytes(int N, int S) { return align_up((int64_t)N * N * S * S * 4, 256); }
 int64_t s3_ws_bytes(int64_t R, int N, int S) {
-    const int64_t score = s3_table_bytes(N, S) + align_up(R * S * 8, 256);     // table + float64 accumulator
-    const int64_t hist = s3_mfma_ws_bytes(R, N);                               // transposed state matrix
-    return score > hist ? score : hist;
+    // score: table + transposed state matrix + float64 accumulator; expected: transposed state matrix
+    return s3_table_bytes(N, S) + s3_mfma_ws_bytes(R, N) + align_up(R * S * 8, 256);
 }
 
 int hist_s3_impl(const int8_t* X8, int64_t R, int32_t N, int64_t ldx, int32_t S, int32_t* counts, void* ws, int64_t ws_bytes,
@@ -310,22 +279,22 @@ int score_s3_impl(const int8_t* X8, int64_t R, int32_t N, int64_t ldx, int32_t S
     if (S > 31) return fail(EPG_ERR_UNSUPPORTED, "score_s3: S=%d > 31 not supported by this build", S);
     if (R == 0) return EPG_OK;
     if (!X8 || !q || !ws) return fail(EPG_ERR_INVALID_ARG, "score_s3: NULL argument");
-    const size_t shmem = (size_t)N * S * 4 + (size_t)S3_SCORE_SLICE * 3;
-    if (shmem > 160 * 1024 - 64) return fail(EPG_ERR_UNSUPPORTED, "score_s3: N*S = %d exceeds the LDS tile (N*S*4 + 8 KB <= 160 KB)", N * S);
-    const int64_t tb = s3_table_bytes(N, S);
-    const int64_t need = tb + (out64 ? 0 : align_up(R * S * 8, 256));
+    const int64_t tb = s3_table_bytes(N, S), xtb = s3_mfma_ws_bytes(R, N);
+    const int64_t need = tb + xtb + (out64 ? 0 : align_up(R * S * 8, 256));
     if (ws_bytes < need) return fail(EPG_ERR_WORKSPACE, "score_s3: workspace %lld < %lld bytes", (long long)ws_bytes, (long long)need);
-    float* T2 = reinterpret_cast<float*>(ws);
-    double* acc = out64 ? out64 : reinterpret_cast<double*>(reinterpret_cast<char*>(ws) + tb);
+    float* T = reinterpret_cast<float*>(ws);
+    char* XT = reinterpret_cast<char*>(ws) + tb;
+    double* acc = out64 ? out64 : reinterpret_cast<double*>(reinterpret_cast<char*>(ws) + tb + xtb);
     const long total = (long)N * N * S * S;
-    hipLaunchKernelGGL(k_s3_table, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, q, N, S, T2);
+    hipLaunchKernelGGL(k_s3_table, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, q, N, S, T);
     EPG_LAUNCH_CHECK("k_s3_table");
+    const long Rp = align_up(R, 32);
+    int rc = transpose_states(reinterpret_cast<const char*>(X8), R, N, ldx, S, XT, Rp, st);
+    if (rc) return rc;
     EPG_HIP(hipMemsetAsync(acc, 0, (size_t)R * S * 8, st));
-    const long nslices = (R + S3_SCORE_SLICE - 1) / S3_SCORE_SLICE;
+    const long nslices = (R + S3S_SLICE - 1) / S3S_SLICE;
     if (nslices * N > 0x7fffffffL) return fail(EPG_ERR_UNSUPPORTED, "score_s3: R*N too large for one call");
-    EPG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_s3_score), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-    hipLaunchKernelGGL(k_s3_score, dim3((unsigned)(nslices * N)), dim3(S3S_THREADS), shmem, st, reinterpret_cast<const char*>(X8), (long)R, N,
-                       (long)ldx, S, T2, acc);
+    hipLaunchKernelGGL(k_s3_score, dim3((unsigned)(nslices * N)), dim3(S3S_THREADS), 0, st, XT, Rp, (long)R, N, S, T, acc);
     EPG_LAUNCH_CHECK("k_s3_score");
     if (out32) {
         long blocks = ((long)R * S + 255) / 256;

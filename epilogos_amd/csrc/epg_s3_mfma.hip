@@ -165,12 +165,19 @@ __global__ __launch_bounds__(64, 2) void k_s3_hist_mfma(const char* __restrict__
 
 int64_t s3_mfma_ws_bytes(int64_t R, int N) { return align_up((int64_t)N * align_up(R, 32) + 64, 256); }
 
+// XT[sample][bin], bins padded to Rp (a multiple of 32), everything that is not a state in [0, S) stored as 31
+int transpose_states(const char* X, int64_t R, int32_t N, int64_t ldx, int32_t S, char* XT, int64_t Rp, hipStream_t st) {
+    hipLaunchKernelGGL(k_transpose_states, dim3((unsigned)((Rp + 63) / 64), (unsigned)((N + 63) / 64)), dim3(256), 0, st, X, (long)R, N,
+                       (long)ldx, S, XT, (long)Rp);
+    EPG_LAUNCH_CHECK("k_transpose_states");
+    return EPG_OK;
+}
+
 int hist_s3_mfma(const char* X, int64_t R, int32_t N, int64_t ldx, int32_t S, int32_t* counts, void* ws, hipStream_t st) {
     const long Rp = align_up(R, 32);
     char* XT = reinterpret_cast<char*>(ws);
-    hipLaunchKernelGGL(k_transpose_states, dim3((unsigned)((Rp + 63) / 64), (unsigned)((N + 63) / 64)), dim3(256), 0, st, X, (long)R, N,
-                       (long)ldx, S, XT, Rp);
-    EPG_LAUNCH_CHECK("k_transpose_states");
+    int rc = transpose_states(X, R, N, ldx, S, XT, Rp, st);
+    if (rc) return rc;
     const int nblk = (N * S + MF_ROWS - 1) / MF_ROWS;
     const long npairs = (long)nblk * (nblk + 1) / 2;
     // split K so that there are a few tasks per wave slot (2 waves per SIMD); int32 atomics combine the splits
