@@ -105,10 +105,13 @@ __global__ __launch_bounds__(S3H_THREADS) void k_s3_hist(const char* __restrict_
 }
 
 // T[a][b][i][j] = float32 kl(float32(1)/P, q[a,b,i,j]); float32 arithmetic like scores.py:479-480.  Same layout as q.
-__global__ void k_s3_table(const float* __restrict__ q, int N, int S, float* __restrict__ T) {
+// rows a in [N, Nceil) and the diagonal a == b are zero, so that the score kernel needs no predicates
+__global__ void k_s3_table(const float* __restrict__ q, int N, int Nceil, int S, float* __restrict__ T) {
     const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long total = (long)N * N * S * S;
-    if (e >= total) return;
+    const long SS = (long)S * S, total = (long)N * N * SS;
+    if (e >= (long)Nceil * N * SS) return;
+    const long ab = e / SS;
+    if (e >= total || ab / N == ab % N) { T[e] = 0.0f; return; }
     const float qv = q[e];
     const float obs = 1.0f / (float)((long)N * (N - 1));
     float v = 0.0f;
@@ -131,99 +134,124 @@ __global__ void k_s3_table(const float* __restrict__ q, int N, int S, float* __r
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int S3S_THREADS = 256;
 constexpr int S3S_BPT = 16;                       // bins per thread
-constexpr int S3S_SLICE = S3S_THREADS * S3S_BPT;  // 4096 bins per block
+constexpr int S3S_SLICE = S3S_THREADS * S3S_BPT;  // bins per block
 constexpr int S3S_ACH = 4;                        // biosamples a per staging phase
 constexpr int S3S_LD = 33;                        // floats per table row: odd, so rows of different x_b start on different banks
+constexpr int S3S_TAB = 32 * S3S_LD * 4;          // bytes of one padded table
+constexpr int S3S_DUMMY = 31 * S3S_LD + 32;       // a slot no gather reads (column 32)
 
-__global__ __launch_bounds__(S3S_THREADS) void k_s3_score(const char* __restrict__ XT, long Rp, long R, int N, int S,
-                                                           const float* __restrict__ T, double* __restrict__ out64) {
-    __shared__ float tab[2][S3S_ACH][32][S3S_LD];  // [phase][a][x_b][x_a], zero outside S x S
-    const int b = blockIdx.x % N;                 // b fastest: the N blocks of a slice share its XT rows in L2
-    const long r0 = (long)(blockIdx.x / N) * S3S_SLICE + (long)threadIdx.x * S3S_BPT;
-    const int SS = S * S;
+// Everything the loop touches is unconditional: XT4 holds 4*state (31 -> 124 for "not a state" and for padded bins),
+// the table has zero rows for a >= N and a zero diagonal a == b, invalid staging elements go to a dummy LDS slot and
+// out-of-range addresses are clamped.  (With per-element predicates hipcc turned the loads into flat loads with
+// selected addresses and spilled the default value to scratch.)  Per-thread offsets are unsigned 32-bit byte offsets
+// from wave-uniform bases, which is the scalar-base + vector-offset form of global_load.
+template <int STG>
+struct S3Stage {
+    u32 soff[STG], doff[STG];                     // byte offsets: source inside T[a0][b], slot inside a phase buffer
+    float v[STG];
+};
 
-    // zero the padding once (both phases); the S x S part is rewritten every phase
-    for (int e = threadIdx.x; e < 2 * S3S_ACH * 32 * S3S_LD; e += S3S_THREADS) (&tab[0][0][0][0])[e] = 0.f;
-    // this thread's 16 bins: x_b (bytes) and the LDS row offsets x_b * 32 floats
-    uint4 xbv = make_uint4(0x1f1f1f1fu, 0x1f1f1f1fu, 0x1f1f1f1fu, 0x1f1f1f1fu);
-    if (r0 < Rp) xbv = *reinterpret_cast<const uint4*>(XT + (long)b * Rp + r0);
-    const u32 xbw[4] = {xbv.x, xbv.y, xbv.z, xbv.w};
-    u32 rowoff[S3S_BPT];                            // byte offset of tab[..][a][x_b][0]
+__device__ __forceinline__ float ldf(const char* base, u32 off) { return *reinterpret_cast<const float*>(base + off); }
+
+template <int PH, int STG>
+__device__ __forceinline__ void s3_phase(const char* __restrict__ XTs, long Rp, u32 toff, int N, int Nceil, int a0,
+                                         const char* __restrict__ Tb, long a_stride, char* tabc, S3Stage<STG>& sg,
+                                         const u32 (&rowoff)[S3S_BPT], uint4 (&raw)[S3S_ACH], double (&acc)[S3S_BPT]) {
+    // tables of the next phase (requested one phase ago) -> the other buffer; then request the phase after
+    char* dst = tabc + (PH ^ 1) * S3S_ACH * S3S_TAB;
 #pragma unroll
-    for (int u = 0; u < S3S_BPT; ++u) rowoff[u] = ((xbw[u >> 2] >> (8 * (u & 3))) & 0xffu) * (u32)S3S_LD * 4u;
+    for (int k = 0; k < STG; ++k) *reinterpret_cast<float*>(dst + sg.doff[k]) = sg.v[k];
+    if (a0 + 2 * S3S_ACH < Nceil) {                // wave-uniform
+        const char* src = Tb + (long)(a0 + 2 * S3S_ACH) * a_stride;
+#pragma unroll
+        for (int k = 0; k < STG; ++k) sg.v[k] = ldf(src, sg.soff[k]);
+    }
+    uint4 nraw[S3S_ACH];
+#pragma unroll
+    for (int ai = 0; ai < S3S_ACH; ++ai) {
+        int a = a0 + S3S_ACH + ai;
+        a = a < N ? a : N - 1;                     // rows past N read a valid row; their tables are zero
+        nraw[ai] = *reinterpret_cast<const uint4*>(XTs + (long)a * Rp + toff);
+    }
+    float part[S3S_BPT];
+#pragma unroll
+    for (int u = 0; u < S3S_BPT; ++u) part[u] = 0.f;
+#pragma unroll
+    for (int ai = 0; ai < S3S_ACH; ++ai) {
+        const u32 w[4] = {raw[ai].x, raw[ai].y, raw[ai].z, raw[ai].w};
+#pragma unroll
+        for (int u = 0; u < S3S_BPT; ++u) {
+            const u32 xa4 = (w[u >> 2] >> (8 * (u & 3))) & 0xffu;              // 4 * x_a
+            part[u] += *reinterpret_cast<const float*>(tabc + (rowoff[u] + xa4) + (PH * S3S_ACH + ai) * S3S_TAB);
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < S3S_BPT; ++u) acc[u] += (double)part[u];
+#pragma unroll
+    for (int ai = 0; ai < S3S_ACH; ++ai) raw[ai] = nraw[ai];
+    __syncthreads();
+}
+
+template <int STG>
+__global__ __launch_bounds__(S3S_THREADS, STG <= 6 ? 3 : 2) void k_s3_score(const char* __restrict__ XT4, long Rp, long R, int N, int Nceil, int S,
+                                                              const float* __restrict__ T, double* __restrict__ out64) {
+    __shared__ float tab[2][S3S_ACH][32][S3S_LD];  // [phase][a][x_b][x_a], zero outside S x S
+    char* tabc = reinterpret_cast<char*>(&tab[0][0][0][0]);
+    const int b = blockIdx.x % N;                 // b fastest: the N blocks of a slice share its XT rows in L2
+    const long slice0 = (long)(blockIdx.x / N) * S3S_SLICE;
+    const long r0 = slice0 + (long)threadIdx.x * S3S_BPT;
+    const char* XTs = XT4 + slice0;               // wave-uniform base of this slice
+    const u32 toff = (u32)((r0 < Rp ? r0 : Rp - 16) - slice0);   // threads past the end gather from valid memory, write nothing
+    const int SS = S * S;
+    const long a_stride = (long)N * SS * 4;       // bytes between T[a][b] and T[a+1][b]
+
+    for (int e = threadIdx.x; e < 2 * S3S_ACH * 32 * S3S_LD; e += S3S_THREADS) (&tab[0][0][0][0])[e] = 0.f;
+    const uint4 xbv = *reinterpret_cast<const uint4*>(XTs + (long)b * Rp + toff);
+    const u32 xbw[4] = {xbv.x, xbv.y, xbv.z, xbv.w};
+    u32 rowoff[S3S_BPT];                            // byte offset of row x_b inside a padded table
+#pragma unroll
+    for (int u = 0; u < S3S_BPT; ++u) rowoff[u] = ((xbw[u >> 2] >> (8 * (u & 3))) & 0xffu) * (u32)S3S_LD;   // (4 x_b) * LD
     double acc[S3S_BPT];
 #pragma unroll
     for (int u = 0; u < S3S_BPT; ++u) acc[u] = 0.0;
 
-    // staging map of this thread, computed once (the integer divisions cost as much as a whole phase of gathers):
-    // element e = tid + k*THREADS of a phase's S3S_ACH*S*S table values -> source offset and padded/transposed LDS slot
-    constexpr int STG = (S3S_ACH * 31 * 31 + S3S_THREADS - 1) / S3S_THREADS;
-    long soff[STG];
-    int doff[STG], sai[STG];
+    // staging map of this thread, computed once: element e = tid + k*THREADS of a phase's ACH*S*S table values ->
+    // source offset in T[.][b] and padded, transposed LDS slot (tab[..][a][x_b = j][x_a = i])
+    S3Stage<STG> sg;
 #pragma unroll
     for (int k = 0; k < STG; ++k) {
         const int e = threadIdx.x + k * S3S_THREADS;
         const int ai = e / SS, ij = e - ai * SS;
         const int i = ij / S, j = ij - i * S;
-        sai[k] = e < S3S_ACH * SS ? ai : -1;
-        soff[k] = (long)ai * N * SS + ij;
-        doff[k] = (ai * 32 + j) * S3S_LD + i;
+        const bool ok = e < S3S_ACH * SS;
+        sg.soff[k] = ok ? (u32)(ai * N * SS + ij) * 4u : 0u;
+        sg.doff[k] = (ok ? (u32)((ai * 32 + j) * S3S_LD + i) : (u32)S3S_DUMMY) * 4u;
     }
-    auto stage = [&](int phase, int a0) {           // tables T[a0 .. a0+ACH) [b] -> tab[phase], transposed + padded
-        const float* src = T + ((long)a0 * N + b) * SS;
-        float* dst = &tab[phase][0][0][0];
-        float v[STG];
-#pragma unroll
-        for (int k = 0; k < STG; ++k) {
-            const int a = a0 + sai[k];
-            v[k] = (sai[k] >= 0 && a < N && a != b) ? src[soff[k]] : 0.f;      // a == b contributes nothing
-        }
-#pragma unroll
-        for (int k = 0; k < STG; ++k)
-            if (sai[k] >= 0) dst[doff[k]] = v[k];
-    };
+    const char* Tb = reinterpret_cast<const char*>(T + (long)b * SS);
     __syncthreads();
-    stage(0, 0);
-    __syncthreads();
-    auto load_phase = [&](int a0, uint4 (&raw)[S3S_ACH]) {
+    {   // phase 0 directly, phase 1 requested
 #pragma unroll
-        for (int ai = 0; ai < S3S_ACH; ++ai)
-            raw[ai] = (a0 + ai < N && r0 < Rp) ? *reinterpret_cast<const uint4*>(XT + (long)(a0 + ai) * Rp + r0) : xbv;
-    };
-    const char* t0 = reinterpret_cast<const char*>(&tab[0][0][0][0]);
-    uint4 raw[S3S_ACH], nraw[S3S_ACH];
-    load_phase(0, raw);
-    int phase = 0;
-    for (int a0 = 0; a0 < N; a0 += S3S_ACH, phase ^= 1) {
-        load_phase(a0 + S3S_ACH, nraw);                                  // next phase's state bytes: in flight during this one
-        if (a0 + S3S_ACH < N) stage(phase ^ 1, a0 + S3S_ACH);          // next tables while this phase is consumed
-        float part[S3S_BPT];
-        u32 rbase[S3S_BPT];                       // LDS byte address of this phase's row x_b of table 0
-        const u32 pbase = (u32)(reinterpret_cast<const char*>(&tab[phase][0][0][0]) - t0);
+        for (int k = 0; k < STG; ++k) sg.v[k] = ldf(Tb, sg.soff[k]);
 #pragma unroll
-        for (int u = 0; u < S3S_BPT; ++u) { part[u] = 0.f; rbase[u] = rowoff[u] + pbase; }
-        const int na = N - a0 < S3S_ACH ? N - a0 : S3S_ACH;
+        for (int k = 0; k < STG; ++k) *reinterpret_cast<float*>(tabc + sg.doff[k]) = sg.v[k];
+        if (S3S_ACH < Nceil) {
+            const char* src = Tb + (long)S3S_ACH * a_stride;
 #pragma unroll
-        for (int ai = 0; ai < S3S_ACH; ++ai) {
-            if (ai >= na) break;                  // wave-uniform
-            const u32 w[4] = {raw[ai].x, raw[ai].y, raw[ai].z, raw[ai].w};
-#pragma unroll
-            for (int u = 0; u < S3S_BPT; ++u) {
-                const u32 xa4 = ((w[u >> 2] >> (8 * (u & 3))) & 0xffu) << 2;
-                // table ai of the phase sits at a compile-time offset: folded into the ds_read immediate
-                part[u] += *reinterpret_cast<const float*>(t0 + (rbase[u] + xa4) + ai * (32 * S3S_LD * 4));
-            }
+            for (int k = 0; k < STG; ++k) sg.v[k] = ldf(src, sg.soff[k]);
         }
+    }
+    uint4 raw[S3S_ACH];
 #pragma unroll
-        for (int u = 0; u < S3S_BPT; ++u) acc[u] += (double)part[u];
-#pragma unroll
-        for (int ai = 0; ai < S3S_ACH; ++ai) raw[ai] = nraw[ai];
-        __syncthreads();
+    for (int ai = 0; ai < S3S_ACH; ++ai) raw[ai] = *reinterpret_cast<const uint4*>(XTs + (long)(ai < N ? ai : N - 1) * Rp + toff);
+    __syncthreads();
+    for (int a0 = 0; a0 < Nceil; a0 += 2 * S3S_ACH) {
+        s3_phase<0, STG>(XTs, Rp, toff, N, Nceil, a0, Tb, a_stride, tabc, sg, rowoff, raw, acc);
+        if (a0 + S3S_ACH < Nceil) s3_phase<1, STG>(XTs, Rp, toff, N, Nceil, a0 + S3S_ACH, Tb, a_stride, tabc, sg, rowoff, raw, acc);
     }
 #pragma unroll
     for (int u = 0; u < S3S_BPT; ++u) {
         const long row = r0 + u;
-        const u32 xb = (xbw[u >> 2] >> (8 * (u & 3))) & 0xffu;
+        const u32 xb = ((xbw[u >> 2] >> (8 * (u & 3))) & 0xffu) >> 2;
         if (row < R && xb < (u32)S) atomicAdd(&out64[row * S + xb], acc[u]);
     }
 }
@@ -240,10 +268,11 @@ static int s3_ta(int S) {
 }
 
 int64_t s3_mfma_ws_bytes(int64_t R, int N);
-int transpose_states(const char* X, int64_t R, int32_t N, int64_t ldx, int32_t S, char* XT, int64_t Rp, hipStream_t st);
+int transpose_states(const char* X, int64_t R, int32_t N, int64_t ldx, int32_t S, char* XT, int64_t Rp, int shift, hipStream_t st);
 int hist_s3_mfma(const char* X, int64_t R, int32_t N, int64_t ldx, int32_t S, int32_t* counts, void* ws, hipStream_t st);
 
-int64_t s3_table_bytes(int N, int S) { return align_up((int64_t)N * N * S * S * 4, 256); }
+static int s3_nceil(int N) { return (N + S3S_ACH - 1) / S3S_ACH * S3S_ACH; }
+int64_t s3_table_bytes(int N, int S) { return align_up((int64_t)s3_nceil(N) * N * S * S * 4, 256); }
 int64_t s3_ws_bytes(int64_t R, int N, int S) {
     // score: table + transposed state matrix + float64 accumulator; expected: transposed state matrix
     return s3_table_bytes(N, S) + s3_mfma_ws_bytes(R, N) + align_up(R * S * 8, 256);
@@ -285,16 +314,22 @@ int score_s3_impl(const int8_t* X8, int64_t R, int32_t N, int64_t ldx, int32_t S
     float* T = reinterpret_cast<float*>(ws);
     char* XT = reinterpret_cast<char*>(ws) + tb;
     double* acc = out64 ? out64 : reinterpret_cast<double*>(reinterpret_cast<char*>(ws) + tb + xtb);
-    const long total = (long)N * N * S * S;
-    hipLaunchKernelGGL(k_s3_table, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, q, N, S, T);
+    const int Nceil = s3_nceil(N);
+    const long total = (long)Nceil * N * S * S;
+    hipLaunchKernelGGL(k_s3_table, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, q, N, Nceil, S, T);
     EPG_LAUNCH_CHECK("k_s3_table");
     const long Rp = align_up(R, 32);
-    int rc = transpose_states(reinterpret_cast<const char*>(X8), R, N, ldx, S, XT, Rp, st);
+    int rc = transpose_states(reinterpret_cast<const char*>(X8), R, N, ldx, S, XT, Rp, 2, st);   // bytes = 4 * state
     if (rc) return rc;
     EPG_HIP(hipMemsetAsync(acc, 0, (size_t)R * S * 8, st));
     const long nslices = (R + S3S_SLICE - 1) / S3S_SLICE;
     if (nslices * N > 0x7fffffffL) return fail(EPG_ERR_UNSUPPORTED, "score_s3: R*N too large for one call");
-    hipLaunchKernelGGL(k_s3_score, dim3((unsigned)(nslices * N)), dim3(S3S_THREADS), 0, st, XT, Rp, (long)R, N, S, T, acc);
+    // staging elements per thread: ceil(ACH * S * S / THREADS)
+    const int stg = (S3S_ACH * S * S + S3S_THREADS - 1) / S3S_THREADS;
+    const dim3 grid((unsigned)(nslices * N)), block(S3S_THREADS);
+    if (stg <= 6) hipLaunchKernelGGL(k_s3_score<6>, grid, block, 0, st, XT, Rp, (long)R, N, Nceil, S, T, acc);
+    else if (stg <= 10) hipLaunchKernelGGL(k_s3_score<10>, grid, block, 0, st, XT, Rp, (long)R, N, Nceil, S, T, acc);
+    else hipLaunchKernelGGL(k_s3_score<16>, grid, block, 0, st, XT, Rp, (long)R, N, Nceil, S, T, acc);
     EPG_LAUNCH_CHECK("k_s3_score");
     if (out32) {
         long blocks = ((long)R * S + 255) / 256;

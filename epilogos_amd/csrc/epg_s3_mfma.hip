@@ -24,7 +24,7 @@ constexpr int MF_T = 3;               // tiles per block side
 constexpr int MF_ROWS = 32 * MF_T;    // (sample, state) rows per block
 
 __global__ __launch_bounds__(256) void k_transpose_states(const char* __restrict__ X, long R, int N, long ldx, int S,
-                                                           char* __restrict__ XT, long Rp) {
+                                                           char* __restrict__ XT, long Rp, int shift) {
     __shared__ unsigned char tile[64][65];
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const long b0 = (long)blockIdx.x * 64;
@@ -38,7 +38,7 @@ __global__ __launch_bounds__(256) void k_transpose_states(const char* __restrict
             v = (unsigned char)X[bin * ldx + smp];
             if (v >= S) v = 31;
         }
-        tile[ty + 4 * i][tx] = v;
+        tile[ty + 4 * i][tx] = (unsigned char)(v << shift);
     }
     __syncthreads();
 #pragma unroll
@@ -165,10 +165,11 @@ __global__ __launch_bounds__(64, 2) void k_s3_hist_mfma(const char* __restrict__
 
 int64_t s3_mfma_ws_bytes(int64_t R, int N) { return align_up((int64_t)N * align_up(R, 32) + 64, 256); }
 
-// XT[sample][bin], bins padded to Rp (a multiple of 32), everything that is not a state in [0, S) stored as 31
-int transpose_states(const char* X, int64_t R, int32_t N, int64_t ldx, int32_t S, char* XT, int64_t Rp, hipStream_t st) {
+// XT[sample][bin], bins padded to Rp (a multiple of 32), everything that is not a state in [0, S) stored as 31;
+// bytes are stored shifted left by `shift` (the S3 score kernel wants 4 * state, a ready-made LDS byte offset)
+int transpose_states(const char* X, int64_t R, int32_t N, int64_t ldx, int32_t S, char* XT, int64_t Rp, int shift, hipStream_t st) {
     hipLaunchKernelGGL(k_transpose_states, dim3((unsigned)((Rp + 63) / 64), (unsigned)((N + 63) / 64)), dim3(256), 0, st, X, (long)R, N,
-                       (long)ldx, S, XT, (long)Rp);
+                       (long)ldx, S, XT, (long)Rp, shift);
     EPG_LAUNCH_CHECK("k_transpose_states");
     return EPG_OK;
 }
@@ -176,7 +177,7 @@ int transpose_states(const char* X, int64_t R, int32_t N, int64_t ldx, int32_t S
 int hist_s3_mfma(const char* X, int64_t R, int32_t N, int64_t ldx, int32_t S, int32_t* counts, void* ws, hipStream_t st) {
     const long Rp = align_up(R, 32);
     char* XT = reinterpret_cast<char*>(ws);
-    int rc = transpose_states(X, R, N, ldx, S, XT, Rp, st);
+    int rc = transpose_states(X, R, N, ldx, S, XT, Rp, 0, st);
     if (rc) return rc;
     const int nblk = (N * S + MF_ROWS - 1) / MF_ROWS;
     const long npairs = (long)nblk * (nblk + 1) / 2;

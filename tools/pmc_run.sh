@@ -16,11 +16,14 @@ groups[tcp2]="TCP_TCC_READ_REQ_LATENCY_sum TCP_TCP_LATENCY_sum TCP_TOTAL_ACCESSE
 groups[ta]="TA_FLAT_READ_WAVEFRONTS_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum TA_TA_BUSY_sum"
 groups[tcc]="TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum"
 groups[tcc2]="TCC_TAG_STALL_sum TCC_EA0_RDREQ_DRAM_CREDIT_STALL_sum TCC_BUSY_avr TCC_EA0_RDREQ_LEVEL_sum"
+groups[lds]="SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL SQ_WAIT_INST_LDS SQ_INST_CYCLES_SALU"
 groups[fetch]="FETCH_SIZE"
 groups[write]="WRITE_SIZE"
 cd /tmp
-for g in "${!groups[@]}"; do
-  timeout 120 rocprofv3 --pmc ${groups[$g]} --kernel-trace --output-format csv -d $out/$g -o p -- python3 $R/tools/kbench.py "$@" > $out/$g.log 2>&1 || echo "pass $g failed"
+# PMC_SCRIPT=tools/kbench_all.py and PMC_GROUPS="sq sq2 lds" select another driver script / a subset of the passes
+script=${PMC_SCRIPT:-tools/kbench.py}
+for g in ${PMC_GROUPS:-${!groups[@]}}; do
+  timeout ${PMC_TIMEOUT:-120} rocprofv3 --pmc ${groups[$g]} --kernel-trace --output-format csv -d $out/$g -o p -- python3 $R/$script "$@" > $out/$g.log 2>&1 || echo "pass $g failed"
 done
 cd $R
 python3 tools/pmc_summary.py $out
