@@ -136,7 +136,10 @@ constexpr int S3S_THREADS = 256;
 constexpr int S3S_BPT = 16;                       // bins per thread
 constexpr int S3S_SLICE = S3S_THREADS * S3S_BPT;  // bins per block
 constexpr int S3S_ACH = 4;                        // biosamples a per staging phase
-constexpr int S3S_LD = 33;                        // floats per table row: odd, so rows of different x_b start on different banks
+// Floats per table row.  Rows are stored in the order 31 - x_b, so the LDS bank of a gather is (x_a - x_b) mod 32.
+// With rows in natural order the bank is x_a + x_b and the pairs (i, j) and (j, i) -- equally likely for every
+// state distribution -- always collide; measured: half of the LDS cycles were bank conflicts.
+constexpr int S3S_LD = 33;
 constexpr int S3S_TAB = 32 * S3S_LD * 4;          // bytes of one padded table
 constexpr int S3S_DUMMY = 31 * S3S_LD + 32;       // a slot no gather reads (column 32)
 
@@ -195,7 +198,7 @@ __device__ __forceinline__ void s3_phase(const char* __restrict__ XTs, long Rp, 
 template <int STG>
 __global__ __launch_bounds__(S3S_THREADS, STG <= 6 ? 3 : 2) void k_s3_score(const char* __restrict__ XT4, long Rp, long R, int N, int Nceil, int S,
                                                               const float* __restrict__ T, double* __restrict__ out64) {
-    __shared__ float tab[2][S3S_ACH][32][S3S_LD];  // [phase][a][x_b][x_a], zero outside S x S
+    __shared__ float tab[2][S3S_ACH][32][S3S_LD];  // [phase][a][31 - x_b][x_a], zero outside S x S
     char* tabc = reinterpret_cast<char*>(&tab[0][0][0][0]);
     const int b = blockIdx.x % N;                 // b fastest: the N blocks of a slice share its XT rows in L2
     const long slice0 = (long)(blockIdx.x / N) * S3S_SLICE;
@@ -210,7 +213,7 @@ __global__ __launch_bounds__(S3S_THREADS, STG <= 6 ? 3 : 2) void k_s3_score(cons
     const u32 xbw[4] = {xbv.x, xbv.y, xbv.z, xbv.w};
     u32 rowoff[S3S_BPT];                            // byte offset of row x_b inside a padded table
 #pragma unroll
-    for (int u = 0; u < S3S_BPT; ++u) rowoff[u] = ((xbw[u >> 2] >> (8 * (u & 3))) & 0xffu) * (u32)S3S_LD;   // (4 x_b) * LD
+    for (int u = 0; u < S3S_BPT; ++u) rowoff[u] = (124u - ((xbw[u >> 2] >> (8 * (u & 3))) & 0xffu)) * (u32)S3S_LD;   // 4 * (31 - x_b) * LD
     double acc[S3S_BPT];
 #pragma unroll
     for (int u = 0; u < S3S_BPT; ++u) acc[u] = 0.0;
@@ -225,7 +228,7 @@ __global__ __launch_bounds__(S3S_THREADS, STG <= 6 ? 3 : 2) void k_s3_score(cons
         const int i = ij / S, j = ij - i * S;
         const bool ok = e < S3S_ACH * SS;
         sg.soff[k] = ok ? (u32)(ai * N * SS + ij) * 4u : 0u;
-        sg.doff[k] = (ok ? (u32)((ai * 32 + j) * S3S_LD + i) : (u32)S3S_DUMMY) * 4u;
+        sg.doff[k] = (ok ? (u32)((ai * 32 + 31 - j) * S3S_LD + i) : (u32)S3S_DUMMY) * 4u;
     }
     const char* Tb = reinterpret_cast<const char*>(T + (long)b * SS);
     __syncthreads();
