@@ -41,6 +41,7 @@ PROTOTYPES = {
     "epg_score_s2_from_binhist": (C.c_int, [_p, _i64, _i32, _i32, _i64, _p, _p, _p, _p, _i64, _p]),
     "epg_score_s3": (C.c_int, [_p, _i64, _i32, _i64, _i32, _p, _p, _p, _p, _i64, _p]),
     "epg_pair_finish": (C.c_int, [_p, _p, _i64, _i32, _p, _p, _p]),
+    "epg_pair_metrics": (C.c_int, [_p, _i64, _i32, _i32, _p, _p, _p]),
     "epg_quiescent": (C.c_int, [_p, _i32, _i64, _p, _i32, _i64, _i64, _i32, _p, _p]),
     "epg_null_hist": (C.c_int, [_p, _i32, _i64, _p, _i32, _i64, _i64, _i32, _i32, _i32, _u64, _i64, _p, _p, _p]),
 }

@@ -76,6 +76,11 @@ class HipBackend:
         d, dist = self.engine.pair_finish(ta, tb)
         return d.cpu().numpy(), dist.cpu().numpy()
 
+    def pair_metrics(self, delta, roundtrip=True):
+        td = self.torch.from_numpy(np.ascontiguousarray(delta, dtype=np.float32)).to(self.device)
+        dist, maxdiff = self.engine.pair_metrics(td, roundtrip)
+        return dist.cpu().numpy(), maxdiff.cpu().numpy()
+
     def quiescent(self, xa, xb, qstate):
         m = self.engine.quiescent(self.to_device(xa), xa.shape[1], self.to_device(xb), xb.shape[1], qstate)
         return m.cpu().numpy().astype(bool)

@@ -38,6 +38,7 @@ int hist_s2_from_binhist_impl(const uint16_t*, int64_t, int32_t, int64_t*, hipSt
 int64_t s2_table_bytes(int, int);
 int score_s2_from_hist_impl(const uint16_t*, int64_t, int32_t, int32_t, int64_t, const float*, double*, float*, void*, int64_t, hipStream_t);
 int pair_finish_impl(const float*, const float*, int64_t, int32_t, float*, float*, hipStream_t);
+int pair_metrics_impl(const float*, int64_t, int32_t, int32_t, float*, int32_t*, hipStream_t);
 int quiescent_impl(const int8_t*, int32_t, int64_t, const int8_t*, int32_t, int64_t, int64_t, int32_t, uint8_t*, hipStream_t);
 int hist_s3_impl(const int8_t*, int64_t, int32_t, int64_t, int32_t, int32_t*, void*, int64_t, hipStream_t);
 int64_t s3_ws_bytes(int64_t, int, int);
@@ -143,6 +144,9 @@ int epg_score_s3(const int8_t* X, int64_t R, int32_t N, int64_t ldx, int32_t S, 
     return score_s3_impl(X, R, N, ldx, S, q, out64, out32, ws, ws_bytes, (hipStream_t)stream);
 }
 
+int epg_pair_metrics(const float* delta, int64_t R, int32_t S, int32_t roundtrip, float* dist, int32_t* maxdiff, void* stream) {
+    return pair_metrics_impl(delta, R, S, roundtrip, dist, maxdiff, (hipStream_t)stream);
+}
 int epg_pair_finish(const float* a, const float* b, int64_t R, int32_t S, float* delta, float* signed_sqdist, void* stream) {
     return pair_finish_impl(a, b, R, S, delta, signed_sqdist, (hipStream_t)stream);
 }

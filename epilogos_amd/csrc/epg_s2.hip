@@ -228,6 +228,38 @@ int score_s2_from_hist_impl(const uint16_t* H, int64_t R, int32_t N, int32_t S, 
     return EPG_OK;
 }
 
+// "%.5f" then strtod then float32: v * 1e5 is exact in double (24-bit x 17-bit significands), rint is half-even on that
+// exact value like the correctly rounded decimal conversion, and k / 1e5 is the correctly rounded quotient, i.e. the
+// double nearest to the decimal k * 10^-5 that the parser produces.
+__device__ __forceinline__ float text_roundtrip_f5(float v) { return (float)(rint((double)v * 1e5) / 1e5); }
+
+__global__ __launch_bounds__(256) void k_pair_metrics(const float* __restrict__ delta, long R, int S, int roundtrip,
+                                                       float* __restrict__ dist, int* __restrict__ maxdiff) {
+    const long row = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= R) return;
+    float sq = 0.f, sd = 0.f, best = -1.f;
+    int arg = S;
+    for (int s = 0; s < S; ++s) {
+        float d = delta[row * S + s];
+        if (roundtrip) d = text_roundtrip_f5(d);
+        sq = __fadd_rn(sq, __fmul_rn(d, d));          // np.square, then a separate add: no fused multiply-add
+        sd = __fadd_rn(sd, d);
+        if (fabsf(d) >= best) { best = fabsf(d); arg = s + 1; }   // >= : ties go to the higher state
+    }
+    const float sg = sd > 0.f ? 1.f : (sd < 0.f ? -1.f : sd);     // np.sign
+    dist[row] = __fmul_rn(sq, sg);
+    maxdiff[row] = arg;
+}
+
+int pair_metrics_impl(const float* delta, int64_t R, int32_t S, int32_t roundtrip, float* dist, int32_t* maxdiff, hipStream_t st) {
+    if (R < 0 || S < 1) return fail(EPG_ERR_INVALID_ARG, "pair_metrics: bad shape");
+    if (R == 0) return EPG_OK;
+    if (!delta || !dist || !maxdiff) return fail(EPG_ERR_INVALID_ARG, "pair_metrics: NULL argument");
+    hipLaunchKernelGGL(k_pair_metrics, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, st, delta, (long)R, S, roundtrip, dist, maxdiff);
+    EPG_LAUNCH_CHECK("k_pair_metrics");
+    return EPG_OK;
+}
+
 int pair_finish_impl(const float* a, const float* b, int64_t R, int32_t S, float* delta, float* dist, hipStream_t st) {
     if (R < 0 || S < 1 || S > 32) return fail(EPG_ERR_INVALID_ARG, "pair_finish: bad shape");
     if (R == 0) return EPG_OK;

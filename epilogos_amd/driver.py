@@ -154,11 +154,14 @@ def run_paired_groups(files1, files2, numStates, saliency, outputDir, fileTag, q
         na, nb = be.null_scores(xa, xb, numStates, saliency, q, groupSize, nullSeed, row0=int(file_start[fi] + lo))
         delta, _ = be.pair_finish(s1, s2)
         _, dist = be.pair_finish(na, nb)
+        real_dist, maxdiff = be.pair_metrics(delta, roundtrip=True)      # what STEP 4 would recompute from the text
         quies = be.quiescent(xa, xb, quiescentState)
         stem = fileStem(files1[fi])
         writeScores(delta, outputDir / ".part_pairwiseDelta_{}_{}_{:012d}.gz".format(fileTag, stem, lo), loc)
         np.save(outputDir / ".part_null_{}_{}_{:012d}.npy".format(fileTag, stem, lo), dist, allow_pickle=False)
         np.save(outputDir / ".part_quies_{}_{}_{:012d}.npy".format(fileTag, stem, lo), quies, allow_pickle=False)
+        np.save(outputDir / ".part_rdist_{}_{}_{:012d}.npy".format(fileTag, stem, lo), real_dist, allow_pickle=False)
+        np.save(outputDir / ".part_mdiff_{}_{}_{:012d}.npy".format(fileTag, stem, lo), maxdiff, allow_pickle=False)
     d.barrier()
     if d.rank == 0:
         for f in files1:
@@ -169,16 +172,23 @@ def run_paired_groups(files1, files2, numStates, saliency, outputDir, fileTag, q
                         shutil.copyfileobj(src, out)
                     os.remove(p)
             parts = {}
-            for kind in ("null", "quies"):
+            for kind in ("null", "quies", "rdist", "mdiff"):
                 arrs = []
                 for p in sorted(outputDir.glob(".part_{}_{}_{}_*.npy".format(kind, fileTag, stem))):
                     arrs.append(np.load(p))
                     os.remove(p)
                 parts[kind] = np.concatenate(arrs) if arrs else np.zeros(0)
-            chrName = readLocations(f, (0, 1))[0, 0]
+            locs = readLocations(f)
+            chrName = locs[0, 0]
             np.savez_compressed(outputDir / "temp_nullDistances_{}_{}.npz".format(fileTag, stem), chrName=np.array([chrName]),
                                 nullDistances=parts["null"])
             np.savez_compressed(outputDir / "temp_quiescence_{}_{}.npz".format(fileTag, stem), chrName=np.array([chrName]),
                                 quiescenceArr=parts["quies"].astype(bool))
+            # side-car for this engine's STEP 4 (roiAndVisualPairwise.readInData): the per-bin reduction the reference
+            # redoes from the pairwiseDelta text, already computed on the GPU; removed with the other temp_*.npz
+            n = len(parts["rdist"])
+            np.savez_compressed(outputDir / "temp_pairMetrics_{}_{}.npz".format(fileTag, stem), chrName=np.array([chrName]),
+                                distances=parts["rdist"].astype(np.float32), maxDiff=parts["mdiff"].astype(np.int32),
+                                starts=locs[:n, 1].astype(np.int64), ends=locs[:n, 2].astype(np.int64))
     d.barrier()
     return q

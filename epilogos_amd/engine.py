@@ -172,6 +172,15 @@ def pair_finish(a, b, want_dist=True):
     return delta, dist
 
 
+def pair_metrics(delta, roundtrip=True):
+    """Signed squared distance float32[R] and 1-based largest-|delta| state int32[R] (roiAndVisualPairwise.py:347-354)."""
+    R, S = delta.shape
+    dist = torch.empty(R, dtype=torch.float32, device=delta.device)
+    maxdiff = torch.empty(R, dtype=torch.int32, device=delta.device)
+    _abi.call("epg_pair_metrics", _ptr(delta), R, S, 1 if roundtrip else 0, _ptr(dist), _ptr(maxdiff), _stream())
+    return dist, maxdiff
+
+
 def quiescent(XA, NA, XB, NB, qstate):
     R, ldxa = _check_states(XA, NA)
     R2, ldxb = _check_states(XB, NB)

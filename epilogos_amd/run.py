@@ -2,9 +2,8 @@
 (click options :18-73, checkFlags :328-375, checkArguments :378-451, fileTag/paths :158-165) for STEP 1-3.
 The per-chromosome SLURM submission (run.py:454-585) is replaced by a bin-range partition across the GPUs of the
 node (one process per GPU under torch.distributed.run; a single process when WORLD_SIZE is unset).  Single mode
-also runs STEP 4 (regionsOfInterest_*.txt, epilogos_amd/roiSingle.py).  The paired STEP 4 (p-values, plots) is outside
-this engine's scope: its inputs (pairwiseDelta_*, temp_nullDistances_*, temp_quiescence_*, exp_freq_*.npy) are written
-exactly as the reference does."""
+also runs STEP 4 (regionsOfInterest_*.txt, epilogos_amd/roiSingle.py); paired mode runs the STEP 4 of
+epilogos_amd/roiAndVisualPairwise.py (pairwiseMetrics, regionsOfInterest, significantLoci; no figures)."""
 import os
 import re
 import sys
@@ -21,8 +20,8 @@ def _natural_key(p):
 
 
 def checkArguments(mode, saliency, inputDirPath, inputDirPath2, outputDirPath, numProcesses, numStates, quiescentState,
-                   groupSize):
-    """Subset of reference run.py:378-451 relevant to STEP 1-3; same exceptions."""
+                   groupSize, numTrials=101, samplingSize=100000, roiWidth=0):
+    """Reference run.py:378-451; same exceptions and messages."""
     if mode == "paired" and saliency == 3:
         raise ValueError("Paired epilogos supports only a saliency of 1 or 2")
     if saliency not in (1, 2, 3):
@@ -43,6 +42,15 @@ def checkArguments(mode, saliency, inputDirPath, inputDirPath2, outputDirPath, n
         raise NotADirectoryError("Given path is not a directory: {}".format(str(outputDirPath)))
     if numProcesses < 0:
         print("ERROR: Number of cores must be positive or zero (0 means use all cores)")
+        sys.exit()
+    if numTrials <= 0:
+        print("ERROR: Number of trials must be greater than zero")
+        sys.exit()
+    if samplingSize <= 0:
+        print("ERROR: Sampling size must be greater than zero")
+        sys.exit()
+    if roiWidth < 0:
+        print("ERROR: Group size value must be greater than 0")
         sys.exit()
     if quiescentState >= numStates:
         print("ERROR: Quiescent state must be a valid state (at most the number of states)")
@@ -65,17 +73,20 @@ def checkArguments(mode, saliency, inputDirPath, inputDirPath2, outputDirPath, n
 @click.option("-s", "--saliency", "saliency", type=int, default=1, show_default=True, help="Saliency level (1, 2, or 3)")
 @click.option("-c", "--num-cores", "numProcesses", type=int, default=1, help="Accepted for compatibility; ignored")
 @click.option("-x", "--exit", "exitBool", is_flag=True, help="SLURM-only flag; accepted and ignored")
-@click.option("-d", "--diagnostic-figures", "diagnosticBool", is_flag=True, help="STEP 4 flag; accepted and ignored")
-@click.option("-t", "--num-trials", "numTrials", type=int, default=101, help="STEP 4 flag; accepted and ignored")
-@click.option("-z", "--sampling-size", "samplingSize", type=int, default=100000, help="STEP 4 flag; accepted and ignored")
+@click.option("-d", "--diagnostic-figures", "diagnosticBool", is_flag=True, help="Figures are not produced; accepted and ignored")
+@click.option("-t", "--num-trials", "numTrials", type=int, default=101, show_default=True,
+              help="Number of gennorm fits of the null distances (paired mode with -n)")
+@click.option("-z", "--sampling-size", "samplingSize", type=int, default=100000, show_default=True,
+              help="Size of the null sub-sample of each fit (paired mode with -n)")
 @click.option("-q", "--quiescent-state", "quiescentState", type=int, default=-1,
               help="1-based quiescent state for paired filtering; 0 disables it [default: last state]")
 @click.option("-g", "--group-size", "groupSize", type=int, default=-1, show_default=True,
               help="Size of the shuffled null groups in paired mode (default: the input group sizes)")
 @click.option("-v", "--version", "version", is_flag=True, help="Print the version and exit")
 @click.option("-p", "--partition", "partition", type=str, help="SLURM-only flag; accepted and ignored")
-@click.option("-n", "--null-distribution", "pvalBool", is_flag=True, help="STEP 4 flag; accepted and ignored")
-@click.option("-w", "--roi-width", "roiWidth", type=int, default=0, help="Bins per region of interest [default: 50 in single mode]")
+@click.option("-n", "--null-distribution", "pvalBool", is_flag=True,
+              help="Paired mode: fit the null distances and report p-values instead of z-scores")
+@click.option("-w", "--roi-width", "roiWidth", type=int, default=0, help="Bins per region of interest [default: 50 single, 125 paired]")
 @click.option("-f", "--file-tag", "fileTag", type=str, default="null",
               help="Tag appended to output filenames [default: input-directory_saliency]")
 @click.option("--exp-freq-mem", "expFreqMem", type=int, default=20000, help="SLURM-only; ignored")
@@ -116,7 +127,7 @@ def main(mode, commandLineBool, inputDirectory, inputDirectory1, inputDirectory2
     if not PurePath(outputDirPath).is_absolute():
         outputDirPath = Path.cwd() / outputDirPath
     checkArguments(mode, saliency, inputDirPath, inputDirPath2, outputDirPath, numProcesses, numStates, quiescentState,
-                   groupSize)
+                   groupSize, numTrials, samplingSize, roiWidth)
     if fileTag == "null":
         fileTag = ("{}_s{}".format(inputDirPath.name, saliency) if mode == "single"
                    else "{}_{}_s{}".format(inputDirPath.name, inputDirPath2.name, saliency))
@@ -171,9 +182,11 @@ def main(mode, commandLineBool, inputDirectory, inputDirectory1, inputDirectory2
         say("\nSTEP 1-3: background counts over [A|B] -> all-reduce -> scores, null groups, deltas (%d GPU(s))" % world)
         run_paired_groups(files, files2, numStates, saliency, outputDirPath, fileTag, quiescentState, groupSize, nullSeed,
                           verbose=False, device=device)
-    if mode == "paired":
-        say("\nSTEP 4 of paired mode (p-values / regions of interest / figures) is not part of this engine; its inputs are in",
-            outputDirPath)
+        if rank == 0:
+            say("\nSTEP 4: Generating p-values & regions of interest (figures are not produced)", flush=True)
+            from .roiAndVisualPairwise import main as roiPairwise
+            roiPairwise(inputDirPath.name, inputDirPath2.name, stateInfo, outputDirPath, fileTag, max(numProcesses, 1), pvalBool,
+                        diagnosticBool, numTrials, samplingSize, storedExpPath, roiWidth if roiWidth else 125, False)
     if world > 1:
         import torch.distributed as dist
         dist.destroy_process_group()

@@ -105,6 +105,15 @@ int epg_score_s3(const int8_t* X, int64_t R, int32_t N, int64_t ldx, int32_t S, 
  * (signed_sqdist may be NULL). */
 int epg_pair_finish(const float* a, const float* b, int64_t R, int32_t S, float* delta, float* signed_sqdist,
                     void* stream);
+/* Per-bin inputs of the paired STEP 4 -- roiAndVisualPairwise.py:347-354 (readInData):
+ *   dist[b]    = sum_s d^2 * sign(sum_s d), float32, states added in ascending order (the reference reduces a
+ *                column-major frame, so numpy adds column after column);
+ *   maxdiff[b] = 1-based state with the largest |d|, ties to the higher state.
+ * d is delta[b, :] as the reference sees it: re-read from the "%.5f" text of pairwiseDelta_*.txt.gz.  roundtrip != 0
+ * applies that text round trip (float32 -> 5 decimals, half-even on the exact value -> nearest float32) to the
+ * float32 delta of epg_pair_finish; roundtrip == 0 takes delta as already parsed from the file. */
+int epg_pair_metrics(const float* delta, int64_t R, int32_t S, int32_t roundtrip, float* dist, int32_t* maxdiff,
+                     void* stream);
 /* mask[b] = all(XA[b,:]==qstate) && all(XB[b,:]==qstate)                          -- scores.py:294-303 */
 int epg_quiescent(const int8_t* XA, int32_t NA, int64_t ldxa, const int8_t* XB, int32_t NB, int64_t ldxb,
                   int64_t R, int32_t qstate, uint8_t* mask, void* stream);

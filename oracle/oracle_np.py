@@ -18,7 +18,7 @@ import numpy as np
 
 __all__ = [
     "split_rows", "bin_hist", "expected_s1", "expected_s2", "expected_s3", "normalise", "kl",
-    "score_s1", "score_s2", "score_s3_f32_sequential", "score_s3_f64", "s3_table", "pair_finish",
+    "score_s1", "score_s2", "score_s3_f32_sequential", "score_s3_f64", "s3_table", "pair_finish", "pair_metrics", "text_roundtrip_f5",
     "quiescent_mask", "format_scores", "shuffle_rows",
 ]
 
@@ -165,6 +165,31 @@ def pair_finish(score_a, score_b):
     d = a - b
     dist = np.sum(np.square(d), axis=1) * np.sign(np.sum(d, axis=1))
     return d, dist
+
+
+def text_roundtrip_f5(v):
+    """float32 -> '{:.5f}' (scores.py:530-531) -> pandas read_table -> float32 (roiAndVisualPairwise.py:340), restated
+    arithmetically: v * 1e5 is exact in float64, rint is half-even like the decimal formatter, k / 1e5 is the
+    correctly rounded double of the decimal string."""
+    v = np.asarray(v, dtype=np.float32)
+    return (np.rint(v.astype(np.float64) * 1e5) / 1e5).astype(np.float32)
+
+
+def pair_metrics(delta, roundtrip=True):
+    """roiAndVisualPairwise.py:347-354 -- signed squared euclidean distance and the 1-based state of the largest
+    |difference| (ties to the higher state) of every bin.  The reference sums a column-major float32 frame over
+    axis 1, which numpy does column after column: plain ascending-state float32 adds, no pairwise blocking."""
+    d = np.asarray(delta, dtype=np.float32)
+    if roundtrip:
+        d = text_roundtrip_f5(d)
+    sq = np.zeros(d.shape[0], dtype=np.float32)
+    sd = np.zeros(d.shape[0], dtype=np.float32)
+    for s in range(d.shape[1]):
+        sq = sq + d[:, s] * d[:, s]
+        sd = sd + d[:, s]
+    dist = sq * np.sign(sd)
+    maxdiff = np.abs(np.argmax(np.abs(np.flip(d, axis=1)), axis=1) - d.shape[1]).astype(np.int32)
+    return dist, maxdiff
 
 
 def quiescent_mask(xa, xb, qstate):

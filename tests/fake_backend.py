@@ -29,6 +29,9 @@ class OracleBackend:
     def pair_finish(self, a, b):
         return onp.pair_finish(a, b)
 
+    def pair_metrics(self, delta, roundtrip=True):
+        return onp.pair_metrics(delta, roundtrip)
+
     def quiescent(self, xa, xb, qstate):
         return onp.quiescent_mask(xa, xb, qstate)
 

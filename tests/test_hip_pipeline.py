@@ -71,34 +71,55 @@ def test_stage_drivers_hip(tmp_path, golden_real, sal):
 
 
 def test_cli_paired_s1(tmp_path, golden_pair):
-    """`epilogos -m paired` through the partitioned driver with the HIP backend (one rank)."""
+    """`epilogos -m paired` with the HIP backend (one rank): STEP 1-3 files through the partitioned driver, then the CLI
+    end to end including STEP 4."""
     from click.testing import CliRunner
+    from epilogos_amd import driver
     from epilogos_amd.run import main
+    from oracle import oracle_np as onp
     from tests.conftest import load_golden
     g = golden_pair
     a, b, out = tmp_path / "male", tmp_path / "female", tmp_path / "out"
-    a.mkdir(); b.mkdir()
+    a.mkdir(); b.mkdir(); out.mkdir()
     write_tsv(a / "matrix_chr1.txt.gz", g["xa"]); write_tsv(b / "matrix_chr1.txt.gz", g["xb"])
     meta = tmp_path / "metadata.tsv"
     names = load_golden("roi.npz")["state_names"]
     meta.write_text("zero_index\tone_index\tshort_name\n" + "".join("%d\t%d\t%s\n" % (i, i + 1, names[i]) for i in range(S)))
-    args = ["-l", "-m", "paired", "-a", str(a), "-b", str(b), "-j", str(meta), "-o", str(out), "--null-seed", "5"]
-    res = CliRunner().invoke(main, args)
-    assert res.exit_code == 0, res.output
     tag = "male_female_s1"                                           # reference run.py:161-162
+    fa, fb = [a / "matrix_chr1.txt.gz"], [b / "matrix_chr1.txt.gz"]
+    driver.run_paired_groups(fa, fb, S, 1, out, tag, S - 1, -1, 5)
     assert np.array_equal(np.load(out / ("exp_freq_%s.npy" % tag)), g["s1_exp"])
     with gzip.open(out / ("pairwiseDelta_%s_matrix_chr1.txt.gz" % tag), "rb") as fh:
         delta = _text_to_array(fh.read())
     np.testing.assert_allclose(delta, g["s1_delta"], atol=1.01e-5)
     assert np.array_equal(np.load(out / ("temp_quiescence_%s_matrix_chr1.npz" % tag))["quiescenceArr"], g["s1_quiescent"])
     nd1 = np.load(out / ("temp_nullDistances_%s_matrix_chr1.npz" % tag))["nullDistances"]
-    # same seed -> same null draws; -q 0 switches the quiescence filter off (run.py:113)
+    # the side-car of STEP 4 is exactly what the reference would recompute from the text it can read
+    side = np.load(out / ("temp_pairMetrics_%s_matrix_chr1.npz" % tag))
+    rd, rm = onp.pair_metrics(delta, roundtrip=False)
+    assert np.array_equal(side["distances"], rd) and np.array_equal(side["maxDiff"], rm)
+    assert np.array_equal(side["starts"], 200 * np.arange(len(rd))) and side["chrName"][0] == "chr1"
+    # same seed -> same null draws; quiescent state -1 switches the filter off
     out2 = tmp_path / "out2"
-    res = CliRunner().invoke(main, args[:-4] + ["-o", str(out2), "--null-seed", "5", "-q", "0"])
-    assert res.exit_code == 0, res.output
-    nd2 = np.load(out2 / ("temp_nullDistances_%s_matrix_chr1.npz" % tag))["nullDistances"]
-    assert np.array_equal(nd1, nd2)
+    out2.mkdir()
+    driver.run_paired_groups(fa, fb, S, 1, out2, tag, -1, -1, 5)
+    assert np.array_equal(nd1, np.load(out2 / ("temp_nullDistances_%s_matrix_chr1.npz" % tag))["nullDistances"])
     assert not np.load(out2 / ("temp_quiescence_%s_matrix_chr1.npz" % tag))["quiescenceArr"].any()
+
+    for flags in ([], ["-n", "-t", "3", "-w", "10"]):
+        out3 = tmp_path / ("cli%d" % len(flags))
+        res = CliRunner().invoke(main, ["-l", "-m", "paired", "-a", str(a), "-b", str(b), "-j", str(meta), "-o", str(out3),
+                                        "--null-seed", "5"] + flags)
+        assert res.exit_code == 0, res.output
+        assert not list(out3.glob("temp_*.npz")) and not (out3 / ("exp_freq_%s.npy" % tag)).exists()
+        with gzip.open(out3 / ("pairwiseMetrics_%s.txt.gz" % tag), "rt") as fh:
+            rows = [l.split("\t") for l in fh.read().splitlines()]
+        assert len(rows) == len(rd) and len(rows[0]) == (8 if flags else 6)
+        got = np.array([float(r[4]) * (1 if r[5] == "+" else -1) for r in rows])
+        np.testing.assert_allclose(got, rd, atol=1.01e-5)
+        assert [r[3] for r in rows] == [names[m - 1] for m in rm]
+        assert (out3 / ("regionsOfInterest_%s.txt" % tag)).exists()
+        assert (out3 / ("significantLoci_%s.txt.gz" % tag)).exists() == bool(flags)
 
 
 def test_two_ranks_on_one_gpu_match_one_rank(tmp_path, golden_real):

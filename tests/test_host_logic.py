@@ -256,6 +256,41 @@ def test_cli_single_mode(tmp_path, golden_real, fake_backend, state_info):
     assert res.exit_code == 0 and "ERROR" in res.output                                     # -i with paired mode
 
 
+def test_cli_paired_mode_to_step4(tmp_path, golden_pair, fake_backend, state_info):
+    """`epilogos -m paired` end to end: STEP 1-3 through the partitioned driver, then STEP 4.  With the reference's
+    arithmetic behind the backend the final files are the reference's own, byte for byte (z-score branch and, with -n,
+    the p-value branch; vectors of tests/golden/make_golden_pairwise.py)."""
+    from click.testing import CliRunner
+    from epilogos_amd.run import main
+    from tests.conftest import load_golden
+    g, g4 = golden_pair, load_golden("pairwise_step4.npz")
+    a, b = tmp_path / "male", tmp_path / "female"
+    a.mkdir(); b.mkdir()
+    start0 = int(g4["start0"])
+    for name, (lo, hi) in zip(g4["split_names"], g4["split_bounds"]):
+        for d, x in ((a, g["xa"]), (b, g["xb"])):
+            write_tsv(d / "matrix_{}.txt.gz".format(name), x[lo:hi], chrom=str(name), start0=start0 + 200 * int(lo))
+    tag = "male_female_s1"                                           # reference run.py:161-162
+    for flags, kind in (([], "z"), (["-n", "-t", "3"], "p")):
+        out = tmp_path / ("out_" + kind)
+        res = CliRunner().invoke(main, ["-l", "-m", "paired", "-a", str(a), "-b", str(b), "-j", str(state_info), "-o", str(out),
+                                        "--null-seed", "5"] + flags)
+        assert res.exit_code == 0, res.output
+        assert _decompressed(out / "pairwiseDelta_{}_matrix_chr10.txt.gz".format(tag)).count(b"\n") == 600
+        assert not list(out.glob("temp_*.npz")) and not (out / "exp_freq_{}.npy".format(tag)).exists()
+        if kind == "z":                                              # deterministic: no null distances involved
+            assert _decompressed(out / "pairwiseMetrics_{}.txt.gz".format(tag)) == g4["real_metrics_z"].tobytes()
+            assert (out / "regionsOfInterest_{}.txt".format(tag)).read_bytes() == g4["real_roi_z_w125"].tobytes()
+        else:                                                        # the null shuffle differs from the reference's draw
+            lines = _decompressed(out / "pairwiseMetrics_{}.txt.gz".format(tag)).split(b"\n")[:-1]
+            ref = g4["real_metrics_z"].tobytes().split(b"\n")[:-1]
+            assert len(lines) == 2048 and all(l.count(b"\t") == 7 and l.startswith(r) for l, r in zip(lines, ref))
+            assert (out / "significantLoci_{}.txt.gz".format(tag)).exists() and (out / "regionsOfInterest_{}.txt".format(tag)).exists()
+    r = CliRunner().invoke(main, ["-l", "-m", "paired", "-a", str(a), "-b", str(b), "-j", str(state_info), "-o", str(tmp_path / "o3"),
+                                  "-t", "0"])
+    assert "Number of trials" in r.output
+
+
 def test_cli_argument_errors(tmp_path, state_info, fake_backend):
     """Error behaviour of the reference's checkFlags / checkArguments (run.py:328-451) for the STEP 1-3 flags."""
     from click.testing import CliRunner
