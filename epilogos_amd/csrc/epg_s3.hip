@@ -9,13 +9,12 @@
 //   (R*N*(N-1) increments), see DESIGN.md.
 //
 // Score pass (reference scores.py:455-506 s3Score):
-//   T[a,b,i,j] = kl(float32(1)/P, q[a,b,i,j]) in float32 (scores.py:479-480), stored transposed as
-//   T2[b][j][a][i] so that the N*S values needed for one (b, j) are contiguous;
+//   T[a,b,i,j] = kl(float32(1)/P, q[a,b,i,j]) in float32 (scores.py:479-480), kept in q's layout, with a zero
+//   diagonal a == b and zero rows up to a multiple of S3S_ACH biosamples;
 //   score[bin, s] = sum_{b: x_b == s} sum_{a != b} T[a, b, x_a, s]   (closed form of scores.py:496-498).
-//   k_s3_score: a block owns one b and a slice of bins; for every state s present in the slice's column b it
-//   stages the tile T2[b][s][:][:] (N*S floats, <= 150 KB) in LDS and, for each bin with x_b == s, a wave
-//   gathers tile[a][x_a] over all a (coalesced row read, LDS gather), reduces in float64 and adds the result to
-//   the float64 score.  The diagonal a == b contributes 0 because q[a,a,:,:] == 0 (kl masks q == 0).
+//   k_s3_score: a block owns one b and a slice of bins of the transposed matrix; it streams over a in phases of
+//   S3S_ACH, staging the tables T[a][b] into LDS as padded tiles, and every thread gathers tab[a][x_b][x_a] for its
+//   16 bins; float32 partial sums of one phase are folded into float64 accumulators.  See DESIGN.md.
 #include "epg_common.h"
 
 #include <stdlib.h>
