@@ -15,6 +15,8 @@
 //    C[b,a,j,i].  The diagonal a == b is skipped (it stays 0 like the reference's).  int32 accumulation: exact.
 #include "epg_common.h"
 
+#include <stdlib.h>
+
 namespace epg {
 
 typedef int v4i __attribute__((ext_vector_type(4)));
@@ -163,6 +165,211 @@ __global__ __launch_bounds__(64, 2) void k_s3_hist_mfma(const char* __restrict__
             }
 }
 
+// Variant B: no operand double-buffering inside a wave (the other wave of the SIMD fills the matrix pipe while this one
+// builds its operands); the registers that frees hold a two-deep ring of raw loads, so a load has two whole steps to land.
+template <int PRIO>
+__global__ __launch_bounds__(64, 2) void k_s3_hist_mfma_b(const char* __restrict__ XT, long Rp, long ksplit_len, int N, int S,
+                                                          int nblk, int* __restrict__ counts) {
+    const int lane = threadIdx.x;
+    const int NS = N * S;
+    int p = blockIdx.x, bm = 0;
+    while (p >= nblk - bm) { p -= nblk - bm; ++bm; }
+    const int bn = bm + p;
+    const long kbeg = (long)blockIdx.y * ksplit_len;
+    const long kend = kbeg + ksplit_len < Rp ? kbeg + ksplit_len : Rp;
+
+    const char* pA[MF_T];
+    const char* pB[MF_T];
+    u32 patA[MF_T], patB[MF_T];
+#pragma unroll
+    for (int t = 0; t < MF_T; ++t) {
+        const int m = (bm * MF_T + t) * 32 + (lane & 31);
+        const int n = (bn * MF_T + t) * 32 + (lane & 31);
+        const int am = m < NS ? m / S : 0, im = m < NS ? m % S : 30;
+        const int an = n < NS ? n / S : 0, in_ = n < NS ? n % S : 30;
+        pA[t] = XT + (long)am * Rp + 16 * (lane >> 5) + kbeg;
+        pB[t] = XT + (long)an * Rp + 16 * (lane >> 5) + kbeg;
+        patA[t] = (u32)im * 0x01010101u;
+        patB[t] = (u32)in_ * 0x01010101u;
+    }
+    v16i acc[MF_T][MF_T];
+#pragma unroll
+    for (int a = 0; a < MF_T; ++a)
+#pragma unroll
+        for (int b = 0; b < MF_T; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0;
+
+    const long nsteps = (kend - kbeg) / 32;       // kbeg, kend are multiples of 32
+    uint4 ra[2][MF_T], rb[2][MF_T];
+#pragma unroll
+    for (int d = 0; d < 2; ++d) {
+        const long off = d < nsteps ? 32L * d : 0;
+#pragma unroll
+        for (int t = 0; t < MF_T; ++t) {
+            ra[d][t] = *reinterpret_cast<const uint4*>(pA[t] + off);
+            rb[d][t] = *reinterpret_cast<const uint4*>(pB[t] + off);
+        }
+    }
+    auto step = [&](const int d, long k) {         // consume ring slot d (step k), refill it with step k + 2
+        v4i fa[MF_T], fb[MF_T];
+#pragma unroll
+        for (int t = 0; t < MF_T; ++t) {
+            fa[t] = onehot16(ra[d][t], patA[t]);
+            fb[t] = onehot16(rb[d][t], patB[t]);
+        }
+        const long off = k + 2 < nsteps ? 32 * (k + 2) : 0;
+#pragma unroll
+        for (int t = 0; t < MF_T; ++t) {
+            ra[d][t] = *reinterpret_cast<const uint4*>(pA[t] + off);
+            rb[d][t] = *reinterpret_cast<const uint4*>(pB[t] + off);
+        }
+        if (PRIO) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int a = 0; a < MF_T; ++a)
+#pragma unroll
+            for (int b = 0; b < MF_T; ++b) acc[a][b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[a], fb[b], acc[a][b], 0, 0, 0);
+        if (PRIO) __builtin_amdgcn_s_setprio(0);
+    };
+    long k = 0;
+    for (; k + 1 < nsteps; k += 2) {
+        step(0, k);
+        step(1, k + 1);
+    }
+    if (k < nsteps) step(0, k);
+
+    const long SS = (long)S * S;
+#pragma unroll
+    for (int ta = 0; ta < MF_T; ++ta)
+#pragma unroll
+        for (int tb = 0; tb < MF_T; ++tb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int v = acc[ta][tb][r];
+                if (!v) continue;
+                const int m = (bm * MF_T + ta) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const int n = (bn * MF_T + tb) * 32 + (lane & 31);
+                if (m >= NS || n >= NS) continue;
+                const int a = m / S, i = m - a * S, b = n / S, j = n - b * S;
+                if (a == b) continue;
+                atomicAdd(&counts[((long)a * N + b) * SS + i * S + j], v);
+                if (bm != bn) atomicAdd(&counts[((long)b * N + a) * SS + j * S + i], v);
+            }
+}
+
+// Variant C: the wave's operand bytes go through LDS.  The 96 rows of a block belong to at most 7 biosamples and the 18
+// state rows of a biosample all need the same 16 bytes, so loading per lane moves every byte ~14 times through the
+// 64 B/clk L1 path, which is what bounded variants A/B (PMC: neither the matrix pipe nor the VALU above 40 %).  Here one
+// global_load_dwordx4 per side fetches the distinct bytes of four k-steps (8 biosamples x 128 bins), one ds_write_b128
+// parks them in LDS and the lanes pick their 16 bytes with broadcast ds_read_b128 (256 B/clk).  One wave per
+// workgroup: no barriers, LDS operations of a wave execute in order.
+constexpr int MC_SMP = 8;                 // biosample slots per side (96 rows span at most 7 biosamples of >= 15 states)
+constexpr int MC_CH = 8;                  // 16-byte chunks per macro-step (128 bins = 4 k-steps)
+constexpr int MC_LD = MC_CH + 1;          // chunk stride in uint4: 144 B between biosamples keeps the b128 groups on distinct banks
+
+template <int PRIO>
+__global__ __launch_bounds__(64, 2) void k_s3_hist_mfma_c(const char* __restrict__ XT, long Rp, long ksplit_len, int N, int S,
+                                                          int nblk, int* __restrict__ counts) {
+    __shared__ uint4 lds[2][2][MC_SMP][MC_LD];
+    const int lane = threadIdx.x;
+    const int NS = N * S;
+    int p = blockIdx.x, bm = 0;
+    while (p >= nblk - bm) { p -= nblk - bm; ++bm; }
+    const int bn = bm + p;
+    const long kbeg = (long)blockIdx.y * ksplit_len;
+    const long kend = kbeg + ksplit_len < Rp ? kbeg + ksplit_len : Rp;
+    const long nsteps = (kend - kbeg) / 32;
+
+    // first biosample of each side's block; a lane's rows address slots relative to it
+    const int sA0 = (bm * MF_ROWS) / S, sB0 = (bn * MF_ROWS) / S;
+    u32 rdA[MF_T], rdB[MF_T], patA[MF_T], patB[MF_T];           // LDS byte offsets of this lane's rows inside a buffer
+#pragma unroll
+    for (int t = 0; t < MF_T; ++t) {
+        const int m = (bm * MF_T + t) * 32 + (lane & 31);
+        const int n = (bn * MF_T + t) * 32 + (lane & 31);
+        const int am = m < NS ? m / S : N - 1, im = m < NS ? m % S : 30;      // rows past N*S match nothing (S <= 30)
+        const int an = n < NS ? n / S : N - 1, in_ = n < NS ? n % S : 30;
+        int la = am - sA0, lb = an - sB0;
+        la = la < MC_SMP ? la : MC_SMP - 1;                                    // only rows past N*S can exceed the slots
+        lb = lb < MC_SMP ? lb : MC_SMP - 1;
+        rdA[t] = (u32)(((0 * MC_SMP + la) * MC_LD + (lane >> 5)) * 16);
+        rdB[t] = (u32)(((1 * MC_SMP + lb) * MC_LD + (lane >> 5)) * 16);
+        patA[t] = (u32)im * 0x01010101u;
+        patB[t] = (u32)in_ * 0x01010101u;
+    }
+    // staging role of this lane: biosample slot lane >> 3, chunk lane & 7
+    const int slot = lane >> 3, chunk = lane & 7;
+    const int gsa = sA0 + slot < N ? sA0 + slot : N - 1, gsb = sB0 + slot < N ? sB0 + slot : N - 1;
+    const char* gA = XT + (long)gsa * Rp;
+    const char* gB = XT + (long)gsb * Rp;
+    const u32 wrA = (u32)(((0 * MC_SMP + slot) * MC_LD + chunk) * 16), wrB = (u32)(((1 * MC_SMP + slot) * MC_LD + chunk) * 16);
+    char* ldsc = reinterpret_cast<char*>(&lds[0][0][0][0]);
+    constexpr u32 BUF = 2 * MC_SMP * MC_LD * 16;
+    auto gload = [&](long M, uint4& va, uint4& vb) {             // macro-step M: bins kbeg + 128 M + 16 chunk ..
+        long off = kbeg + 128 * M + 16 * chunk;
+        off = off < Rp - 16 ? off : Rp - 16;                     // tail chunks past the slice are never consumed
+        va = *reinterpret_cast<const uint4*>(gA + off);
+        vb = *reinterpret_cast<const uint4*>(gB + off);
+    };
+
+    v16i acc[MF_T][MF_T];
+#pragma unroll
+    for (int a = 0; a < MF_T; ++a)
+#pragma unroll
+        for (int b = 0; b < MF_T; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0;
+
+    uint4 va, vb;
+    gload(0, va, vb);
+    *reinterpret_cast<uint4*>(ldsc + wrA) = va;
+    *reinterpret_cast<uint4*>(ldsc + wrB) = vb;
+    gload(1, va, vb);
+    const long nmacro = (nsteps + 3) / 4;
+    for (long M = 0; M < nmacro; ++M) {
+        const u32 cur = (u32)(M & 1) * BUF, nxt = BUF - cur;
+        // data of macro-step M + 1 (requested one macro-step ago) into the other buffer, then request M + 2
+        *reinterpret_cast<uint4*>(ldsc + nxt + wrA) = va;
+        *reinterpret_cast<uint4*>(ldsc + nxt + wrB) = vb;
+        gload(M + 2, va, vb);
+        const int ns = nsteps - 4 * M < 4 ? (int)(nsteps - 4 * M) : 4;
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+            if (s4 >= ns) break;                                 // wave-uniform
+            v4i fa[MF_T], fb[MF_T];
+#pragma unroll
+            for (int t = 0; t < MF_T; ++t) {
+                fa[t] = onehot16(*reinterpret_cast<const uint4*>(ldsc + cur + rdA[t] + 32 * s4), patA[t]);
+                fb[t] = onehot16(*reinterpret_cast<const uint4*>(ldsc + cur + rdB[t] + 32 * s4), patB[t]);
+            }
+            if (PRIO) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int a = 0; a < MF_T; ++a)
+#pragma unroll
+                for (int b = 0; b < MF_T; ++b) acc[a][b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[a], fb[b], acc[a][b], 0, 0, 0);
+            if (PRIO) __builtin_amdgcn_s_setprio(0);
+        }
+    }
+
+    const long SS = (long)S * S;
+#pragma unroll
+    for (int ta = 0; ta < MF_T; ++ta)
+#pragma unroll
+        for (int tb = 0; tb < MF_T; ++tb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int v = acc[ta][tb][r];
+                if (!v) continue;
+                const int m = (bm * MF_T + ta) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const int n = (bn * MF_T + tb) * 32 + (lane & 31);
+                if (m >= NS || n >= NS) continue;
+                const int a = m / S, i = m - a * S, b = n / S, j = n - b * S;
+                if (a == b) continue;
+                atomicAdd(&counts[((long)a * N + b) * SS + i * S + j], v);
+                if (bm != bn) atomicAdd(&counts[((long)b * N + a) * SS + j * S + i], v);
+            }
+}
+
 int64_t s3_mfma_ws_bytes(int64_t R, int N) { return align_up((int64_t)N * align_up(R, 32) + 64, 256); }
 
 // XT[sample][bin], bins padded to Rp (a multiple of 32), everything that is not a state in [0, S) stored as 31;
@@ -190,6 +397,11 @@ int hist_s3_mfma(const char* X, int64_t R, int32_t N, int64_t ldx, int32_t S, in
     if (splits > 65535) splits = 65535;
     const long ksplit_len = ((ksteps + splits - 1) / splits) * 32;
     const long nsplit = (Rp + ksplit_len - 1) / ksplit_len;
+    static const int variant = [] { const char* e = getenv("EPG_S3_MFMA"); return e ? atoi(e) : 0; }();
+    if (variant == 3 && S >= 14) hipLaunchKernelGGL(k_s3_hist_mfma_c<1>, dim3((unsigned)npairs, (unsigned)nsplit), dim3(64), 0, st, XT, Rp, ksplit_len, N, S, nblk, counts);
+    else if (variant == 2) hipLaunchKernelGGL(k_s3_hist_mfma_b<1>, dim3((unsigned)npairs, (unsigned)nsplit), dim3(64), 0, st, XT, Rp, ksplit_len, N, S, nblk, counts);
+    else if (variant == 1) hipLaunchKernelGGL(k_s3_hist_mfma_b<0>, dim3((unsigned)npairs, (unsigned)nsplit), dim3(64), 0, st, XT, Rp, ksplit_len, N, S, nblk, counts);
+    else
     hipLaunchKernelGGL(k_s3_hist_mfma, dim3((unsigned)npairs, (unsigned)nsplit), dim3(64), 0, st, XT, Rp, ksplit_len, N, S, nblk, counts);
     EPG_LAUNCH_CHECK("k_s3_hist_mfma");
     return EPG_OK;
