@@ -7,10 +7,12 @@
 //
 //  * k_transpose_states writes XT[sample][bin] (bins padded to a multiple of 32 with 31, states outside [0,S) turned
 //    into 31) so that a lane's MFMA operand -- 16 consecutive bins of ONE (sample, state) row -- is one 16-byte load.
-//  * k_s3_hist_mfma: one wave per pair of 96-row blocks (3x3 tiles of 32x32, 144 accumulator registers).  The one-hot
-//    operand is never materialised in memory: lane l of tile t owns row m = 32t + (l & 31) = (sample, state) and
-//    turns its 16 state bytes into 0/1 bytes with a SWAR equality test against its own state (6 VALU per dword).
+//  * k_s3_hist_mfma_c / _b: one wave per pair of 96-row blocks (3x3 tiles of 32x32, 144 accumulator registers).  The
+//    one-hot operand is never materialised in memory: lane l of tile t owns row m = 32t + (l & 31) = (sample, state)
+//    and turns its 16 state bytes into 0/1 bytes with a SWAR equality test against its own state (4 VALU per dword).
 //    A and B operands come from the same routine, so both see bins in the same byte order and the K sum pairs them.
+//    Measured alternatives (ms per 1 M bins at N = 833): operands of step k+1 built under the MFMAs of step k with a
+//    sched_group_barrier interleave, per-lane loads 138, through LDS 103-112; plain order through LDS (variant C) 93.
 //  * symmetry: only block pairs bm <= bn are computed; off-diagonal blocks also write the mirrored cells
 //    C[b,a,j,i].  The diagonal a == b is skipped (it stays 0 like the reference's).  int32 accumulation: exact.
 #include "epg_common.h"
@@ -67,107 +69,10 @@ __device__ __forceinline__ v4i onehot16(const uint4 raw, u32 pat) {
     return r;
 }
 
-__global__ __launch_bounds__(64, 2) void k_s3_hist_mfma(const char* __restrict__ XT, long Rp, long ksplit_len, int N, int S,
-                                                      int nblk, int* __restrict__ counts) {
-    const int lane = threadIdx.x;
-    const int NS = N * S;
-    // block pair (bm <= bn) from the linear index over the upper triangle
-    int p = blockIdx.x, bm = 0;
-    while (p >= nblk - bm) { p -= nblk - bm; ++bm; }
-    const int bn = bm + p;
-    const long kbeg = (long)blockIdx.y * ksplit_len;
-    const long kend = kbeg + ksplit_len < Rp ? kbeg + ksplit_len : Rp;
-
-    long offA[MF_T], offB[MF_T];
-    u32 patA[MF_T], patB[MF_T];
-#pragma unroll
-    for (int t = 0; t < MF_T; ++t) {
-        const int m = (bm * MF_T + t) * 32 + (lane & 31);
-        const int n = (bn * MF_T + t) * 32 + (lane & 31);
-        const int am = m < NS ? m / S : 0, im = m < NS ? m % S : 30;      // rows past N*S match nothing (S <= 30)
-        const int an = n < NS ? n / S : 0, in_ = n < NS ? n % S : 30;
-        offA[t] = (long)am * Rp + 16 * (lane >> 5);
-        offB[t] = (long)an * Rp + 16 * (lane >> 5);
-        patA[t] = (u32)im * 0x01010101u;
-        patB[t] = (u32)in_ * 0x01010101u;
-    }
-    v16i acc[MF_T][MF_T];
-#pragma unroll
-    for (int a = 0; a < MF_T; ++a)
-#pragma unroll
-        for (int b = 0; b < MF_T; ++b)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0;
-
-    // software pipeline: while the nine MFMAs of step k run on the matrix pipe, the VALU builds the one-hot operands
-    // of step k+1 and the loads of step k+2 are in flight.  sched_group_barrier interleaves one MFMA with 16 VALU so
-    // that both pipes stay busy; two waves per SIMD (226 registers) cover most of the remaining load latency.
-    // (Measured alternatives: a 6-deep register ring at one wave per SIMD, 182 ms per 1 M bins against 145 ms; a 2-deep
-    // ring at two waves spills to scratch.)
-    uint4 ra[MF_T], rb[MF_T];
-    v4i fa[MF_T], fb[MF_T];
-#pragma unroll
-    for (int t = 0; t < MF_T; ++t) {
-        fa[t] = onehot16(*reinterpret_cast<const uint4*>(XT + offA[t] + kbeg), patA[t]);
-        fb[t] = onehot16(*reinterpret_cast<const uint4*>(XT + offB[t] + kbeg), patB[t]);
-    }
-    {
-        const long k1 = kbeg + 32 < kend ? kbeg + 32 : kbeg;
-#pragma unroll
-        for (int t = 0; t < MF_T; ++t) {
-            ra[t] = *reinterpret_cast<const uint4*>(XT + offA[t] + k1);
-            rb[t] = *reinterpret_cast<const uint4*>(XT + offB[t] + k1);
-        }
-    }
-    for (long k0 = kbeg; k0 < kend; k0 += 32) {
-        v4i na[MF_T], nb[MF_T];
-#pragma unroll
-        for (int t = 0; t < MF_T; ++t) {
-            na[t] = onehot16(ra[t], patA[t]);
-            nb[t] = onehot16(rb[t], patB[t]);
-        }
-        const long k2 = k0 + 64 < kend ? k0 + 64 : k0;
-#pragma unroll
-        for (int t = 0; t < MF_T; ++t) {
-            ra[t] = *reinterpret_cast<const uint4*>(XT + offA[t] + k2);
-            rb[t] = *reinterpret_cast<const uint4*>(XT + offB[t] + k2);
-        }
-#pragma unroll
-        for (int a = 0; a < MF_T; ++a)
-#pragma unroll
-            for (int b = 0; b < MF_T; ++b) acc[a][b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[a], fb[b], acc[a][b], 0, 0, 0);
-#pragma unroll
-        for (int g = 0; g < MF_T * MF_T; ++g) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);    // one MFMA
-            __builtin_amdgcn_sched_group_barrier(0x002, 14, 0);   // its share of the VALU that builds the next operands
-        }
-#pragma unroll
-        for (int t = 0; t < MF_T; ++t) { fa[t] = na[t]; fb[t] = nb[t]; }   // (a copy-free two-step unroll spills)
-    }
-
-    // C/D layout of a 32x32 MFMA: column = lane & 31, row = (r & 3) + 8*(r >> 2) + 4*(lane >> 5)
-    const long SS = (long)S * S;
-#pragma unroll
-    for (int ta = 0; ta < MF_T; ++ta)
-#pragma unroll
-        for (int tb = 0; tb < MF_T; ++tb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int v = acc[ta][tb][r];
-                if (!v) continue;
-                const int m = (bm * MF_T + ta) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                const int n = (bn * MF_T + tb) * 32 + (lane & 31);
-                if (m >= NS || n >= NS) continue;
-                const int a = m / S, i = m - a * S, b = n / S, j = n - b * S;
-                if (a == b) continue;
-                atomicAdd(&counts[((long)a * N + b) * SS + i * S + j], v);
-                if (bm != bn) atomicAdd(&counts[((long)b * N + a) * SS + j * S + i], v);
-            }
-}
-
-// Variant B: no operand double-buffering inside a wave (the other wave of the SIMD fills the matrix pipe while this one
-// builds its operands); the registers that frees hold a two-deep ring of raw loads, so a load has two whole steps to land.
-template <int PRIO>
+// Variant B (S < 14, where a block's 96 rows can span more than 8 biosamples): every lane loads its own 16 bytes.  No
+// operand double-buffering inside a wave (the other wave of the SIMD fills the matrix pipe while this one builds its
+// operands); the registers hold a two-deep ring of raw loads, so a load has two whole steps to land.  122 ms per 1 M
+// bins at N = 833, S = 18: bounded by the 64 B/clk L1 path, every byte travels ~14 times.
 __global__ __launch_bounds__(64, 2) void k_s3_hist_mfma_b(const char* __restrict__ XT, long Rp, long ksplit_len, int N, int S,
                                                           int nblk, int* __restrict__ counts) {
     const int lane = threadIdx.x;
@@ -224,12 +129,12 @@ __global__ __launch_bounds__(64, 2) void k_s3_hist_mfma_b(const char* __restrict
             ra[d][t] = *reinterpret_cast<const uint4*>(pA[t] + off);
             rb[d][t] = *reinterpret_cast<const uint4*>(pB[t] + off);
         }
-        if (PRIO) __builtin_amdgcn_s_setprio(1);
+        __builtin_amdgcn_s_setprio(1);                      // the wave that has its operands gets the matrix pipe
 #pragma unroll
         for (int a = 0; a < MF_T; ++a)
 #pragma unroll
             for (int b = 0; b < MF_T; ++b) acc[a][b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[a], fb[b], acc[a][b], 0, 0, 0);
-        if (PRIO) __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_s_setprio(0);
     };
     long k = 0;
     for (; k + 1 < nsteps; k += 2) {
@@ -257,7 +162,7 @@ __global__ __launch_bounds__(64, 2) void k_s3_hist_mfma_b(const char* __restrict
             }
 }
 
-// Variant C: the wave's operand bytes go through LDS.  The 96 rows of a block belong to at most 7 biosamples and the 18
+// Variant C (default): the wave's operand bytes go through LDS.  The 96 rows of a block belong to at most 7 biosamples and the 18
 // state rows of a biosample all need the same 16 bytes, so loading per lane moves every byte ~14 times through the
 // 64 B/clk L1 path, which is what bounded variants A/B (PMC: neither the matrix pipe nor the VALU above 40 %).  Here one
 // global_load_dwordx4 per side fetches the distinct bytes of four k-steps (8 biosamples x 128 bins), one ds_write_b128
@@ -267,7 +172,6 @@ constexpr int MC_SMP = 8;                 // biosample slots per side (96 rows s
 constexpr int MC_CH = 8;                  // 16-byte chunks per macro-step (128 bins = 4 k-steps)
 constexpr int MC_LD = MC_CH + 1;          // chunk stride in uint4: 144 B between biosamples keeps the b128 groups on distinct banks
 
-template <int PRIO>
 __global__ __launch_bounds__(64, 2) void k_s3_hist_mfma_c(const char* __restrict__ XT, long Rp, long ksplit_len, int N, int S,
                                                           int nblk, int* __restrict__ counts) {
     __shared__ uint4 lds[2][2][MC_SMP][MC_LD];
@@ -342,12 +246,12 @@ __global__ __launch_bounds__(64, 2) void k_s3_hist_mfma_c(const char* __restrict
                 fa[t] = onehot16(*reinterpret_cast<const uint4*>(ldsc + cur + rdA[t] + 32 * s4), patA[t]);
                 fb[t] = onehot16(*reinterpret_cast<const uint4*>(ldsc + cur + rdB[t] + 32 * s4), patB[t]);
             }
-            if (PRIO) __builtin_amdgcn_s_setprio(1);
+            __builtin_amdgcn_s_setprio(1);                      // the wave that has its operands gets the matrix pipe
 #pragma unroll
             for (int a = 0; a < MF_T; ++a)
 #pragma unroll
                 for (int b = 0; b < MF_T; ++b) acc[a][b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[a], fb[b], acc[a][b], 0, 0, 0);
-            if (PRIO) __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_s_setprio(0);
         }
     }
 
@@ -397,12 +301,11 @@ int hist_s3_mfma(const char* X, int64_t R, int32_t N, int64_t ldx, int32_t S, in
     if (splits > 65535) splits = 65535;
     const long ksplit_len = ((ksteps + splits - 1) / splits) * 32;
     const long nsplit = (Rp + ksplit_len - 1) / ksplit_len;
-    static const int variant = [] { const char* e = getenv("EPG_S3_MFMA"); return e ? atoi(e) : 0; }();
-    if (variant == 3 && S >= 14) hipLaunchKernelGGL(k_s3_hist_mfma_c<1>, dim3((unsigned)npairs, (unsigned)nsplit), dim3(64), 0, st, XT, Rp, ksplit_len, N, S, nblk, counts);
-    else if (variant == 2) hipLaunchKernelGGL(k_s3_hist_mfma_b<1>, dim3((unsigned)npairs, (unsigned)nsplit), dim3(64), 0, st, XT, Rp, ksplit_len, N, S, nblk, counts);
-    else if (variant == 1) hipLaunchKernelGGL(k_s3_hist_mfma_b<0>, dim3((unsigned)npairs, (unsigned)nsplit), dim3(64), 0, st, XT, Rp, ksplit_len, N, S, nblk, counts);
-    else
-    hipLaunchKernelGGL(k_s3_hist_mfma, dim3((unsigned)npairs, (unsigned)nsplit), dim3(64), 0, st, XT, Rp, ksplit_len, N, S, nblk, counts);
+    // C needs the 96 rows of a block to span at most 8 biosamples (S >= 14); EPG_S3_MFMA=b forces variant B
+    static const bool force_b = [] { const char* e = getenv("EPG_S3_MFMA"); return e && e[0] == 'b'; }();
+    const dim3 grid((unsigned)npairs, (unsigned)nsplit);
+    if (S >= 14 && !force_b) hipLaunchKernelGGL(k_s3_hist_mfma_c, grid, dim3(64), 0, st, XT, Rp, ksplit_len, N, S, nblk, counts);
+    else hipLaunchKernelGGL(k_s3_hist_mfma_b, grid, dim3(64), 0, st, XT, Rp, ksplit_len, N, S, nblk, counts);
     EPG_LAUNCH_CHECK("k_s3_hist_mfma");
     return EPG_OK;
 }

@@ -87,6 +87,26 @@ def test_s3_score_tile_not_multiple_of_four(eng, N):
     _s3_score_check(eng, x, onp.normalise(c))
 
 
+@pytest.mark.parametrize("S_,N,R", [(5, 40, 300), (13, 23, 1000), (15, 64, 700), (25, 30, 257), (30, 21, 420), (31, 9, 300)])
+def test_s3_other_state_counts(eng, S_, N, R):
+    """State models other than 18: S < 14 takes the per-lane-load MFMA kernel, S = 31 the LDS-atomic one; the score
+    kernel is instantiated for 6, 10 and 16 staging elements per thread."""
+    x = synth_states(R, N, S=S_, seed=S_, uniform=True)
+    keep = x[R // 2, N // 2]
+    x[R // 2, N // 2] = -1                         # not a state: skipped in every pair it takes part in
+    want = onp.expected_s3(x, S_)
+    c = eng.hist_s3(eng.states_to_device(x), N, S_)
+    assert np.array_equal(_np(c).reshape(want.shape), want)
+    x[R // 2, N // 2] = keep                       # scores are defined for valid states only
+    X = eng.states_to_device(x)
+    q = onp.normalise(want)
+    qd = torch.from_numpy(q.reshape(-1)).cuda()
+    o32, o64 = eng.score_s3(X, N, S_, qd, want32=True, want64=True)
+    ref = onp.score_s3_f64(x, q, S_)
+    np.testing.assert_allclose(_np(o64), ref, rtol=2e-6, atol=1e-9)
+    np.testing.assert_allclose(_np(o32), ref.astype(np.float32), rtol=3e-6, atol=1e-9)
+
+
 def test_s3_score_random(eng):
     x = synth_states(9000, 70, seed=3)             # more than one slice of 8192 bins
     q = onp.normalise(onp.expected_s3(x, S))
