@@ -1,4 +1,5 @@
-// S3 expected pass as an int8 matrix-core contraction (gfx950 v_mfma_i32_32x32x32_i8).
+// S3 expected pass as a matrix-core contraction of one-hot operands (gfx950: fp4 MX v_mfma_scale_f32_32x32x64_f8f6f4 by
+// default, int8 v_mfma_i32_32x32x32_i8 as the alternative).
 //
 // C[a,b,i,j] = #{bins : x[a] == i and x[b] == j} is G = E^T E for the one-hot expansion E[bin, (sample, state)]
 // (reference expected.py:183-200 increments exactly these cells, one bin at a time).  This is a genuine dense
@@ -162,7 +163,7 @@ __global__ __launch_bounds__(64, 2) void k_s3_hist_mfma_b(const char* __restrict
             }
 }
 
-// Variant C (default): the wave's operand bytes go through LDS.  The 96 rows of a block belong to at most 7 biosamples and the 18
+// Variant C (int8 with LDS-shared operand bytes; EPG_S3_MFMA=c): the wave's operand bytes go through LDS.  The 96 rows of a block belong to at most 7 biosamples and the 18
 // state rows of a biosample all need the same 16 bytes, so loading per lane moves every byte ~14 times through the
 // 64 B/clk L1 path, which is what bounded variants A/B (PMC: neither the matrix pipe nor the VALU above 40 %).  Here one
 // global_load_dwordx4 per side fetches the distinct bytes of four k-steps (8 biosamples x 128 bins), one ds_write_b128
@@ -274,7 +275,135 @@ __global__ __launch_bounds__(64, 2) void k_s3_hist_mfma_c(const char* __restrict
             }
 }
 
-int64_t s3_mfma_ws_bytes(int64_t R, int N) { return align_up((int64_t)N * align_up(R, 32) + 64, 256); }
+typedef int v8i __attribute__((ext_vector_type(8)));
+typedef float v16f __attribute__((ext_vector_type(16)));
+
+// Variant E (default): the same contraction on the MX path, v_mfma_scale_f32_32x32x64_f8f6f4 with both operands in fp4 (E2M1) and
+// unit block scales (E8M0 127): one instruction covers 64 bins in the time the int8 one covers 32.  A one-hot entry is
+// the fp4 encoding of 1.0 (0b0010); counts accumulate in float32, exact below 2^24, which the K split guarantees.  A
+// lane's 32 bins are 32 state bytes -> eight dwords -> four dwords of nibbles; which bin lands in which nibble does
+// not matter as long as A and B agree, and both come from this routine.
+__device__ __forceinline__ u32 eq_pair_fp4(u32 w0, u32 w1, u32 pat) {
+    const u32 d0 = 0x80808080u - (w0 ^ pat);                     // bit 7 of a byte set <=> byte == pattern (bytes < 32)
+    const u32 d1 = 0x80808080u - (w1 ^ pat);
+    return ((d0 >> 6) & 0x02020202u) | ((d1 >> 2) & 0x20202020u);
+}
+
+__device__ __forceinline__ v8i onehot32_fp4(const uint4 r0, const uint4 r1, u32 pat) {
+    v8i r;
+    r[0] = (int)eq_pair_fp4(r0.x, r0.y, pat);
+    r[1] = (int)eq_pair_fp4(r0.z, r0.w, pat);
+    r[2] = (int)eq_pair_fp4(r1.x, r1.y, pat);
+    r[3] = (int)eq_pair_fp4(r1.z, r1.w, pat);
+    r[4] = r[5] = r[6] = r[7] = 0;                               // fp4 operands use four registers; the rest is not encoded
+    return r;
+}
+
+__global__ __launch_bounds__(64, 2) void k_s3_hist_mfma_e(const char* __restrict__ XT, long Rp, long ksplit_len, int N, int S,
+                                                          int nblk, int* __restrict__ counts) {
+    __shared__ uint4 lds[2][2][MC_SMP][MC_LD];
+    const int lane = threadIdx.x;
+    const int NS = N * S;
+    int p = blockIdx.x, bm = 0;
+    while (p >= nblk - bm) { p -= nblk - bm; ++bm; }
+    const int bn = bm + p;
+    const long kbeg = (long)blockIdx.y * ksplit_len;
+    const long kend = kbeg + ksplit_len < Rp ? kbeg + ksplit_len : Rp;
+    const long nsteps = (kend - kbeg) / 64;                     // K = 64 bins per MFMA; kbeg, kend are multiples of 64
+
+    // first biosample of each side's block; a lane's rows address slots relative to it
+    const int sA0 = (bm * MF_ROWS) / S, sB0 = (bn * MF_ROWS) / S;
+    u32 rdA[MF_T], rdB[MF_T], patA[MF_T], patB[MF_T];           // LDS byte offsets of this lane's rows inside a buffer
+#pragma unroll
+    for (int t = 0; t < MF_T; ++t) {
+        const int m = (bm * MF_T + t) * 32 + (lane & 31);
+        const int n = (bn * MF_T + t) * 32 + (lane & 31);
+        const int am = m < NS ? m / S : N - 1, im = m < NS ? m % S : 30;      // rows past N*S match nothing (S <= 30)
+        const int an = n < NS ? n / S : N - 1, in_ = n < NS ? n % S : 30;
+        int la = am - sA0, lb = an - sB0;
+        la = la < MC_SMP ? la : MC_SMP - 1;                                    // only rows past N*S can exceed the slots
+        lb = lb < MC_SMP ? lb : MC_SMP - 1;
+        rdA[t] = (u32)(((0 * MC_SMP + la) * MC_LD + 2 * (lane >> 5)) * 16);
+        rdB[t] = (u32)(((1 * MC_SMP + lb) * MC_LD + 2 * (lane >> 5)) * 16);
+        patA[t] = (u32)im * 0x01010101u;
+        patB[t] = (u32)in_ * 0x01010101u;
+    }
+    // staging role of this lane: biosample slot lane >> 3, chunk lane & 7
+    const int slot = lane >> 3, chunk = lane & 7;
+    const int gsa = sA0 + slot < N ? sA0 + slot : N - 1, gsb = sB0 + slot < N ? sB0 + slot : N - 1;
+    const char* gA = XT + (long)gsa * Rp;
+    const char* gB = XT + (long)gsb * Rp;
+    const u32 wrA = (u32)(((0 * MC_SMP + slot) * MC_LD + chunk) * 16), wrB = (u32)(((1 * MC_SMP + slot) * MC_LD + chunk) * 16);
+    char* ldsc = reinterpret_cast<char*>(&lds[0][0][0][0]);
+    constexpr u32 BUF = 2 * MC_SMP * MC_LD * 16;
+    auto gload = [&](long M, uint4& va, uint4& vb) {             // macro-step M: bins kbeg + 128 M + 16 chunk ..
+        long off = kbeg + 128 * M + 16 * chunk;
+        off = off < Rp - 16 ? off : Rp - 16;                     // tail chunks past the slice are never consumed
+        va = *reinterpret_cast<const uint4*>(gA + off);
+        vb = *reinterpret_cast<const uint4*>(gB + off);
+    };
+
+    v16f acc[MF_T][MF_T];                                        // exact: a wave's K range is < 2^24 bins
+#pragma unroll
+    for (int a = 0; a < MF_T; ++a)
+#pragma unroll
+        for (int b = 0; b < MF_T; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    uint4 va, vb;
+    gload(0, va, vb);
+    *reinterpret_cast<uint4*>(ldsc + wrA) = va;
+    *reinterpret_cast<uint4*>(ldsc + wrB) = vb;
+    gload(1, va, vb);
+    const long nmacro = (nsteps + 1) / 2;                        // 128 bins = two k-steps of 64
+    for (long M = 0; M < nmacro; ++M) {
+        const u32 cur = (u32)(M & 1) * BUF, nxt = BUF - cur;
+        *reinterpret_cast<uint4*>(ldsc + nxt + wrA) = va;
+        *reinterpret_cast<uint4*>(ldsc + nxt + wrB) = vb;
+        gload(M + 2, va, vb);
+        const int ns = nsteps - 2 * M < 2 ? (int)(nsteps - 2 * M) : 2;
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            if (s2 >= ns) break;                                 // wave-uniform
+            v8i fa[MF_T], fb[MF_T];
+#pragma unroll
+            for (int t = 0; t < MF_T; ++t) {
+                const char* pa = ldsc + cur + rdA[t] + 64 * s2;
+                const char* pb = ldsc + cur + rdB[t] + 64 * s2;
+                fa[t] = onehot32_fp4(*reinterpret_cast<const uint4*>(pa), *reinterpret_cast<const uint4*>(pa + 16), patA[t]);
+                fb[t] = onehot32_fp4(*reinterpret_cast<const uint4*>(pb), *reinterpret_cast<const uint4*>(pb + 16), patB[t]);
+            }
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int a = 0; a < MF_T; ++a)
+#pragma unroll
+                for (int b = 0; b < MF_T; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fa[a], fb[b], acc[a][b], 4, 4, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+            __builtin_amdgcn_s_setprio(0);
+        }
+    }
+
+    const long SS = (long)S * S;
+#pragma unroll
+    for (int ta = 0; ta < MF_T; ++ta)
+#pragma unroll
+        for (int tb = 0; tb < MF_T; ++tb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int v = (int)acc[ta][tb][r];
+                if (!v) continue;
+                const int m = (bm * MF_T + ta) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const int n = (bn * MF_T + tb) * 32 + (lane & 31);
+                if (m >= NS || n >= NS) continue;
+                const int a = m / S, i = m - a * S, b = n / S, j = n - b * S;
+                if (a == b) continue;
+                atomicAdd(&counts[((long)a * N + b) * SS + i * S + j], v);
+                if (bm != bn) atomicAdd(&counts[((long)b * N + a) * SS + j * S + i], v);
+            }
+}
+
+int64_t s3_mfma_ws_bytes(int64_t R, int N) { return align_up((int64_t)N * align_up(R, 64) + 64, 256); }
 
 // XT[sample][bin], bins padded to Rp (a multiple of 32), everything that is not a state in [0, S) stored as 31;
 // bytes are stored shifted left by `shift` (the S3 score kernel wants 4 * state, a ready-made LDS byte offset)
@@ -286,25 +415,30 @@ int transpose_states(const char* X, int64_t R, int32_t N, int64_t ldx, int32_t S
 }
 
 int hist_s3_mfma(const char* X, int64_t R, int32_t N, int64_t ldx, int32_t S, int32_t* counts, void* ws, hipStream_t st) {
-    const long Rp = align_up(R, 32);
+    const long Rp = align_up(R, 64);              // whole 64-bin steps; padded bins hold 31, which matches no row
     char* XT = reinterpret_cast<char*>(ws);
     int rc = transpose_states(X, R, N, ldx, S, XT, Rp, 0, st);
     if (rc) return rc;
     const int nblk = (N * S + MF_ROWS - 1) / MF_ROWS;
     const long npairs = (long)nblk * (nblk + 1) / 2;
-    // split K so that there are a few tasks per wave slot (2 waves per SIMD); int32 atomics combine the splits
+    // split K so that there are a few tasks per wave slot (2 waves per SIMD); int32 atomics combine the splits.  A
+    // split stays below 2^24 bins so that the float32 accumulators of the fp4 kernel hold exact integers.
     const long slots = (long)num_cus() * 8;
     long splits = (4 * slots + npairs - 1) / npairs;
-    const long ksteps = Rp / 32;
+    const long ksteps = Rp / 64;
+    const long min_splits = (Rp + (1L << 24) - 65) / ((1L << 24) - 64);
+    if (splits < min_splits) splits = min_splits;
     if (splits > ksteps) splits = ksteps;
     if (splits < 1) splits = 1;
     if (splits > 65535) splits = 65535;
-    const long ksplit_len = ((ksteps + splits - 1) / splits) * 32;
+    const long ksplit_len = ((ksteps + splits - 1) / splits) * 64;
     const long nsplit = (Rp + ksplit_len - 1) / ksplit_len;
-    // C needs the 96 rows of a block to span at most 8 biosamples (S >= 14); EPG_S3_MFMA=b forces variant B
-    static const bool force_b = [] { const char* e = getenv("EPG_S3_MFMA"); return e && e[0] == 'b'; }();
+    // C / E need the 96 rows of a block to span at most 8 biosamples (S >= 14).  EPG_S3_MFMA=c selects the int8 kernel,
+    // =b the per-lane-load int8 kernel (A/B measurements); default is the fp4 MX kernel.
+    static const char variant = [] { const char* e = getenv("EPG_S3_MFMA"); return e ? e[0] : 'e'; }();
     const dim3 grid((unsigned)npairs, (unsigned)nsplit);
-    if (S >= 14 && !force_b) hipLaunchKernelGGL(k_s3_hist_mfma_c, grid, dim3(64), 0, st, XT, Rp, ksplit_len, N, S, nblk, counts);
+    if (S >= 14 && variant == 'e') hipLaunchKernelGGL(k_s3_hist_mfma_e, grid, dim3(64), 0, st, XT, Rp, ksplit_len, N, S, nblk, counts);
+    else if (S >= 14 && variant == 'c') hipLaunchKernelGGL(k_s3_hist_mfma_c, grid, dim3(64), 0, st, XT, Rp, ksplit_len, N, S, nblk, counts);
     else hipLaunchKernelGGL(k_s3_hist_mfma_b, grid, dim3(64), 0, st, XT, Rp, ksplit_len, N, S, nblk, counts);
     EPG_LAUNCH_CHECK("k_s3_hist_mfma");
     return EPG_OK;
