@@ -30,6 +30,23 @@ if stats.exists():
     for r in keep:
         lines.append("| `%s` | %s | %.0f | %s | %s |" % (r["Name"].split("(")[0], r["Calls"], float(r["AverageNs"]), r["MinNs"], r["MaxNs"]))
     lines.append("")
+stats_all = src / "stats_all" / "p_kernel_stats.csv"
+if stats_all.exists():
+    rows = list(csv.DictReader(open(stats_all)))
+    keep = [r for r in rows if "epg::" in r["Name"]]
+    with open(dst / ("%s_s2s3_kernel_stats.csv" % label), "w", newline="") as f:
+        w = csv.DictWriter(f, fieldnames=rows[0].keys())
+        w.writeheader()
+        w.writerows(keep)
+    lines += ["## `rocprofv3 --kernel-trace --stats -- python3 tools/kbench_all.py --bins 15000000 --s3-bins 1000000 --null-bins 1000000`",
+              "(S2 on 15 M bins, S3 and the null shuffle on 1 M bins, 833 biosamples)", "",
+              "| kernel | calls | avg ns | min ns | max ns |", "|---|---|---|---|---|"]
+    for r in keep:
+        lines.append("| `%s` | %s | %.0f | %s | %s |" % (r["Name"].split("(")[0], r["Calls"], float(r["AverageNs"]), r["MinNs"], r["MaxNs"]))
+    lines.append("")
+    log = src / "stats_all.log"
+    if log.exists():
+        lines += ["```"] + [l for l in log.read_text().splitlines() if l.startswith(("S2", "S3", "paired"))] + ["```", ""]
 traffic = {}
 for cname in ("fetch", "write"):
     f = src / cname / "p_counter_collection.csv"
