@@ -39,6 +39,8 @@ def load():
     lib.epgio_close_table.argtypes = [p]
     lib.epgio_write_scores.restype = C.c_int
     lib.epgio_write_scores.argtypes = [C.c_char_p, p, p, p, i64, i32, i32, i32]
+    lib.epgio_write_metrics.restype = C.c_int
+    lib.epgio_write_metrics.argtypes = [C.c_char_p, p, p, p, p, p, p, p, p, p, p, p, i64, i32, i32]
     lib.epgio_format_f5.restype = i64
     lib.epgio_format_f5.argtypes = [p, i64, C.c_char, p, i64]
     _lib = lib
@@ -76,6 +78,18 @@ class Locations:
         if len(self) == 0:
             return np.empty((0, 3), dtype=object)
         return pd.read_table(io.BytesIO(self.blob.tobytes()), header=None, sep="\t").to_numpy()
+
+    def columns(self):
+        """(chromosome object array, start int64, end int64) of every row."""
+        import pandas as pd
+        if len(self) == 0:
+            return np.empty(0, dtype=object), np.zeros(0, dtype=np.int64), np.zeros(0, dtype=np.int64)
+        df = pd.read_table(io.BytesIO(self.blob.tobytes()), header=None, sep="\t")
+        return df.iloc[:, 0].to_numpy(dtype=object), df.iloc[:, 1].to_numpy(dtype=np.int64), df.iloc[:, 2].to_numpy(dtype=np.int64)
+
+    def start_end(self):
+        _, s, e = self.columns()
+        return s, e
 
     @staticmethod
     def from_object_array(loc):
@@ -117,6 +131,36 @@ def write_scores(path, locations, scores, threads=0, gzip_level=6):
     off = np.ascontiguousarray(locations.offsets, dtype=np.int64)
     rc = load().epgio_write_scores(str(path).encode(), blob.ctypes.data, off.ctypes.data, scores.ctypes.data, R, S,
                                    threads, gzip_level)
+    if rc != 0:
+        raise EpilogosIOError(_err())
+
+
+def _string_table(strings):
+    enc = [str(x).encode() for x in strings]
+    off = np.zeros(len(enc) + 1, dtype=np.int64)
+    np.cumsum([len(e) for e in enc], out=off[1:])
+    return np.frombuffer(b"".join(enc) + b"\0", dtype=np.uint8).copy(), off
+
+
+def write_metrics(path, chrom_names, chrom_idx, start, end, state_names, maxdiff, dist, pvals=None, mh=None, threads=0,
+                  gzip_level=6):
+    """pairwiseMetrics text (see epilogos_io.h): chrom_names[chrom_idx[r]], start, end, state_names[maxdiff[r] - 1],
+    |dist| %.5f, sign [, p %.5e, adjusted p %.5e]."""
+    R = len(dist)
+    cb, co = _string_table(chrom_names)
+    nb, no = _string_table(state_names)
+    ci = np.ascontiguousarray(chrom_idx, dtype=np.int32)
+    st_, en = np.ascontiguousarray(start, dtype=np.int64), np.ascontiguousarray(end, dtype=np.int64)
+    md = np.ascontiguousarray(maxdiff, dtype=np.int32)
+    di = np.ascontiguousarray(dist, dtype=np.float32)
+    if R and (ci.min() < 0 or ci.max() >= len(chrom_names) or md.min() < 1 or md.max() > len(state_names)):
+        raise ValueError("chromosome or state index out of range")
+    pv = None if pvals is None else np.ascontiguousarray(pvals, dtype=np.float64)
+    mv = None if mh is None else np.ascontiguousarray(mh, dtype=np.float64)
+    rc = load().epgio_write_metrics(str(path).encode(), cb.ctypes.data, co.ctypes.data, ci.ctypes.data, st_.ctypes.data, en.ctypes.data,
+                                    nb.ctypes.data, no.ctypes.data, md.ctypes.data, di.ctypes.data,
+                                    None if pv is None else pv.ctypes.data, None if mv is None else mv.ctypes.data, R, threads,
+                                    gzip_level)
     if rc != 0:
         raise EpilogosIOError(_err())
 

@@ -2,6 +2,7 @@
 // Contract: include/epilogos_io.h.
 #include "epilogos_io.h"
 
+#include <cmath>
 #include <zlib.h>
 
 #include <algorithm>
@@ -339,6 +340,64 @@ int epgio_write_scores(const char* path, const char* loc, const int64_t* loc_off
                     *o++ = '\n';
                 }
                 txt.resize((size_t)(o - txt.data()));
+                good[k] = gzip_member(txt, gzip_level, z[k]);
+            });
+        for (auto& x : th) x.join();
+        for (int k = 0; k < nb && ok; ++k) {
+            if (!good[k] || fwrite(z[k].data(), 1, z[k].size(), f) != z[k].size()) ok = false;
+        }
+    }
+    if (fclose(f) != 0) ok = false;
+    return ok ? 0 : fail("write error on %s", path);
+}
+
+int epgio_write_metrics(const char* path, const char* chrom, const int64_t* chrom_off, const int32_t* chrom_idx, const int64_t* start,
+                        const int64_t* end, const char* names, const int64_t* names_off, const int32_t* maxdiff, const float* dist,
+                        const double* pvals, const double* mh, int64_t R, int32_t threads, int32_t gzip_level) {
+    if (!path || (R > 0 && (!chrom || !chrom_off || !chrom_idx || !start || !end || !names || !names_off || !maxdiff || !dist)) ||
+        ((pvals == nullptr) != (mh == nullptr)))
+        return fail("write_metrics: bad argument");
+    if (gzip_level < 1 || gzip_level > 9) gzip_level = 6;
+    FILE* f = fopen(path, "wb");
+    if (!f) return fail("cannot create %s", path);
+    const int T = n_threads(threads);
+    const int64_t CH = 32768;
+    const int64_t nchunks = (R + CH - 1) / CH;
+    if (R == 0) {
+        std::vector<unsigned char> z;
+        gzip_member(std::vector<char>(), gzip_level, z);
+        fwrite(z.data(), 1, z.size(), f);
+    }
+    bool ok = true;
+    for (int64_t c0 = 0; c0 < nchunks && ok; c0 += T) {
+        const int nb = (int)std::min<int64_t>(T, nchunks - c0);
+        std::vector<std::vector<unsigned char>> z(nb);
+        std::vector<int> good(nb, 0);
+        std::vector<std::thread> th;
+        for (int k = 0; k < nb; ++k)
+            th.emplace_back([&, k] {
+                const int64_t r0 = (c0 + k) * CH, r1 = std::min(R, r0 + CH);
+                std::vector<char> txt;
+                txt.reserve((size_t)(r1 - r0) * 96);
+                char num[64];
+                for (int64_t r = r0; r < r1; ++r) {
+                    const int32_t ci = chrom_idx[r], mi = maxdiff[r] - 1;
+                    txt.insert(txt.end(), chrom + chrom_off[ci], chrom + chrom_off[ci + 1]);
+                    int n = snprintf(num, sizeof num, "\t%lld\t%lld\t", (long long)start[r], (long long)end[r]);
+                    txt.insert(txt.end(), num, num + n);
+                    txt.insert(txt.end(), names + names_off[mi], names + names_off[mi + 1]);
+                    txt.push_back('\t');
+                    const float d = dist[r];
+                    char* e = fmt_f5(std::fabs(d), num);                     // "{:.5f}".format(abs(distance)) of the float32
+                    txt.insert(txt.end(), num, e);
+                    txt.push_back('\t');
+                    txt.push_back(d >= 0.0f ? '+' : '-');                   // helpers.findSign: x >= 0
+                    if (pvals) {
+                        n = snprintf(num, sizeof num, "\t%.5e\t%.5e", pvals[r], mh[r]);
+                        txt.insert(txt.end(), num, num + n);
+                    }
+                    txt.push_back('\n');
+                }
                 good[k] = gzip_member(txt, gzip_level, z[k]);
             });
         for (auto& x : th) x.join();

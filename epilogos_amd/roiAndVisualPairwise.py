@@ -29,6 +29,7 @@ import numpy as np
 import pandas as pd
 import scipy.stats as st
 
+from . import _io
 from . import backend as _backend
 from .helpers import getNumStates, strToBool
 from .roiSingle import findSign, getStateNames, maxMean, orderChromosomes
@@ -86,16 +87,7 @@ def fitDistances(outputDirPath, numProcesses, numTrials, samplingSize):
     _, distanceArrNull = _ordered_concat(nulls)
     _, quiescenceArr = _ordered_concat(quies)
     nonQuiescentIdx = np.where(np.invert(quiescenceArr.astype(bool)))[0]
-    data = distanceArrNull[nonQuiescentIdx]
-    if numProcesses > 1 and numTrials > 1:
-        with closing(Pool(numProcesses)) as pool:
-            results = pool.starmap(fitOnSubSample, zip(repeat(data, numTrials), repeat(samplingSize, numTrials)))
-        pool.join()
-    else:
-        results = [fitOnSubSample(data, samplingSize) for _ in range(numTrials)]
-    nnlf = np.array([r[1] for r in results], dtype=np.float64)
-    pick = np.argsort(nnlf, kind="stable")[int((numTrials - 1) / 2)]
-    return tuple(results[pick][0]), distanceArrNull, nonQuiescentIdx
+    return _fitParams(distanceArrNull, quiescenceArr, numProcesses, numTrials, samplingSize), distanceArrNull, nonQuiescentIdx
 
 
 def readInData(outputDirPath, numStates, backend=None):
@@ -147,22 +139,15 @@ def calculatePVals(distanceArrReal, beta, loc, scale):
 def writeMetrics(locationArr, chrDict, maxDiffArr, nameArr, distanceArrReal, outputDirPath, fileTag, pvalBool, pvals=(),
                  mhPvals=()):
     """pairwiseMetrics_{tag}.txt.gz: chr, start, end, state, |distance| %.5f, sign [, p %.5e, BH p %.5e]
-    (reference :520-573)."""
+    (reference :520-573), through the native multi-threaded writer (same decompressed bytes)."""
     outputDirPath.mkdir(parents=True, exist_ok=True)
-    chrom = [chrDict[c] for c in locationArr[:, 0]]
-    names = [nameArr[m - 1] for m in maxDiffArr]
-    with gzip.open(outputDirPath / "pairwiseMetrics_{}.txt.gz".format(fileTag), "wt") as out:
-        step = 1 << 16
-        for lo in range(0, len(distanceArrReal), step):
-            hi = min(lo + step, len(distanceArrReal))
-            if pvalBool:
-                out.write("".join("{}\t{}\t{}\t{}\t{:.5f}\t{}\t{:.5e}\t{:.5e}\n".format(
-                    chrom[i], locationArr[i, 1], locationArr[i, 2], names[i], abs(distanceArrReal[i]),
-                    findSign(distanceArrReal[i]), pvals[i], mhPvals[i]) for i in range(lo, hi)))
-            else:
-                out.write("".join("{}\t{}\t{}\t{}\t{:.5f}\t{}\n".format(
-                    chrom[i], locationArr[i, 1], locationArr[i, 2], names[i], abs(distanceArrReal[i]),
-                    findSign(distanceArrReal[i])) for i in range(lo, hi)))
+    numbers = sorted(chrDict)
+    index = np.zeros(max(numbers) + 1 if numbers else 1, dtype=np.int32)
+    index[numbers] = np.arange(len(numbers), dtype=np.int32)
+    _io.write_metrics(outputDirPath / "pairwiseMetrics_{}.txt.gz".format(fileTag), [chrDict[n] for n in numbers],
+                      index[locationArr[:, 0]] if len(locationArr) else np.zeros(0, dtype=np.int32), locationArr[:, 1],
+                      locationArr[:, 2], list(nameArr), maxDiffArr, distanceArrReal, pvals if pvalBool else None,
+                      mhPvals if pvalBool else None)
 
 
 def _stars_p(p):
@@ -227,62 +212,108 @@ def createROINoSignificance(filePath, locationArr, chrDict, distanceArr, maxDiff
                 findSign(score), z, _stars_z(z)))
 
 
+def _stage(verbose, label):
+    if verbose: print(label + "...", flush=True)
+    else: print("    " + label + "\t", end="", flush=True)
+    return time()
+
+
+def _done(verbose, t0):
+    print("    Time:", time() - t0, flush=True) if verbose else print("\t[Done]", flush=True)
+
+
+def _fitParams(distanceArrNull, quiescenceArr, numProcesses, numTrials, samplingSize):
+    """Median-likelihood gennorm fit of the non-quiescent null distances (reference :196-221)."""
+    data = distanceArrNull[np.where(np.invert(quiescenceArr.astype(bool)))[0]]
+    if numProcesses > 1 and numTrials > 1:
+        with closing(Pool(numProcesses)) as pool:
+            results = pool.starmap(fitOnSubSample, zip(repeat(data, numTrials), repeat(samplingSize, numTrials)))
+        pool.join()
+    else:
+        results = [fitOnSubSample(data, samplingSize) for _ in range(numTrials)]
+    nnlf = np.array([r[1] for r in results], dtype=np.float64)
+    return tuple(results[np.argsort(nnlf, kind="stable")[int((numTrials - 1) / 2)]][0])
+
+
+def _finish(params, locationArr, distanceArrReal, maxDiffArr, chrDict, stateInfo, outputDirPath, fileTag, pvalBool, roiWidth,
+            expFreqPath, verbose):
+    """Everything of main() after the inputs are in memory (reference :72-169 without the figures)."""
+    stateNameList = getStateNames(stateInfo)
+    roiPath = outputDirPath / "regionsOfInterest_{}.txt".format(fileTag)
+    if pvalBool:
+        beta, loc, scale = params[0], params[-2], params[-1]
+        t0 = _stage(verbose, "Calculating p-vals")
+        pvals = calculatePVals(distanceArrReal, beta, loc, scale)
+        _done(verbose, t0)
+        t0 = _stage(verbose, "Benjamini-Hochberg procedure")
+        mhPvals = benjaminiHochberg(pvals)
+        _done(verbose, t0)
+        t0 = _stage(verbose, "Writing metrics")
+        writeMetrics(locationArr, chrDict, maxDiffArr, stateNameList, distanceArrReal, outputDirPath, fileTag, True,
+                     pvals=pvals, mhPvals=mhPvals)
+        _done(verbose, t0)
+        t0 = _stage(verbose, "Regions of interest txt")
+        createROITxt(roiPath, locationArr, chrDict, distanceArrReal, maxDiffArr, stateNameList, pvals, mhPvals, roiWidth)
+        _done(verbose, t0)
+        t0 = _stage(verbose, "Significant loci txt")
+        createSignificantLociTxt(outputDirPath / "significantLoci_{}.txt.gz".format(fileTag), locationArr, chrDict,
+                                 distanceArrReal, maxDiffArr, stateNameList, pvals, mhPvals)
+        _done(verbose, t0)
+    else:
+        t0 = _stage(verbose, "Z-Scores")
+        zScores = np.abs(st.zscore(distanceArrReal))
+        _done(verbose, t0)
+        t0 = _stage(verbose, "Writing metrics")
+        writeMetrics(locationArr, chrDict, maxDiffArr, stateNameList, distanceArrReal, outputDirPath, fileTag, False)
+        _done(verbose, t0)
+        t0 = _stage(verbose, "Regions of interest txt")
+        createROINoSignificance(roiPath, locationArr, chrDict, distanceArrReal, maxDiffArr, stateNameList, zScores, roiWidth)
+        _done(verbose, t0)
+    remove(Path(expFreqPath))
+
+
+def mainFromArrays(results, stateInfo, outputDir, fileTag, numProcesses, pvalBool, numTrials, samplingSize, expFreqPath,
+                   roiWidth, verbose):
+    """main() on the arrays driver.run_paired_groups hands back ({stem: dict(chrName, locations, nullDistances,
+    quiescenceArr, distances, maxDiff)}) instead of the temp_*.npz / pairwiseDelta text round trip."""
+    outputDirPath = Path(outputDir)
+    if numProcesses == 0:
+        numProcesses = cpu_count()
+    byChr = {v["chrName"]: v for v in results.values()}
+    chrOrder = orderChromosomes(list(byChr))
+    cat = lambda key: np.concatenate([byChr[c][key] for c in chrOrder])
+    params = None
+    if pvalBool:
+        t0 = _stage(verbose, "Fitting distances")
+        params = _fitParams(cat("nullDistances"), cat("quiescenceArr"), numProcesses, numTrials, samplingSize)
+        _done(verbose, t0)
+    cols = [byChr[c]["locations"].columns() for c in chrOrder]
+    chrNum = np.concatenate([np.full(len(c[1]), i + 1, dtype=np.int64) for i, c in enumerate(cols)])
+    starts, ends = np.concatenate([c[1] for c in cols]), np.concatenate([c[2] for c in cols])
+    order = np.lexsort((ends, starts, chrNum))
+    locationArr = np.stack([chrNum[order], starts[order], ends[order]], axis=1)
+    chrDict = {i + 1: c for i, c in enumerate(chrOrder)}
+    _finish(params, locationArr, cat("distances")[order], cat("maxDiff")[order], chrDict, stateInfo, outputDirPath, fileTag, pvalBool,
+            roiWidth, expFreqPath, verbose)
+
+
 def main(group1Name, group2Name, stateInfo, outputDir, fileTag, numProcesses, pvalBool, diagnosticBool, numTrials,
          samplingSize, expFreqPath, roiWidth, verbose, backend=None):
     tTotal = time()
     outputDirPath = Path(outputDir)
     numStates = getNumStates(stateInfo)
-    stateNameList = getStateNames(stateInfo)
     if numProcesses == 0:
         numProcesses = cpu_count()
-
-    def stage(label):
-        if verbose: print(label + "...", flush=True)
-        else: print("    " + label + "\t", end="", flush=True)
-        return time()
-
-    def done(t0):
-        print("    Time:", time() - t0, flush=True) if verbose else print("\t[Done]", flush=True)
-
+    params = None
     if pvalBool:
-        t0 = stage("Fitting distances")
+        t0 = _stage(verbose, "Fitting distances")
         params, _, _ = fitDistances(outputDirPath, numProcesses, numTrials, samplingSize)
-        done(t0)
-    t0 = stage("Reading in files")
+        _done(verbose, t0)
+    t0 = _stage(verbose, "Reading in files")
     locationArr, distanceArrReal, maxDiffArr, chrDict = readInData(outputDirPath, numStates, backend)
-    done(t0)
-    if pvalBool:
-        beta, loc, scale = params[0], params[-2], params[-1]
-        t0 = stage("Calculating p-vals")
-        pvals = calculatePVals(distanceArrReal, beta, loc, scale)
-        done(t0)
-        t0 = stage("Benjamini-Hochberg procedure")
-        mhPvals = benjaminiHochberg(pvals)
-        done(t0)
-        t0 = stage("Writing metrics")
-        writeMetrics(locationArr, chrDict, maxDiffArr, stateNameList, distanceArrReal, outputDirPath, fileTag, True,
-                     pvals=pvals, mhPvals=mhPvals)
-        done(t0)
-        t0 = stage("Regions of interest txt")
-        createROITxt(outputDirPath / "regionsOfInterest_{}.txt".format(fileTag), locationArr, chrDict, distanceArrReal,
-                     maxDiffArr, stateNameList, pvals, mhPvals, roiWidth)
-        done(t0)
-        t0 = stage("Significant loci txt")
-        createSignificantLociTxt(outputDirPath / "significantLoci_{}.txt.gz".format(fileTag), locationArr, chrDict,
-                                 distanceArrReal, maxDiffArr, stateNameList, pvals, mhPvals)
-        done(t0)
-    else:
-        t0 = stage("Z-Scores")
-        zScores = np.abs(st.zscore(distanceArrReal))
-        done(t0)
-        t0 = stage("Writing metrics")
-        writeMetrics(locationArr, chrDict, maxDiffArr, stateNameList, distanceArrReal, outputDirPath, fileTag, False)
-        done(t0)
-        t0 = stage("Regions of interest txt")
-        createROINoSignificance(outputDirPath / "regionsOfInterest_{}.txt".format(fileTag), locationArr, chrDict,
-                                distanceArrReal, maxDiffArr, stateNameList, zScores, roiWidth)
-        done(t0)
-    remove(Path(expFreqPath))
+    _done(verbose, t0)
+    _finish(params, locationArr, distanceArrReal, maxDiffArr, chrDict, stateInfo, outputDirPath, fileTag, pvalBool, roiWidth,
+            expFreqPath, verbose)
     if verbose: print("Total Time:", time() - tTotal, flush=True)
 
 

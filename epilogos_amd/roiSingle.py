@@ -97,7 +97,9 @@ def createTopScoresTxt(filePath, locationArr, scoreArr, nameArr, roiWidth):
     (reference roiSingle.py:95-142)."""
     W = int(roiWidth)
     total = scoreArr.sum(axis=1)                                  # float32, numpy's pairwise order like the reference
-    chrom, w_start, w_end, sc, centre = maxMean(locationArr[:, 0], locationArr[:, 1], locationArr[:, 2], total, W, 100)
+    # locationArr: the reference's [R, 3] object array, or (chromosome, start, end) columns
+    c0, c1, c2 = locationArr if isinstance(locationArr, tuple) else (locationArr[:, 0], locationArr[:, 1], locationArr[:, 2])
+    chrom, w_start, w_end, sc, centre = maxMean(c0, c1, c2, total, W, 100)
     S = scoreArr.shape[1]
     lines = []
     for k in range(len(centre)):
@@ -111,6 +113,21 @@ def createTopScoresTxt(filePath, locationArr, scoreArr, nameArr, roiWidth):
                                                           findSign(v)))
     with open(filePath, "w") as outFile:
         outFile.write("".join(lines))
+
+
+def mainFromArrays(results, outputDir, stateInfo, fileTag, expFreqPath, roiWidth, verbose):
+    """main() on the arrays driver.run_single_group hands back -- {stem: (chrName, scoreArr, _io.Locations)} -- instead
+    of temp_scores_*.npz files: same output file, no 170 B/bin round trip through compressed pickles."""
+    byChr = {v[0]: v for v in results.values()}
+    order = orderChromosomes(list(byChr))
+    scoreArr = np.concatenate([byChr[c][1] for c in order])
+    cols = [byChr[c][2].columns() for c in order]
+    locationArr = tuple(np.concatenate([c[k] for c in cols]) for k in range(3))
+    if not verbose: print("    Regions of interest txt\t", end="", flush=True)
+    createTopScoresTxt(Path(outputDir) / "regionsOfInterest_{}.txt".format(fileTag), locationArr, scoreArr,
+                       getStateNames(stateInfo), roiWidth)
+    if not verbose: print("\t[Done]", flush=True)
+    remove(Path(expFreqPath))
 
 
 def main(outputDir, stateInfo, fileTag, expFreqPath, roiWidth, verbose):

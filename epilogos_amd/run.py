@@ -7,7 +7,10 @@ epilogos_amd/roiAndVisualPairwise.py (pairwiseMetrics, regionsOfInterest, signif
 import os
 import re
 import sys
+import time as _time
 from pathlib import Path, PurePath
+
+_T_START = _time.time()
 
 import click
 
@@ -149,17 +152,25 @@ def main(mode, commandLineBool, inputDirectory, inputDirectory1, inputDirectory2
         dist.init_process_group(backend=dist_backend or ("nccl" if device is not None else "gloo"))
     rank = int(os.environ.get("RANK", "0"))
     say = print if rank == 0 else (lambda *a, **k: None)
+    if os.environ.get("EPILOGOS_TIMING") and rank == 0:
+        import time
+        print("    [timing] %-34s %7.2f s" % ("imports + device init (since process start)", time.time() - _T_START), flush=True)
 
     files = sorted(inputDirPath.glob("*"), key=_natural_key)
     say("State Model =", numStates, " Saliency level =", saliency, " GPUs =", world)
     if mode == "single":
         from .driver import run_single_group
         say("\nSTEP 1-3: background counts -> all-reduce -> scores (bin-range partition over %d GPU(s))" % world)
-        run_single_group(files, numStates, saliency, outputDirPath, fileTag, verbose=False, device=device)
+        _, results = run_single_group(files, numStates, saliency, outputDirPath, fileTag, verbose=False, device=device,
+                                      keep_temp_scores=False)
         if rank == 0:
             say("\nSTEP 4: Finding regions of interest", flush=True)
-            from .roiSingle import main as roiSingle
-            roiSingle(outputDirPath, stateInfo, fileTag, storedExpPath, roiWidth if roiWidth else 50, False)
+            import time
+            t0 = time.perf_counter()
+            from .roiSingle import mainFromArrays as roiSingle
+            roiSingle(results, outputDirPath, stateInfo, fileTag, storedExpPath, roiWidth if roiWidth else 50, False)
+            if os.environ.get("EPILOGOS_TIMING"):
+                print("    [timing] %-34s %7.2f s" % ("STEP 4", time.perf_counter() - t0), flush=True)
     else:
         from .driver import run_paired_groups
         files2 = []
@@ -180,13 +191,17 @@ def main(mode, commandLineBool, inputDirectory, inputDirectory1, inputDirectory2
                 seed = t.cpu().numpy()
             nullSeed = int(seed[0])
         say("\nSTEP 1-3: background counts over [A|B] -> all-reduce -> scores, null groups, deltas (%d GPU(s))" % world)
-        run_paired_groups(files, files2, numStates, saliency, outputDirPath, fileTag, quiescentState, groupSize, nullSeed,
-                          verbose=False, device=device)
+        _, results = run_paired_groups(files, files2, numStates, saliency, outputDirPath, fileTag, quiescentState, groupSize,
+                                       nullSeed, verbose=False, device=device, keep_temps=False)
         if rank == 0:
             say("\nSTEP 4: Generating p-values & regions of interest (figures are not produced)", flush=True)
-            from .roiAndVisualPairwise import main as roiPairwise
-            roiPairwise(inputDirPath.name, inputDirPath2.name, stateInfo, outputDirPath, fileTag, max(numProcesses, 1), pvalBool,
-                        diagnosticBool, numTrials, samplingSize, storedExpPath, roiWidth if roiWidth else 125, False)
+            import time
+            t0 = time.perf_counter()
+            from .roiAndVisualPairwise import mainFromArrays as roiPairwise
+            roiPairwise(results, stateInfo, outputDirPath, fileTag, max(numProcesses, 1), pvalBool, numTrials, samplingSize,
+                        storedExpPath, roiWidth if roiWidth else 125, False)
+            if os.environ.get("EPILOGOS_TIMING"):
+                print("    [timing] %-34s %7.2f s" % ("STEP 4", time.perf_counter() - t0), flush=True)
     if world > 1:
         import torch.distributed as dist
         dist.destroy_process_group()

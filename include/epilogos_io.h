@@ -50,6 +50,16 @@ void epgio_close_table(epgio_table* t);
 int epgio_write_scores(const char* path, const char* loc, const int64_t* loc_off, const float* scores, int64_t R,
                        int32_t S, int32_t threads, int32_t gzip_level);
 
+/* pairwiseMetrics_*.txt.gz of the paired STEP 4 (roiAndVisualPairwise.py:520-573 writeMetrics): one line per bin,
+ *   chromosome \t start \t end \t state name \t "%.5f" of |distance| (float32) \t "+" if distance >= 0 else "-"
+ *   [ \t "%.5e" p-value \t "%.5e" adjusted p-value ]          (pvals and mh both NULL or both given)
+ * chromosome names: table of nchrom strings (chrom + chrom_off[i] .. chrom_off[i+1]) indexed by chrom_idx[r]; state
+ * names likewise, indexed by maxdiff[r] - 1.  Multi-member gzip like epgio_write_scores. */
+int epgio_write_metrics(const char* path, const char* chrom, const int64_t* chrom_off, const int32_t* chrom_idx,
+                        const int64_t* start, const int64_t* end, const char* names, const int64_t* names_off,
+                        const int32_t* maxdiff, const float* dist, const double* pvals, const double* mh, int64_t R,
+                        int32_t threads, int32_t gzip_level);
+
 /* Format n float32 values exactly like Python's "%.5f" % float(v) (correctly rounded, "-0.00000" kept), each followed
  * by `sep`; returns the number of bytes written to buf (cap must be >= 48*n).  Exposed for tests. */
 int64_t epgio_format_f5(const float* v, int64_t n, char sep, char* buf, int64_t cap);

@@ -108,3 +108,36 @@ def test_format_f5_is_pythons_percent_5f():
         want = ["%.5f" % float(v) for v in arr]
         bad = [(float(a), g, w) for a, g, w in zip(arr, got, want) if g != w]
         assert not bad, bad[:5]
+
+
+def test_write_metrics_matches_python_formatting(tmp_path):
+    """pairwiseMetrics lines of the native writer == the reference's str.format template
+    (roiAndVisualPairwise.py:560-569), including -0.0, huge / tiny p-values and more rows than one gzip member."""
+    rng = np.random.default_rng(11)
+    R = 70001
+    chroms = ["chr1", "chr10", "chrX"]
+    ci = np.sort(rng.integers(0, 3, R)).astype(np.int32)
+    start = np.arange(R, dtype=np.int64) * 200
+    end = start + 200
+    names = ["TssA", "Enh G1", "Quies"]
+    md = rng.integers(1, 4, R).astype(np.int32)
+    dist = (rng.normal(0, 3, R) * rng.choice([1e-7, 1e-3, 1, 1e4], R)).astype(np.float32)
+    dist[:4] = [0.0, -0.0, np.float32(2.5e-6), np.float32(-123456.789)]
+    pv = rng.random(R) ** 20
+    pv[:5] = [0.0, 1.0, 1e-300, 5e-324, 0.999995]
+    mh = np.minimum(pv * 3, 1.0)
+    sign = lambda x: "+" if x >= 0 else "-"
+    for with_p in (False, True):
+        out = tmp_path / ("m%d.txt.gz" % with_p)
+        _io.write_metrics(out, chroms, ci, start, end, names, md, dist, pv if with_p else None, mh if with_p else None)
+        got = gzip.open(out, "rb").read().decode().splitlines()
+        assert len(got) == R
+        for i in list(range(200)) + list(rng.integers(0, R, 300)) + [R - 1]:
+            want = "{}\t{}\t{}\t{}\t{:.5f}\t{}".format(chroms[ci[i]], start[i], end[i], names[md[i] - 1], abs(dist[i]), sign(dist[i]))
+            if with_p:
+                want += "\t{:.5e}\t{:.5e}".format(pv[i], mh[i])
+            assert got[i] == want
+    _io.write_metrics(tmp_path / "empty.txt.gz", chroms, [], [], [], names, [], [])
+    assert gzip.open(tmp_path / "empty.txt.gz", "rb").read() == b""
+    with pytest.raises(ValueError):
+        _io.write_metrics(tmp_path / "bad.txt.gz", chroms, [5], [0], [200], names, [1], [0.5])
