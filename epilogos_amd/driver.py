@@ -84,10 +84,27 @@ def _count_rows(files):
 
 
 def _read_parts(files, parts):
-    """readTable of every (file, lo, hi) of this rank, files in parallel (gz inflate is serial per file)."""
+    """readTable of every (file, lo, hi) of this rank, files in parallel (gz inflate is serial per file); hi = None
+    reads to the last complete line, which is what countRows counts (helpers.py:94)."""
     from concurrent.futures import ThreadPoolExecutor
     with ThreadPoolExecutor(max_workers=max(1, min(8, len(parts)))) as pool:
-        return list(pool.map(lambda part: readTable(files[part[0]], (part[1], part[2])), parts))
+        return list(pool.map(lambda part: readTable(files[part[0]], None if part[2] is None else (part[1], part[2])), parts))
+
+
+def _plan_and_read(files, d, tm):
+    """(rows per file, this rank's parts, their parsed tables).  A single rank reads whole files and takes the row counts
+    from the parse instead of a separate gunzip pass per file."""
+    if d.world == 1:
+        tables = _read_parts(files, [(fi, 0, None) for fi in range(len(files))])
+        rows = [t[0].shape[0] for t in tables]
+        tm.lap("parse (row counts included)")
+        return rows, [(fi, 0, rows[fi]) for fi in range(len(files))], tables
+    rows = _count_rows(files)
+    tm.lap("count rows")
+    parts = plan_partition(rows, d.world)[d.rank]
+    tables = _read_parts(files, parts)
+    tm.lap("parse")
+    return rows, parts, tables
 
 
 def _publish(outputDir, kind, fileTag, stem, lo, rank, payload, mine):
@@ -142,13 +159,9 @@ def run_single_group(files, numStates, saliency, outputDir, fileTag, verbose=Fal
     files = [Path(f) for f in files]
     outputDir = Path(outputDir)
     tm = _Timer(d.rank)
-    rows = _count_rows(files)
-    tm.lap("count rows")
-    my_parts = plan_partition(rows, d.world)[d.rank]
+    rows, my_parts, tables = _plan_and_read(files, d, tm)
 
     # STEP 1: local counts over my bin ranges
-    tables = _read_parts(files, my_parts)
-    tm.lap("parse")
     counts = None
     for x, _ in tables:
         c = be.expected_counts(x, numStates, saliency)
@@ -215,13 +228,10 @@ def run_paired_groups(files1, files2, numStates, saliency, outputDir, fileTag, q
     files1, files2 = [Path(f) for f in files1], [Path(f) for f in files2]
     outputDir = Path(outputDir)
     tm = _Timer(d.rank)
-    rows = _count_rows(files1)
-    tm.lap("count rows")
-    my_parts = plan_partition(rows, d.world)[d.rank]
+    rows, my_parts, ta = _plan_and_read(files1, d, tm)
     file_start = np.concatenate([[0], np.cumsum(rows)]).astype(np.int64)
-
-    ta, tb = _read_parts(files1, my_parts), _read_parts(files2, my_parts)
-    tm.lap("parse")
+    tb = _read_parts(files2, my_parts)                       # the second group follows the first one's row ranges
+    tm.lap("parse group 2")
     counts, chunks = None, []
     for (fi, lo, hi), (xa, loc), (xb, _) in zip(my_parts, ta, tb):
         if xb.shape[0] != xa.shape[0]:
