@@ -2,6 +2,7 @@
 (getNumStates :9-17, strToBool :47-60, countRows :80-99, splitRows :102-120, readStates :123-194), minus the pieces that
 belong to ROI/plotting.  States come back as int8 (0-based) instead of the reference's int64: that is the layout the
 GPU kernels stream."""
+import os
 from pathlib import Path
 
 import numpy as np
@@ -35,11 +36,40 @@ def splitRows(totalRows, numProcesses):
     return [(i * totalRows // numProcesses, (i + 1) * totalRows // numProcesses) for i in range(numProcesses)]
 
 
+def _cache_paths(path):
+    """Binary cache of a parsed matrix file: EPILOGOS_CACHE_DIR/<key>.{states,locblob,locoff}.npy, keyed
+    by the file's absolute path, size and modification time so that a changed input is parsed again."""
+    root = os.environ.get("EPILOGOS_CACHE_DIR")
+    if not root:
+        return None
+    import hashlib
+    st = os.stat(path)
+    key = hashlib.sha1("{}|{}|{}".format(os.path.abspath(path), st.st_size, st.st_mtime_ns).encode()).hexdigest()[:20]
+    base = Path(root) / "{}_{}".format(Path(path).name.split(".")[0], key)
+    return [Path(str(base) + ext) for ext in (".states.npy", ".locblob.npy", ".locoff.npy")]
+
+
 def readTable(path, rowsToCalc=None):
     """Rows [lo, hi) of a matrix file through the native multi-threaded parser: int8 0-based states
-    [rows, N] and the rows' first three columns as written (a _io.Locations)."""
-    states, loc = _io.read_table(Path(path), rowsToCalc)
-    return states, loc
+    [rows, N] and the rows' first three columns as written (a _io.Locations).  With EPILOGOS_CACHE_DIR set (the command
+    line's --cache-dir) the parsed file is kept as an int8 [R, N] .npy plus the coordinate side-car and later runs on the
+    same input memory-map it instead of inflating and parsing ~1.7 KB of text per bin again."""
+    cache = _cache_paths(path)
+    if cache is None:
+        return _io.read_table(Path(path), rowsToCalc)
+    if not all(c.exists() for c in cache):
+        states, loc = _io.read_table(Path(path), None)
+        cache[0].parent.mkdir(parents=True, exist_ok=True)
+        for c, arr in zip(cache, (states, loc.blob, loc.offsets)):
+            tmp = Path(str(c) + ".tmp%d.npy" % os.getpid())              # atomic: ranks may fill the cache concurrently
+            np.save(tmp, arr, allow_pickle=False)
+            os.replace(tmp, c)
+    states = np.load(cache[0], mmap_mode="r")
+    loc = _io.Locations(np.load(cache[1], mmap_mode="r"), np.load(cache[2], mmap_mode="r"))
+    lo, hi = (0, states.shape[0]) if rowsToCalc is None else (max(rowsToCalc[0], 0), min(rowsToCalc[1], states.shape[0]))
+    hi = max(hi, lo)
+    part = loc.slice(lo, hi)
+    return np.ascontiguousarray(states[lo:hi]), _io.Locations(np.ascontiguousarray(part.blob), np.ascontiguousarray(part.offsets))
 
 
 def _read_int8(path, rowsToCalc):

@@ -97,9 +97,11 @@ def checkArguments(mode, saliency, inputDirPath, inputDirPath2, outputDirPath, n
 @click.option("--score-mem", "scoreMem", type=int, default=40000, help="SLURM-only; ignored")
 @click.option("--roi-mem", "roiMem", type=int, default=-1, help="SLURM-only; ignored")
 @click.option("--null-seed", "nullSeed", type=int, default=None, help="Seed for the paired-mode null shuffles (default: random)")
+@click.option("--cache-dir", "cacheDir", type=str, default=None,
+              help="Keep parsed input matrices (int8 + coordinates) here; later runs on the same files skip the text parse")
 def main(mode, commandLineBool, inputDirectory, inputDirectory1, inputDirectory2, outputDirectory, stateInfo, saliency,
          numProcesses, exitBool, diagnosticBool, numTrials, samplingSize, quiescentState, groupSize, version, partition,
-         pvalBool, roiWidth, fileTag, expFreqMem, expCombMem, scoreMem, roiMem, nullSeed):
+         pvalBool, roiWidth, fileTag, expFreqMem, expCombMem, scoreMem, roiMem, nullSeed, cacheDir):
     """Information-theoretic navigation of multi-tissue functional genomic annotations -- MI355X scoring engine."""
     if version:
         print("Version:", __version__)
@@ -118,6 +120,8 @@ def main(mode, commandLineBool, inputDirectory, inputDirectory1, inputDirectory2
     if stateInfo is None:
         print("ERROR: [-j, --state-info] is required"); sys.exit()
 
+    if cacheDir:
+        os.environ["EPILOGOS_CACHE_DIR"] = str(Path(cacheDir).resolve())
     numStates = getNumStates(stateInfo)
     quiescentState = numStates - 1 if quiescentState == -1 else quiescentState - 1     # 1-based -> 0-based, 0 -> off
     inputDirPath = Path(inputDirectory if mode == "single" else inputDirectory1)

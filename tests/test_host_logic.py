@@ -247,6 +247,14 @@ def test_cli_single_mode(tmp_path, golden_real, fake_backend, state_info):
     res = CliRunner().invoke(main, ["-l", "-i", str(ind), "-j", str(state_info), "-o", str(out), "-c", "8"])
     assert res.exit_code == 0, res.output
     assert _decompressed(out / "scores_in10_s1_matrix_chr1.txt.gz") == g["s1_text"].tobytes()   # default tag: {dir}_s{sal}
+    # a second run through the binary input cache gives the same bytes
+    out2 = tmp_path / "out_cached"
+    for _ in range(2):
+        res = CliRunner().invoke(main, ["-l", "-i", str(ind), "-j", str(state_info), "-o", str(out2), "--cache-dir", str(tmp_path / "cache")])
+        assert res.exit_code == 0, res.output
+        assert _decompressed(out2 / "scores_in10_s1_matrix_chr1.txt.gz") == g["s1_text"].tobytes()
+    assert len(list((tmp_path / "cache").glob("matrix_chr1_*.npy"))) == 3
+    os.environ.pop("EPILOGOS_CACHE_DIR", None)
     # STEP 4 ran: the reference's regions of interest, and its clean-up of exp_freq / temp_scores (quirk Q4)
     from tests.conftest import load_golden
     assert (out / "regionsOfInterest_in10_s1.txt").read_bytes() == load_golden("roi.npz")["roi_single_w50"].tobytes()

@@ -141,3 +141,30 @@ def test_write_metrics_matches_python_formatting(tmp_path):
     assert gzip.open(tmp_path / "empty.txt.gz", "rb").read() == b""
     with pytest.raises(ValueError):
         _io.write_metrics(tmp_path / "bad.txt.gz", chroms, [5], [0], [200], names, [1], [0.5])
+
+
+def test_binary_input_cache(tmp_path, monkeypatch):
+    """the parsed matrix kept as int8 .npy + coordinate side-car; keyed by path, size and mtime."""
+    rng = np.random.default_rng(2)
+    x = rng.integers(0, 18, size=(300, 11)).astype(np.int8)
+    f = tmp_path / "matrix_chr7.txt.gz"
+    write_tsv(f, x, chrom="chr7", start0=1000)
+    plain_states, plain_loc = helpers.readTable(f, (17, 203))
+    monkeypatch.setenv("EPILOGOS_CACHE_DIR", str(tmp_path / "cache"))
+    for _ in range(2):                                           # first call fills the cache, second one maps it
+        st, loc = helpers.readTable(f, (17, 203))
+        assert st.dtype == np.int8 and st.flags["C_CONTIGUOUS"] and np.array_equal(st, plain_states)
+        assert np.array_equal(loc.blob, plain_loc.blob) and np.array_equal(loc.offsets, plain_loc.offsets)
+    files = sorted(p.name for p in (tmp_path / "cache").iterdir())
+    assert len(files) == 3 and all(n.startswith("matrix_chr7_") for n in files)
+    full, floc = helpers.readTable(f)
+    assert np.array_equal(full, x) and len(floc) == 300
+    assert helpers.readTable(f, (290, 400))[0].shape == (10, 11)           # clipped like the parser clips
+    # a rewritten input is parsed again
+    import os
+    import time
+    x2 = x.copy(); x2[0, 0] = (x2[0, 0] + 1) % 18
+    write_tsv(f, x2, chrom="chr7", start0=1000)
+    os.utime(f, ns=(time.time_ns() + 10**9, time.time_ns() + 10**9))
+    assert np.array_equal(helpers.readTable(f)[0], x2)
+    assert len(list((tmp_path / "cache").iterdir())) == 6
