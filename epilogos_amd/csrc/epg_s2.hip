@@ -5,48 +5,121 @@ namespace epg {
 
 // ---------------------------------------------------------------------------------------------------------------
 // S2 expected: C[i,j] += sum_b h_i*h_j (i != j), h_i*(h_i - 1) (i == j)      (expected.py:146-158 s2Calc)
-// One thread per ordered pair (i, j) (up to 4 pairs per thread for S <= 31), bins staged through LDS in
-// batches; exact integer arithmetic (u64 accumulators).  Reads 2*S bytes per bin.
+// The matrix is symmetric, so one thread per UNORDERED state pair i <= j (171 at S = 18) plus one per state for
+// sum_b h_i (the diagonal's correction).  A batch of 128 bins is staged in LDS as bin PAIRS -- word (i, k) = counts of
+// state i in bins 2k and 2k+1 as two u16 -- so that one v_dot2_u32_u16 adds two bins' products to a 32-bit partial
+// sum: with counts < 4096 (any real N) 128 products stay below 2^32 and the partial sum goes to the u64 accumulator
+// once per batch.  A batch with a larger count takes the plain u64 path.  Exact integer arithmetic either way.
+// Reads 2*S bytes per bin; 15 M bins x 18 states: 0.43 ms (the per-ordered-pair u64 version took 1.5 ms).
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int S2H_BATCH = 128;
+constexpr int S2H_PAIRS = S2H_BATCH / 2;
+constexpr int S2H_ROLES = 3;                 // 256 threads x 3 >= S(S+1)/2 + S for S <= 31
+constexpr int S2H_LD = S2H_PAIRS + 1;        // row stride of the pair matrix in words: odd, rows start on different banks
+typedef unsigned short v2u16 __attribute__((ext_vector_type(2)));
 
 __global__ __launch_bounds__(256) void k_s2_hist_from_binhist(const u16* __restrict__ H, long R, int S,
                                                                u64* __restrict__ counts) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    u32* s_h = reinterpret_cast<u32*>(smem);  // [S2H_BATCH][S] as u32
-    const int SS = S * S;
-    u64 acc[4] = {0, 0, 0, 0};
-    int pi[4], pj[4];
+    u16* s_raw = reinterpret_cast<u16*>(smem);                                   // [S2H_BATCH][S]
+    u32* s_p = reinterpret_cast<u32*>(smem + (((size_t)S2H_BATCH * S * 2 + 15) & ~(size_t)15));   // [S][S2H_LD]
+    // roles: pair (i <= j) for role < npair, row sum of state role - npair for the next S roles; up to S2H_ROLES per thread
+    const int npair = S * (S + 1) / 2;
+    int ti[S2H_ROLES], tj[S2H_ROLES];
+    u64 acc[S2H_ROLES];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int p = threadIdx.x + 256 * k;
-        pi[k] = p < SS ? p / S : -1;
-        pj[k] = p < SS ? p % S : 0;
+    for (int q = 0; q < S2H_ROLES; ++q) {
+        const int role = threadIdx.x + 256 * q;
+        ti[q] = -1;
+        tj[q] = 0;
+        acc[q] = 0;
+        if (role < npair) {
+            int t = role, i = 0;
+            while (t >= S - i) { t -= S - i; ++i; }
+            ti[q] = i;
+            tj[q] = i + t;
+        } else if (role < npair + S) {
+            ti[q] = role - npair;
+            tj[q] = -1;                                                          // sum of h_ti
+        }
     }
+    // a batch is 256*S bytes = 16*S 16-byte words: at most two per thread, requested one batch ahead
     const long nb = (R + S2H_BATCH - 1) / S2H_BATCH;
+    const int nw = 16 * S;
+    const long total_bytes = R * S * 2;
+    auto fetch = [&](long batch, int w) -> uint4 {
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (batch >= nb || w >= nw) return v;
+        const long off = batch * (256L * S) + 16L * w;
+        const char* src = reinterpret_cast<const char*>(H) + off;
+        if (off + 16 <= total_bytes) return *reinterpret_cast<const uint4*>(src);
+        u16 t[8] = {0, 0, 0, 0, 0, 0, 0, 0};                                       // the words around the end of H
+        for (int k = 0; k < 8; ++k)
+            if (off + 2 * k < total_bytes) t[k] = *reinterpret_cast<const u16*>(src + 2 * k);
+        return make_uint4(t[0] | (u32)t[1] << 16, t[2] | (u32)t[3] << 16, t[4] | (u32)t[5] << 16, t[6] | (u32)t[7] << 16);
+    };
+    uint4 pre0 = fetch(blockIdx.x, threadIdx.x), pre1 = fetch(blockIdx.x, threadIdx.x + 256);
     for (long batch = blockIdx.x; batch < nb; batch += gridDim.x) {
         const long r0 = batch * S2H_BATCH;
         const int rows = (int)((R - r0) < S2H_BATCH ? (R - r0) : S2H_BATCH);
         __syncthreads();
-        for (int e = threadIdx.x; e < rows * S; e += 256) s_h[e] = H[r0 * S + e];
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            if (pi[k] < 0) continue;
-            const int i = pi[k], j = pj[k];
-            const u32 dj = (i == j) ? 1u : 0u;
-            u64 a = 0;
-            for (int r = 0; r < rows; ++r) {
-                const u32 hi = s_h[r * S + i];
-                const u32 hj = s_h[r * S + j];
-                a += (u64)hi * (u64)(hj - (hi ? dj : 0u));  // h_i == 0 contributes 0 (no u32 wrap)
+        int big = 0;
+        {
+            uint4* dst = reinterpret_cast<uint4*>(s_raw);
+            if ((int)threadIdx.x < nw) dst[threadIdx.x] = pre0;
+            if ((int)threadIdx.x + 256 < nw) dst[threadIdx.x + 256] = pre1;
+            const u32 m = pre0.x | pre0.y | pre0.z | pre0.w | pre1.x | pre1.y | pre1.z | pre1.w;
+            big = (m & 0xF000F000u) != 0;
+            pre0 = fetch(batch + gridDim.x, threadIdx.x);                         // lands while this batch is counted
+            pre1 = fetch(batch + gridDim.x, threadIdx.x + 256);
+        }
+        big = __syncthreads_or(big);
+        if (!big) {
+            for (int e = threadIdx.x; e < S * S2H_PAIRS; e += 256) {
+                const int i = e / S2H_PAIRS, k = e - i * S2H_PAIRS;
+                s_p[i * S2H_LD + k] = (u32)s_raw[(2 * k) * S + i] | ((u32)s_raw[(2 * k + 1) * S + i] << 16);
             }
-            acc[k] += a;
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < S2H_ROLES; ++q) {
+                if (ti[q] < 0) continue;
+                const u32* pi = s_p + ti[q] * S2H_LD;
+                u32 part = 0;
+                if (tj[q] >= 0) {
+                    const u32* pj = s_p + tj[q] * S2H_LD;
+#pragma unroll 8
+                    for (int k = 0; k < S2H_PAIRS; ++k)
+                        part = __builtin_amdgcn_udot2(__builtin_bit_cast(v2u16, pi[k]), __builtin_bit_cast(v2u16, pj[k]), part, false);
+                } else {
+#pragma unroll 8
+                    for (int k = 0; k < S2H_PAIRS; ++k)
+                        part = __builtin_amdgcn_udot2(__builtin_bit_cast(v2u16, pi[k]), __builtin_bit_cast(v2u16, 0x00010001u), part, false);
+                }
+                acc[q] += part;
+            }
+        } else {                                                                 // counts >= 4096: 64-bit products
+#pragma unroll
+            for (int q = 0; q < S2H_ROLES; ++q) {
+                if (ti[q] < 0) continue;
+                u64 a = 0;
+                for (int r = 0; r < rows; ++r) {
+                    const u64 hi = s_raw[r * S + ti[q]];
+                    a += tj[q] >= 0 ? hi * (u64)s_raw[r * S + tj[q]] : hi;
+                }
+                acc[q] += a;
+            }
         }
     }
+    // C[i,j] = C[j,i] = sum h_i h_j;  C[i,i] = sum h_i^2 - sum h_i
 #pragma unroll
-    for (int k = 0; k < 4; ++k)
-        if (pi[k] >= 0 && acc[k]) atomicAdd(&counts[pi[k] * S + pj[k]], acc[k]);
+    for (int q = 0; q < S2H_ROLES; ++q) {
+        if (ti[q] < 0 || !acc[q]) continue;
+        if (tj[q] < 0) atomicAdd(&counts[ti[q] * S + ti[q]], (u64)0 - acc[q]);    // two's complement: adds -sum h_i
+        else {
+            atomicAdd(&counts[ti[q] * S + tj[q]], acc[q]);
+            if (ti[q] != tj[q]) atomicAdd(&counts[tj[q] * S + ti[q]], acc[q]);
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -64,6 +137,11 @@ __global__ void k_s2_tables(const float* __restrict__ q, int S, long perms, int 
         const double qd = (double)q[t];
         LPQ[t] = qd == 0.0 ? LPQ_MASKED : log2((double)perms * qd);
     }
+    if (t == 0) {                                   // LPQ[S*S] = number of masked (q == 0) entries: selects the score kernel
+        int nz = 0;
+        for (int e = 0; e < S * S; ++e) nz += q[e] == 0.0f;
+        LPQ[S * S] = (double)nz;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -74,7 +152,8 @@ __global__ void k_s2_tables(const float* __restrict__ q, int S, long perms, int 
 template <typename OT>
 __global__ __launch_bounds__(256) void k_score_s2_from_hist(const u16* __restrict__ H, long R, int S, double inv_perms,
                                                              int maxc, const double* __restrict__ gLH,
-                                                             const double* __restrict__ gLPQ, OT* __restrict__ out) {
+                                                             const double* __restrict__ gLPQ, OT* __restrict__ out,
+                                                             int fast_exists) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // layout: LPQ [S*S] doubles | per wave: lh [BPW*S] doubles | per wave: hh [BPW*S] u32
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -82,6 +161,7 @@ __global__ __launch_bounds__(256) void k_score_s2_from_hist(const u16* __restric
     double* s_lpq = reinterpret_cast<double*>(smem);
     double* s_lh = s_lpq + S * S + wave * BPW * S;
     u32* s_hh = reinterpret_cast<u32*>(s_lpq + S * S + 4 * BPW * S) + wave * BPW * S;
+    if (fast_exists && gLPQ[S * S] == 0.0) return;   // no masked entry and a fast instantiation for this S: that one runs
     for (int e = threadIdx.x; e < S * S; e += 256) s_lpq[e] = gLPQ[e];
     __syncthreads();
 
@@ -119,6 +199,74 @@ __global__ __launch_bounds__(256) void k_score_s2_from_hist(const u16* __restric
             }
         }
         if (valid) out[row * S + j] = (OT)acc;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// S2 score when no q[i,j] is zero (every whole-genome background): the sum over i is linear in the bin's counts once the
+// logs are split,
+//     sum_i h_i * other_ij * (LH[h_i] + L_ij - LPQ[i,j])
+//   = h_j * [ sum_i h_i * (LH[h_i] - LPQ[i,j]) + LH[h_j] * sum_i h_i ]   (all i as if i != j)
+//     - h_j * h_j * (2 LH[h_j] - LPQ[j,j]) + h_j * (h_j - 1) * (LH[h_j] + LH[h_j - 1] - LPQ[j,j])   (the diagonal put right)
+// so a lane (bin, j) keeps column j of LPQ in registers and does one subtract and one fma per i on the bin's
+// (h_i, LH[h_i]) pairs, which sit in LDS and are broadcast to the S lanes of the bin: ~2 float64 operations per term
+// instead of ~8 instructions with a per-term mask.  Same masked-zero semantics: h_i == 0 and h_j == 0 give exact zeros.
+// Float64 throughout; the order of the sum differs from the reference's, the result by ~1e-13 relative.
+// ---------------------------------------------------------------------------------------------------------------
+template <int S, typename OT, bool LDS_LH>
+__global__ __launch_bounds__(256) void k_score_s2_fast(const u16* __restrict__ H, long R, double inv_perms, int maxc,
+                                                        const double* __restrict__ gLH, const double* __restrict__ gLPQ,
+                                                        OT* __restrict__ out) {
+    if (gLPQ[S * S] != 0.0) return;                  // some q == 0: the general kernel runs instead
+    constexpr int BPW = 64 / S;
+    __shared__ double2 s_hl[4][BPW * S];
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double* s_LH = reinterpret_cast<double*>(smem);  // log2 table in LDS when it fits (maxc < 4096): the gather per count
+    if (LDS_LH) {                                    // is then ~100 cycles instead of an L2 round trip on the critical path
+        for (int e = threadIdx.x; e <= maxc; e += 256) s_LH[e] = gLH[e];
+        __syncthreads();
+    }
+    const double* LH = LDS_LH ? s_LH : gLH;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int bsub = lane / S, j = lane - bsub * S;
+    const bool active = bsub < BPW;
+    double lpq[S];
+#pragma unroll
+    for (int i = 0; i < S; ++i) lpq[i] = gLPQ[i * S + (active ? j : 0)];
+    const double lpqjj = gLPQ[(active ? j : 0) * (S + 1)];
+    const double2* hl = &s_hl[wave][(active ? bsub : 0) * S];
+    const long ngroups = (R + BPW - 1) / BPW;
+    const long stride = (long)gridDim.x * 4;
+    long grp = (long)blockIdx.x * 4 + wave;
+    auto load_h = [&](long g) -> u32 {
+        const long row = g * BPW + bsub;
+        return (g < ngroups && active && row < R) ? (u32)H[row * S + j] : 0u;
+    };
+    u32 hnext = load_h(grp);
+    for (; grp < ngroups; grp += stride) {
+        const long row = grp * BPW + bsub;
+        const bool valid = active && row < R;
+        u32 hj = hnext;
+        hnext = load_h(grp + stride);                // the next group's counts travel while this one is scored
+        if (hj > (u32)maxc) hj = (u32)maxc;
+        const double lj = LH[hj];
+        const double ljm1 = LH[hj ? hj - 1 : 0];
+        const double dj = (double)hj;
+        __builtin_amdgcn_wave_barrier();
+        if (active) s_hl[wave][bsub * S + j] = make_double2(dj, lj);
+        __builtin_amdgcn_wave_barrier();
+        double t = 0.0, n = 0.0;
+#pragma unroll
+        for (int i = 0; i < S; ++i) {
+            const double2 v = hl[i];
+            t = fma(v.x, v.y - lpq[i], t);
+            n += v.x;
+        }
+        const double all = fma(lj, n, t);
+        const double diag_as_off = dj * (2.0 * lj - lpqjj);
+        const double diag = (dj - 1.0) * (lj + ljm1 - lpqjj);
+        const double sc = hj ? dj * inv_perms * (all - diag_as_off + diag) : 0.0;
+        if (valid) out[row * S + j] = (OT)sc;
     }
 }
 
@@ -195,15 +343,16 @@ int hist_s2_from_binhist_impl(const uint16_t* H, int64_t R, int32_t S, int64_t* 
     if (R == 0) return EPG_OK;
     if (!H || !counts) return fail(EPG_ERR_INVALID_ARG, "hist_s2: NULL argument");
     const long nb = (R + S2H_BATCH - 1) / S2H_BATCH;
-    long blocks = nb < num_cus() * 4L ? nb : num_cus() * 4L;
-    const size_t shmem = (size_t)S2H_BATCH * S * 4;
+    if (reinterpret_cast<uintptr_t>(H) & 15) return fail(EPG_ERR_INVALID_ARG, "hist_s2: H must be 16-byte aligned");
+    long blocks = nb < num_cus() * 8L ? nb : num_cus() * 8L;
+    const size_t shmem = (((size_t)S2H_BATCH * S * 2 + 15) & ~(size_t)15) + (size_t)S * S2H_LD * 4;
     hipLaunchKernelGGL(k_s2_hist_from_binhist, dim3((int)blocks), dim3(256), shmem, st, H, (long)R, S,
                        reinterpret_cast<u64*>(counts));
     EPG_LAUNCH_CHECK("k_s2_hist_from_binhist");
     return EPG_OK;
 }
 
-int64_t s2_table_bytes(int maxc, int S) { return align_up((int64_t)(maxc + 1) * 8, 256) + align_up((int64_t)S * S * 8, 256); }
+int64_t s2_table_bytes(int maxc, int S) { return align_up((int64_t)(maxc + 1) * 8, 256) + align_up((int64_t)(S * S + 1) * 8, 256); }
 
 int score_s2_from_hist_impl(const uint16_t* H, int64_t R, int32_t N, int32_t S, int64_t perms, const float* q,
                             double* out64, float* out32, void* ws, int64_t ws_bytes, hipStream_t st) {
@@ -222,9 +371,24 @@ int score_s2_from_hist_impl(const uint16_t* H, int64_t R, int32_t N, int32_t S, 
     if (blocks > num_cus() * 8L) blocks = num_cus() * 8L;
     const size_t shmem = (size_t)S * S * 8 + (size_t)4 * BPW * S * 8 + (size_t)4 * BPW * S * 4;
     const double inv = 1.0 / (double)perms;
-    if (out32) hipLaunchKernelGGL((k_score_s2_from_hist<float>), dim3((int)blocks), dim3(256), shmem, st, H, (long)R, S, inv, N, LH, LPQ, out32);
-    if (out64) hipLaunchKernelGGL((k_score_s2_from_hist<double>), dim3((int)blocks), dim3(256), shmem, st, H, (long)R, S, inv, N, LH, LPQ, out64);
+    // both kernels are launched; LPQ[S*S] (the number of q == 0 entries, known on the device only) decides which works
+    const int fast = S == 15 || S == 18 || S == 25;
+    if (out32) hipLaunchKernelGGL((k_score_s2_from_hist<float>), dim3((int)blocks), dim3(256), shmem, st, H, (long)R, S, inv, N, LH, LPQ, out32, fast);
+    if (out64) hipLaunchKernelGGL((k_score_s2_from_hist<double>), dim3((int)blocks), dim3(256), shmem, st, H, (long)R, S, inv, N, LH, LPQ, out64, fast);
     EPG_LAUNCH_CHECK("k_score_s2_from_hist");
+    const bool lds_lh = N < 4096;
+    const size_t lh_bytes = lds_lh ? (size_t)(N + 1) * 8 : 0;
+#define EPG_S2_FAST(SV)                                                                                                         \
+    if (S == SV && lds_lh) {                                                                                                    \
+        if (out32) hipLaunchKernelGGL((k_score_s2_fast<SV, float, true>), dim3((int)blocks), dim3(256), lh_bytes, st, H, (long)R, inv, N, LH, LPQ, out32);   \
+        if (out64) hipLaunchKernelGGL((k_score_s2_fast<SV, double, true>), dim3((int)blocks), dim3(256), lh_bytes, st, H, (long)R, inv, N, LH, LPQ, out64);  \
+    } else if (S == SV) {                                                                                                       \
+        if (out32) hipLaunchKernelGGL((k_score_s2_fast<SV, float, false>), dim3((int)blocks), dim3(256), 0, st, H, (long)R, inv, N, LH, LPQ, out32);   \
+        if (out64) hipLaunchKernelGGL((k_score_s2_fast<SV, double, false>), dim3((int)blocks), dim3(256), 0, st, H, (long)R, inv, N, LH, LPQ, out64);  \
+    }
+    EPG_S2_FAST(15) EPG_S2_FAST(18) EPG_S2_FAST(25)
+#undef EPG_S2_FAST
+    EPG_LAUNCH_CHECK("k_score_s2_fast");
     return EPG_OK;
 }
 

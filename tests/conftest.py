@@ -19,6 +19,14 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def free_port():
+    """A TCP port that is free right now, for torch.distributed.run rendezvous in the multi-process tests."""
+    import socket
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        return sock.getsockname()[1]
+
+
 def load_golden(name):
     return dict(np.load(GOLDEN / name, allow_pickle=False))
 

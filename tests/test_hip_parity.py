@@ -241,6 +241,23 @@ def test_s2_random_vs_oracle(eng, N, R):
 
 
 # ---------------------------------------------------------------------------------------------- paired extras
+@pytest.mark.parametrize("S_,R,hi", [(18, 1000, 834), (5, 129, 4096), (25, 300, 900), (31, 257, 4095), (18, 700, 65536), (30, 1, 70)])
+def test_s2_counts_from_arbitrary_histograms(eng, S_, R, hi):
+    """k_s2_hist_from_binhist on histograms it is handed directly: every S up to 31 (one to three pair roles per
+    thread), batches that end mid-way, and counts >= 4096, which leave the 32-bit dot-product path."""
+    rng = np.random.default_rng(S_ * 1000 + R)
+    h = rng.integers(0, hi, size=(R, S_)).astype(np.uint16)
+    if hi > 4096:
+        h[: R // 2] %= 4096                        # both paths within one call
+    H = torch.from_numpy(h.view(np.int16)).cuda()
+    c = eng.hist_s2_from_binhist(H, S_)
+    h64 = h.astype(np.int64)
+    want = h64.T @ h64 - np.diag(h64.sum(axis=0))
+    assert np.array_equal(_np(c).reshape(S_, S_), want)
+    c = eng.hist_s2_from_binhist(H, S_, counts=c)  # accumulates
+    assert np.array_equal(_np(c).reshape(S_, S_), 2 * want)
+
+
 def test_pair_finish_and_quiescent(eng, golden_pair):
     g = golden_pair
     for sal in (1, 2):

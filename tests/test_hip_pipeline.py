@@ -4,6 +4,8 @@ import gzip
 import numpy as np
 import pytest
 
+from tests.conftest import free_port
+
 torch = pytest.importorskip("torch")
 
 from tests.test_host_logic import write_tsv
@@ -142,7 +144,7 @@ def test_two_ranks_on_one_gpu_match_one_rank(tmp_path, golden_real):
     outs = {}
     for world in (1, 2):
         out = tmp_path / ("out%d" % world)
-        port = str(29700 + os.getpid() % 200 + world)
+        port = str(free_port())
         env = dict(os.environ, PYTHONPATH=str(root), EPILOGOS_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr",
                "127.0.0.1", "--master-port", port, "-m", "epilogos_amd.run", "-l", "-i", str(ind), "-j", str(meta), "-o", str(out),

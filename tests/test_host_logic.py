@@ -10,6 +10,8 @@ from pathlib import Path
 import numpy as np
 import pytest
 
+from tests.conftest import free_port
+
 from epilogos_amd import backend, driver, helpers
 from tests.fake_backend import OracleBackend
 
@@ -219,7 +221,7 @@ def test_two_rank_gloo_paired_matches_single_process(tmp_path, golden_pair):
     for world in (1, 2):
         out = tmp_path / ("out%d" % world)
         out.mkdir()
-        port = str(29600 + os.getpid() % 300 + world)
+        port = str(free_port())
         env = dict(os.environ, PYTHONPATH=str(ROOT), MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
                "--master-addr", "127.0.0.1", "--master-port", port, str(ROOT / "tests" / "gloo_worker.py"), str(ind), str(out)]
