@@ -3,9 +3,8 @@
 // the per-state counts of the two groups enter the scores, so the kernel draws the group membership directly:
 // sequential selection sampling over the row's columns (column c joins group A with probability
 // need_A / remaining, group B with need_B / remaining) is exactly the law of (first ga, next gb) of a uniform
-// permutation.  Randomness: Philox4x32-10 keyed by the seed, counter = (global row, column block) -- the result
-// depends only on (seed, row0 + row), never on the launch geometry or on which GPU owns the row.
-// One lane per row; the lane's two histograms live in LDS as private uint16 columns (no atomics).  gfx950 only.
+// permutation.  Randomness: Philox4x32-10 keyed by the seed, counter = (global row, group, column block) -- the result
+// depends only on (seed, row0 + row), never on the launch geometry or on which GPU owns the row.  gfx950 only.
 #include "epg_common.h"
 
 namespace epg {
@@ -22,43 +21,100 @@ __device__ __forceinline__ void philox4x32_10(u32 (&c)[4], u32 k0, u32 k1) {
     }
 }
 
+constexpr int NH_CH = 64;                 // columns per staged chunk
+constexpr int NH_LD = 80;                 // bytes per staged row: 16-lane groups of a ds_read_b128 then cover all 64 banks
+
+// One lane per row, a wave owns 64 rows.  The rows' state bytes are read coalesced (four lanes fetch 64 contiguous bytes
+// of a row, sixteen rows per instruction, the next chunk requested while the current one is processed) and handed over
+// through the wave's LDS slot, so that every byte is fetched once; a lane reading its own row directly touches 64
+// different cache lines per instruction and was 10x slower.  The two group histograms of a row are the low and high
+// halves of one uint32 counter per state, [state][lane] in LDS: one ds_add_u32 per column, no read-modify-write.
+// Philox counter = (global row, source group, block of four columns): a pure function of (seed, global row).
 __global__ __launch_bounds__(256) void k_null_hist(const char* __restrict__ XA, int NA, long ldxa, const char* __restrict__ XB,
                                                     int NB, long ldxb, long R, int S, int ga, int gb, u64 seed, long row0,
                                                     u16* __restrict__ HA, u16* __restrict__ HB) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    u16* h = reinterpret_cast<u16*>(smem);   // [2][S][256]
-    const int tid = threadIdx.x;
-    const long row = (long)blockIdx.x * 256 + tid;
-    for (int e = tid; e < 2 * S * 256; e += 256) h[e] = 0;
+    u32* hist = reinterpret_cast<u32*>(smem);                                    // [S + 1][256], row S takes non-states
+    char* stage = smem + (size_t)(S + 1) * 256 * 4;                              // [256][NH_LD]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long wrow0 = (long)blockIdx.x * 256 + 64 * wave;                       // first row of this wave
+    const long row = wrow0 + lane;
+    for (int e = tid; e < (S + 1) * 256; e += 256) hist[e] = 0;
     __syncthreads();
-    if (row < R) {
-        const u64 grow = (u64)(row0 + row);
-        const int M = NA + NB;
-        u32 needA = (u32)ga, needB = (u32)gb, rem = (u32)M;
-        const char* pa = XA + row * ldxa;
-        const char* pb = XB + row * ldxb;
-        for (int c0 = 0; c0 < M && (needA | needB); c0 += 4) {
-            u32 ctr[4] = {(u32)grow, (u32)(grow >> 32), (u32)(c0 >> 2), 0u};
-            philox4x32_10(ctr, (u32)seed, (u32)(seed >> 32));
+    char* wstage = stage + (size_t)64 * wave * NH_LD;
+    const u64 grow = (u64)(row0 + row);
+    u32 needA = (u32)ga, needB = (u32)gb, rem = (u32)(NA + NB);
+    // staging role of this lane: rows (lane >> 2) + 16 k of the wave, 16-byte piece lane & 3 of the 64-byte chunk
+    const int piece = lane & 3, srow = lane >> 2;
+    for (int g = 0; g < 2; ++g) {
+        const char* X = g ? XB : XA;
+        const int Ng = g ? NB : NA;
+        const long ldx = g ? ldxb : ldxa;
+        auto load_chunk = [&](int c0, uint4 (&v)[4]) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const int c = c0 + k;
-                if (c >= M) break;
-                const u32 pick = (u32)(((u64)ctr[k] * rem) >> 32);      // uniform in [0, rem)
-                const int x = (int)(unsigned char)(c < NA ? pa[c] : pb[c - NA]);
-                if (pick < needA) {
-                    if (x < S) h[(0 * S + x) * 256 + tid] += 1;
-                    --needA;
-                } else if (pick < needA + needB) {
-                    if (x < S) h[(1 * S + x) * 256 + tid] += 1;
-                    --needB;
+                const long r = wrow0 + srow + 16 * k;
+                const long c = c0 + 16 * piece;
+                v[k] = make_uint4(~0u, ~0u, ~0u, ~0u);                          // 0xFF: not a state
+                if (r < R && c < Ng) {
+                    const char* src = X + r * ldx + c;
+                    if (c + 16 <= ldx) v[k] = *reinterpret_cast<const uint4*>(src);   // whole piece inside the row's pitch
+                    else {
+                        unsigned char t[16];
+                        for (int q = 0; q < 16; ++q) t[q] = c + q < Ng ? (unsigned char)src[q] : 0xFF;
+                        v[k] = make_uint4(t[0] | t[1] << 8 | t[2] << 16 | (u32)t[3] << 24, t[4] | t[5] << 8 | t[6] << 16 | (u32)t[7] << 24,
+                                          t[8] | t[9] << 8 | t[10] << 16 | (u32)t[11] << 24, t[12] | t[13] << 8 | t[14] << 16 | (u32)t[15] << 24);
+                    }
                 }
-                --rem;
+            }
+        };
+        uint4 pre[4];
+        load_chunk(0, pre);
+        for (int c0 = 0; c0 < Ng; c0 += NH_CH) {
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int k = 0; k < 4; ++k) *reinterpret_cast<uint4*>(wstage + (srow + 16 * k) * NH_LD + 16 * piece) = pre[k];
+            __builtin_amdgcn_wave_barrier();
+            if (c0 + NH_CH < Ng) load_chunk(c0 + NH_CH, pre);                   // next chunk: in flight during this one
+            uint4 mine[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) mine[k] = *reinterpret_cast<const uint4*>(wstage + lane * NH_LD + 16 * k);
+            const u32 w[16] = {mine[0].x, mine[0].y, mine[0].z, mine[0].w, mine[1].x, mine[1].y, mine[1].z, mine[1].w,
+                               mine[2].x, mine[2].y, mine[2].z, mine[2].w, mine[3].x, mine[3].y, mine[3].z, mine[3].w};
+            if (row < R && (needA | needB)) {
+#pragma unroll
+                for (int b4 = 0; b4 < 16; ++b4) {
+                    const int cb = c0 + 4 * b4;
+                    if (cb >= Ng) break;                                         // wave-uniform
+                    u32 ctr[4] = {(u32)grow, (u32)(grow >> 32), (u32)(cb >> 2), (u32)g};
+                    philox4x32_10(ctr, (u32)seed, (u32)(seed >> 32));
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        if (cb + k >= Ng) break;                                 // wave-uniform
+                        const u32 pick = (u32)(((u64)ctr[k] * rem) >> 32);      // uniform in [0, rem)
+                        u32 x = (w[b4] >> (8 * k)) & 0xffu;
+                        x = x < (u32)S ? x : (u32)S;
+                        const bool inA = pick < needA, inB = !inA && pick < needA + needB;
+                        const u32 val = inA ? 1u : (inB ? 0x10000u : 0u);
+                        atomicAdd(&hist[x * 256 + tid], val);                    // own column of the counter matrix: no contention
+                        needA -= inA;
+                        needB -= inB;
+                        --rem;
+                    }
+                }
+            } else {
+                rem -= (u32)((Ng - c0) < NH_CH ? (Ng - c0) : NH_CH);
             }
         }
-        for (int s = 0; s < S; ++s) {
-            HA[row * S + s] = h[(0 * S + s) * 256 + tid];
-            HB[row * S + s] = h[(1 * S + s) * 256 + tid];
+    }
+    __builtin_amdgcn_wave_barrier();
+    // rows of this wave back to [row][state], coalesced
+    for (int e = lane; e < 64 * S; e += 64) {
+        const int r = e / S, st = e - r * S;
+        if (wrow0 + r < R) {
+            const u32 v = hist[st * 256 + 64 * wave + r];
+            HA[(wrow0 + r) * S + st] = (u16)(v & 0xffffu);
+            HB[(wrow0 + r) * S + st] = (u16)(v >> 16);
         }
     }
 }
@@ -73,7 +129,7 @@ int null_hist_impl(const int8_t* XA, int32_t NA, int64_t ldxa, const int8_t* XB,
     if (NA + NB > 65535) return fail(EPG_ERR_UNSUPPORTED, "null_hist: more than 65535 columns");
     if (R == 0) return EPG_OK;
     if (!XA || !XB || !HA || !HB) return fail(EPG_ERR_INVALID_ARG, "null_hist: NULL argument");
-    const size_t shmem = (size_t)2 * S * 256 * 2;
+    const size_t shmem = (size_t)(S + 1) * 256 * 4 + (size_t)256 * NH_LD;
     hipLaunchKernelGGL(k_null_hist, dim3((unsigned)((R + 255) / 256)), dim3(256), shmem, st, reinterpret_cast<const char*>(XA), NA,
                        (long)ldxa, reinterpret_cast<const char*>(XB), NB, (long)ldxb, (long)R, S, ga, gb, (u64)seed, (long)row0, HA, HB);
     EPG_LAUNCH_CHECK("k_null_hist");

@@ -144,6 +144,39 @@ def test_null_hist_properties(eng):
     assert (hag.sum(axis=1) == g).all() and (hbg.sum(axis=1) == g).all() and (hag + hbg <= tot).all()
 
 
+@pytest.mark.parametrize("packed", [False, True])
+def test_null_hist_wide_rows(eng, packed):
+    """The 379 + 342 split of the headline matrix: several 64-column chunks per group, a last partial chunk, a Philox
+    block cut by the end of a group (379 = 4 * 94 + 3), rows that do not fill the last block, bytes that are not states,
+    and rows at pitch N (pieces that cross the end of a row go through the byte path)."""
+    R, NA, NB = 1000, 379, 342
+    xa = synth_states(R, NA, seed=11)
+    xb = synth_states(R, NB, seed=12)
+    xa[5, 3] = -1
+    xb[7, 341] = 25
+    if packed:
+        XA = torch.from_numpy(xa.copy()).cuda()
+        XB = torch.from_numpy(xb.copy()).cuda()
+    else:
+        XA, XB = eng.states_to_device(xa), eng.states_to_device(xb)
+    tot = onp.bin_hist(np.concatenate([xa, xb], axis=1), S).astype(np.int64)
+    HA, HB = eng.null_hist(XA, NA, XB, NB, S, NA, NB, seed=7)
+    ha, hb = eng.hist_to_numpy(HA).astype(np.int64), eng.hist_to_numpy(HB).astype(np.int64)
+    assert np.array_equal(ha + hb, tot)
+    ok = np.ones(R, dtype=bool); ok[[5, 7]] = False
+    assert (ha[ok].sum(axis=1) == NA).all() and (hb[ok].sum(axis=1) == NB).all()
+    assert ha[5].sum() + hb[5].sum() == NA + NB - 1 and ha[7].sum() + hb[7].sum() == NA + NB - 1
+    # the same rows through the padded layout give the same draws
+    HA2, HB2 = eng.null_hist(eng.states_to_device(xa), NA, eng.states_to_device(xb), NB, S, NA, NB, seed=7)
+    assert torch.equal(HA, HA2) and torch.equal(HB, HB2)
+    # mean of group A's count of the dominant state = NA / (NA + NB) of the row's total
+    frac = ha[:, 17].sum() / tot[:, 17].sum()
+    assert abs(frac - NA / (NA + NB)) < 0.005
+    HAg, HBg = eng.null_hist(XA, NA, XB, NB, S, 100, 100, seed=7)
+    hag, hbg = eng.hist_to_numpy(HAg).astype(np.int64), eng.hist_to_numpy(HBg).astype(np.int64)
+    assert (hag[ok].sum(axis=1) == 100).all() and (hbg[ok].sum(axis=1) == 100).all() and (hag + hbg <= tot).all()
+
+
 def test_null_hist_is_a_uniform_shuffle(eng):
     """Same row repeated: the count of state s in group A is hypergeometric(M, K_s, NA) -- check mean and variance,
     and compare with numpy's argsort-of-uniforms shuffle (the reference's method, helpers.py:183-184)."""
