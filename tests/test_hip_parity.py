@@ -241,6 +241,28 @@ def test_s2_random_vs_oracle(eng, N, R):
 
 
 # ---------------------------------------------------------------------------------------------- paired extras
+@pytest.mark.parametrize("packed", [False, True])
+def test_quiescent_wide_rows(eng, packed):
+    """Rows of 379 + 342 bytes: all-quiescent rows, and rows with exactly one other state at the first byte, the last
+    byte, either side of the 256-byte step and in group B only; padded and packed (unaligned rows) layouts."""
+    R, NA, NB, q = 300, 379, 342, 17
+    xa = np.full((R, NA), q, dtype=np.int8)
+    xb = np.full((R, NB), q, dtype=np.int8)
+    spots = [(10, "a", 0), (11, "a", NA - 1), (12, "a", 255), (13, "a", 256), (14, "b", 0), (15, "b", NB - 1), (16, "b", 300),
+             (17, "a", 15), (18, "a", 16), (19, "b", 336)]
+    for r, grp, c in spots:
+        (xa if grp == "a" else xb)[r, c] = 3
+    xa[100:200] = synth_states(100, NA, seed=5)
+    if packed:
+        XA, XB = torch.from_numpy(xa.copy()).cuda(), torch.from_numpy(xb.copy()).cuda()
+    else:
+        XA, XB = eng.states_to_device(xa), eng.states_to_device(xb)
+    want = onp.quiescent_mask(xa, xb, q)
+    assert want.sum() == R - len(spots) - 100
+    assert np.array_equal(_np(eng.quiescent(XA, NA, XB, NB, q)).astype(bool), want)
+    assert not _np(eng.quiescent(XA, NA, XB, NB, 3)).any()
+
+
 @pytest.mark.parametrize("S_,R,hi", [(18, 1000, 834), (5, 129, 4096), (25, 300, 900), (31, 257, 4095), (18, 700, 65536), (30, 1, 70)])
 def test_s2_counts_from_arbitrary_histograms(eng, S_, R, hi):
     """k_s2_hist_from_binhist on histograms it is handed directly: every S up to 31 (one to three pair roles per

@@ -65,3 +65,18 @@ if "null" in a.what:
     bench.generate_shard(torch, XB, NB, S, 0)
     t, _ = timed(lambda: engine.null_hist(XA, NA, XB, NB, S, NA, NB, seed=1))
     print("paired null shuffle: %8.3f ms for %d bins x (%d+%d) -> %.2f Mbins/s" % (t, R, NA, NB, R / t / 1e3))
+if "pair" in a.what:
+    R, NA, NB = a.bins, 379, 342
+    sa = torch.randn((R, S), dtype=torch.float32, device="cuda")
+    sb = torch.randn((R, S), dtype=torch.float32, device="cuda")
+    t, (delta, _) = timed(lambda: engine.pair_finish(sa, sb))
+    print("pair_finish        : %8.3f ms for %d bins -> %.2f Gbins/s (%.0f GB/s of its 3*72+4 B/bin)" % (t, R, R / t / 1e6, R * 220 / t / 1e6))
+    t, _ = timed(lambda: engine.pair_metrics(delta, roundtrip=True))
+    print("pair_metrics       : %8.3f ms for %d bins -> %.2f Gbins/s (%.0f GB/s of its 72+8 B/bin)" % (t, R, R / t / 1e6, R * 80 / t / 1e6))
+    del sa, sb, delta
+    torch.cuda.empty_cache()
+    XA, XB = engine.alloc_states(R, NA), engine.alloc_states(R, NB)
+    bench.generate_shard(torch, XA, NA, S, 0)
+    bench.generate_shard(torch, XB, NB, S, 0)
+    t, _ = timed(lambda: engine.quiescent(XA, NA, XB, NB, S - 1))
+    print("quiescent          : %8.3f ms for %d bins x (%d+%d) -> %.2f Gbins/s (%.0f GB/s)" % (t, R, NA, NB, R / t / 1e6, R * (NA + NB) / t / 1e6))
