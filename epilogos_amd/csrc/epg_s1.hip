@@ -8,25 +8,32 @@ namespace epg {
 // K1: X[R, ldx] int8 -> H[R, S] uint16 (+ counts[S] += column sums).  HBM-bound: N bytes read, 2*S written per bin.
 // Restates np.unique(row, return_counts=True) of scores.py:341/444 and expected.py:111-113,152.
 // ---------------------------------------------------------------------------------------------------------------
-// Store `nbytes` (a multiple of 4) staged in the wave's LDS buffer to `dst` (16-byte aligned): whole 16-byte chunks
+// Store `nbytes` (a multiple of 2) staged in the wave's LDS buffer to `dst` (16-byte aligned): whole 16-byte chunks
 // with dwordx4 stores -- consecutive lanes, consecutive chunks, so every store instruction covers whole 128-byte
-// lines -- and a dword tail for a short last super-tile.
+// lines -- then a dword tail and, for an odd number of uint16 (odd S, odd number of rows), the last two bytes.
 __device__ __forceinline__ void store_staged(const char* lds, char* dst, int nbytes, int lane) {
     const int nchunks = nbytes >> 4;
     for (int c = lane; c < nchunks; c += 64)
         *reinterpret_cast<uint4*>(dst + 16 * c) = *reinterpret_cast<const uint4*>(lds + 16 * c);
     const int tail0 = nchunks << 4;
-    for (int o = tail0 + 4 * lane; o < nbytes; o += 256)
+    for (int o = tail0 + 4 * lane; o + 4 <= nbytes; o += 256)
         *reinterpret_cast<u32*>(dst + o) = *reinterpret_cast<const u32*>(lds + o);
+    if ((nbytes & 2) && lane == 0) *reinterpret_cast<u16*>(dst + nbytes - 2) = *reinterpret_cast<const u16*>(lds + nbytes - 2);
 }
 
-template <int S, int NG>
-__global__ __launch_bounds__(256) void k_bin_hist(const char* __restrict__ X, long R, int N, long ldx,
+// SC = number of states the counting core decodes (a template parameter: its loops live in registers); Sout <= SC = the
+// state model's size = columns of H.  A model between two instantiations runs on the next larger one and only its own
+// columns are stored (an occurrence of a state >= Sout is "not a state", like in the reference's inputs it cannot occur).
+// FULL: Sout == SC at compile time (the reference's 15-, 18- and 25-state models).
+template <int SC, int NG, bool FULL>
+__global__ __launch_bounds__(256) void k_bin_hist(const char* __restrict__ X, long R, int N, long ldx, int Sout_,
                                                    u16* __restrict__ H, u64* __restrict__ counts) {
+    constexpr int S = SC;
     constexpr int ND = (S + 1) / 2;
-    constexpr int ROWB = 2 * S;                        // bytes of one row of H
+    const int Sout = FULL ? S : Sout_;
+    const int ROWB = 2 * Sout;                         // bytes of one row of H
     __shared__ u64 s_cnt[S + 1];
-    __shared__ __attribute__((aligned(16))) char s_stage[4][32 * ROWB];
+    __shared__ __attribute__((aligned(16))) char s_stage[4][32 * 2 * S];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = lane & 3, b = lane >> 2;
     if (threadIdx.x <= S) s_cnt[threadIdx.x] = 0;
@@ -63,7 +70,7 @@ __global__ __launch_bounds__(256) void k_bin_hist(const char* __restrict__ X, lo
         if (H) {
             // stage the bin's uint16 row: d[] already is that layout, one dword per pair of states
             char* srow = &s_stage[wave][(half * 16 + b) * ROWB];
-            if constexpr ((S & 1) == 0) {
+            if constexpr (FULL && (S & 1) == 0) {        // even, full width: whole dwords
 #pragma unroll
                 for (int k = 0; k < (ND + 3) / 4; ++k) {
                     const u32 v = sel4(d[4 * k], 4 * k + 1 < ND ? d[4 * k + 1] : 0u, 4 * k + 2 < ND ? d[4 * k + 2] : 0u,
@@ -75,7 +82,7 @@ __global__ __launch_bounds__(256) void k_bin_hist(const char* __restrict__ X, lo
                 for (int k = 0; k < (S + 3) / 4; ++k) {
                     const u32 v = (j & 2) ? (2 * k + 1 < ND ? d[2 * k + 1] : 0u) : d[2 * k];
                     const u32 c = (j & 1) ? v >> 16 : v & 0xffffu;
-                    if (4 * k + j < S) *reinterpret_cast<u16*>(srow + 2 * (4 * k + j)) = (u16)c;
+                    if (4 * k + j < Sout) *reinterpret_cast<u16*>(srow + 2 * (4 * k + j)) = (u16)c;
                 }
             }
         }
@@ -88,7 +95,7 @@ __global__ __launch_bounds__(256) void k_bin_hist(const char* __restrict__ X, lo
     if (counts) {
         flush();
         __syncthreads();
-        if (threadIdx.x < S && s_cnt[threadIdx.x]) atomicAdd(&counts[threadIdx.x], s_cnt[threadIdx.x]);
+        if ((int)threadIdx.x < Sout && s_cnt[threadIdx.x]) atomicAdd(&counts[threadIdx.x], s_cnt[threadIdx.x]);
     }
 }
 
@@ -249,23 +256,32 @@ static int grid_for_tiles(long R) {
 int g_blocks_per_cu = 4;  // persistent grid size (epg_debug_set_variant tunes it for A/B runs)
 
 template <int S, int NG>
-static void launch_bin_hist(const char* X, long R, int N, long ldx, u16* H, u64* counts, hipStream_t st) {
-    hipLaunchKernelGGL((k_bin_hist<S, NG>), dim3(grid_for_tiles(R)), dim3(256), 0, st, X, R, N, ldx, H, counts);
+static void launch_bin_hist(const char* X, long R, int N, long ldx, int Sout, u16* H, u64* counts, hipStream_t st) {
+    // odd S stores uint16 by uint16 either way; with the row width as a run-time value that path measured 2.30 ms
+    // against 2.64 ms for the compile-time one (15 M x 833, S = 15), so only even S takes the compile-time width
+    constexpr bool FULL = (S & 1) == 0;
+    hipLaunchKernelGGL((k_bin_hist<S, NG, FULL>), dim3(grid_for_tiles(R)), dim3(256), 0, st, X, R, N, ldx, Sout, H, counts);
+}
+
+// a state model of another size: the counting core of the next instantiated size, any-N load loop, only Sout columns stored
+template <int SC>
+static void launch_bin_hist_any(const char* X, long R, int N, long ldx, int Sout, u16* H, u64* counts, hipStream_t st) {
+    hipLaunchKernelGGL((k_bin_hist<SC, 0, false>), dim3(grid_for_tiles(R)), dim3(256), 0, st, X, R, N, ldx, Sout, H, counts);
 }
 
 template <int S>
-static void dispatch_bin_hist_ng(const char* X, long R, int N, long ldx, u16* H, u64* counts, hipStream_t st) {
+static void dispatch_bin_hist_ng(const char* X, long R, int N, long ldx, int Sout, u16* H, u64* counts, hipStream_t st) {
     const int ng = (N + 127) / 128;
     switch (ng) {
-        case 1: launch_bin_hist<S, 1>(X, R, N, ldx, H, counts, st); break;
-        case 2: launch_bin_hist<S, 2>(X, R, N, ldx, H, counts, st); break;
-        case 3: launch_bin_hist<S, 3>(X, R, N, ldx, H, counts, st); break;
-        case 4: launch_bin_hist<S, 4>(X, R, N, ldx, H, counts, st); break;
-        case 5: launch_bin_hist<S, 5>(X, R, N, ldx, H, counts, st); break;
-        case 6: launch_bin_hist<S, 6>(X, R, N, ldx, H, counts, st); break;
-        case 7: launch_bin_hist<S, 7>(X, R, N, ldx, H, counts, st); break;
-        case 8: launch_bin_hist<S, 8>(X, R, N, ldx, H, counts, st); break;
-        default: launch_bin_hist<S, 0>(X, R, N, ldx, H, counts, st); break;
+        case 1: launch_bin_hist<S, 1>(X, R, N, ldx, Sout, H, counts, st); break;
+        case 2: launch_bin_hist<S, 2>(X, R, N, ldx, Sout, H, counts, st); break;
+        case 3: launch_bin_hist<S, 3>(X, R, N, ldx, Sout, H, counts, st); break;
+        case 4: launch_bin_hist<S, 4>(X, R, N, ldx, Sout, H, counts, st); break;
+        case 5: launch_bin_hist<S, 5>(X, R, N, ldx, Sout, H, counts, st); break;
+        case 6: launch_bin_hist<S, 6>(X, R, N, ldx, Sout, H, counts, st); break;
+        case 7: launch_bin_hist<S, 7>(X, R, N, ldx, Sout, H, counts, st); break;
+        case 8: launch_bin_hist<S, 8>(X, R, N, ldx, Sout, H, counts, st); break;
+        default: launch_bin_hist<S, 0>(X, R, N, ldx, Sout, H, counts, st); break;
     }
 }
 
@@ -287,17 +303,14 @@ int bin_hist_impl(const int8_t* X8, int64_t R, int32_t N, int64_t ldx, int32_t S
     u64* cnt = reinterpret_cast<u64*>(counts);
     const long Rf = fast_rows(R, N, ldx);
     if (Rf > 0) {
-        switch (S) {
-            case 18: dispatch_bin_hist_ng<18>(X, Rf, N, ldx, H, cnt, st); break;
-            case 15: dispatch_bin_hist_ng<15>(X, Rf, N, ldx, H, cnt, st); break;   // the reference's other ChromHMM models
-            case 25: dispatch_bin_hist_ng<25>(X, Rf, N, ldx, H, cnt, st); break;
-            default: {
-                // generic: count all 31 decodable states into a scratch-free path is not possible with a
-                // different row width, so fall back to the safe kernel for unusual S
-                hipLaunchKernelGGL(k_bin_hist_safe, dim3((int)((Rf + 3) / 4 > num_cus() * 8L ? num_cus() * 8L : (Rf + 3) / 4)),
-                                   dim3(256), 0, st, X, 0L, Rf, N, ldx, S, H, cnt);
-            }
-        }
+        // the reference's models have their own instantiation; any other size runs on the next larger counting core
+        if (S == 15) dispatch_bin_hist_ng<15>(X, Rf, N, ldx, S, H, cnt, st);
+        else if (S == 18) dispatch_bin_hist_ng<18>(X, Rf, N, ldx, S, H, cnt, st);
+        else if (S == 25) dispatch_bin_hist_ng<25>(X, Rf, N, ldx, S, H, cnt, st);
+        else if (S < 15) launch_bin_hist_any<15>(X, Rf, N, ldx, S, H, cnt, st);
+        else if (S < 18) launch_bin_hist_any<18>(X, Rf, N, ldx, S, H, cnt, st);
+        else if (S < 25) launch_bin_hist_any<25>(X, Rf, N, ldx, S, H, cnt, st);
+        else launch_bin_hist_any<31>(X, Rf, N, ldx, S, H, cnt, st);
         EPG_LAUNCH_CHECK("k_bin_hist");
     }
     if (Rf < R) {

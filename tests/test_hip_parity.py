@@ -241,6 +241,28 @@ def test_s2_random_vs_oracle(eng, N, R):
 
 
 # ---------------------------------------------------------------------------------------------- paired extras
+@pytest.mark.parametrize("S_,N,R", [(2, 40, 1000), (10, 833, 777), (16, 130, 2049), (20, 833, 1031), (26, 64, 333), (31, 300, 1000), (15, 50, 31)])
+def test_bin_hist_any_state_model(eng, S_, N, R):
+    """State models between the instantiated sizes of the counting core (15, 18, 25, 31) run on the next larger one and
+    store only their own columns; odd S with an odd number of rows in the last tile ends on a two-byte store."""
+    x = synth_states(R, N, S=S_, seed=S_ + N, uniform=True)
+    x[R // 3, N // 2] = S_                            # not a state of this model, though the counting core can decode it
+    x[R // 2, 0] = -1
+    X = eng.states_to_device(x)
+    guard = torch.full((R * S_ + 64,), 0x5a5a, dtype=torch.int16, device="cuda")     # H with a canary behind it
+    H = guard[: R * S_].view(R, S_)
+    H, counts = eng.bin_hist(X, N, S_, H=H)
+    want = onp.bin_hist(x, S_)
+    assert np.array_equal(eng.hist_to_numpy(H), want)
+    assert np.array_equal(_np(counts), want.sum(axis=0))
+    assert (guard[R * S_:] == 0x5a5a).all()
+    q = eng.normalise(counts)
+    o32, o64 = eng.score_s1_from_binhist(H, N, S_, q, want32=True, want64=True)
+    ref = onp.score_s1(x, onp.normalise(want.sum(axis=0)), S_)
+    np.testing.assert_allclose(_np(o64), ref, rtol=1e-11, atol=0)
+    np.testing.assert_allclose(_np(o32), ref.astype(np.float32), rtol=2e-7, atol=0)
+
+
 @pytest.mark.parametrize("packed", [False, True])
 def test_quiescent_wide_rows(eng, packed):
     """Rows of 379 + 342 bytes: all-quiescent rows, and rows with exactly one other state at the first byte, the last
