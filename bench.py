@@ -196,6 +196,8 @@ def main():
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
+    if os.environ.get("EPG_BENCH_TRACE") and rank == 0:      # per-step k_bin_hist times (clock ramps, box variance)
+        print("k_bin_hist ms per step:", " ".join("%.3f" % e[0].elapsed_time(e[1]) for e in ev), file=sys.stderr, flush=True)
     hist_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in ev])) if args.steps else float("nan")
     rest_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in ev])) if args.steps else float("nan")
 

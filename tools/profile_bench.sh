@@ -16,6 +16,6 @@ timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -
 timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/fetch -o p -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $out/fetch.log 2>&1
 timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/write -o p -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $out/write.log 2>&1
 # the other kernels of the path (S2, S3 expected/score, null shuffle) through tools/kbench_all.py
-timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_all -o p -- python3 $R/tools/kbench_all.py --bins 15000000 --s3-bins 1000000 --null-bins 1000000 > $out/stats_all.log 2>&1
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_all -o p -- python3 $R/tools/kbench_all.py --what s2,s3,null,pair --bins 15000000 --s3-bins 1000000 --null-bins 1000000 > $out/stats_all.log 2>&1
 cd $R
 python3 tools/profile_digest.py $out $label

@@ -46,7 +46,7 @@ if stats_all.exists():
     lines.append("")
     log = src / "stats_all.log"
     if log.exists():
-        lines += ["```"] + [l for l in log.read_text().splitlines() if l.startswith(("S2", "S3", "paired"))] + ["```", ""]
+        lines += ["```"] + [l for l in log.read_text().splitlines() if l.startswith(("S2", "S3", "paired", "pair_", "quiescent"))] + ["```", ""]
 traffic = {}
 for cname in ("fetch", "write"):
     f = src / cname / "p_counter_collection.csv"
