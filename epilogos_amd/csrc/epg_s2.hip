@@ -346,14 +346,6 @@ __global__ __launch_bounds__(256) void k_pair_finish(const float* __restrict__ a
     }
 }
 
-// quiescent from the two groups' histograms: every column of A and of B equals qstate  (scores.py:294-303)
-__global__ __launch_bounds__(256) void k_quiescent_from_hist(const u16* __restrict__ HA, int NA, const u16* __restrict__ HB,
-                                                              int NB, long R, int S, int qstate, uint8_t* __restrict__ mask) {
-    const long row = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (row >= R) return;
-    mask[row] = (HA[row * S + qstate] == NA && HB[row * S + qstate] == NB) ? 1 : 0;
-}
-
 // quiescent straight from the state matrices: 16 lanes per row, 16-byte chunks compared as four words against the
 // quiescent state in every byte.  Most bins fail within their first chunks: a wave (four rows) stops reading a group as
 // soon as all of its rows have failed.
