@@ -41,6 +41,31 @@ class HipBackend:
             return eng.hist_s3(X, N, S).cpu().numpy().reshape(N, N, S, S)
         raise ValueError("Please ensure that saliency metric is either 1, 2, or 3")
 
+    # device-resident accumulation for the genome-wide driver: the S3 count array is 899 MB at N = 833, so it stays in
+    # HBM from the first chunk to the all-reduce and the normalisation instead of crossing PCIe once per chunk
+    def counts_begin(self, S, saliency, N):
+        n = {1: S, 2: S * S, 3: N * N * S * S}[saliency]
+        return self.torch.zeros(n, dtype=self.torch.int32 if saliency == 3 else self.torch.int64, device=self.device)
+
+    def counts_add(self, acc, x, S, saliency):
+        eng = self.engine
+        N = x.shape[1]
+        X = self.to_device(x)
+        if saliency == 1:
+            eng.bin_hist(X, N, S, want_hist=False, counts=acc)
+        elif saliency == 2:
+            H, _ = eng.bin_hist(X, N, S, want_counts=False)
+            eng.hist_s2_from_binhist(H, S, counts=acc)
+        elif saliency == 3:
+            eng.hist_s3(X, N, S, counts=acc)
+        else:
+            raise ValueError("Please ensure that saliency metric is either 1, 2, or 3")
+
+    def counts_finish(self, acc, shape):
+        """(exp_freq on the device for the score pass, exp_freq as the host array that is saved)."""
+        qd = self.engine.normalise(acc)
+        return qd, qd.cpu().numpy().reshape(shape)
+
     def check_counts(self, counts, R, N, saliency):
         """Every state byte must have been counted: a byte outside [0, S) is silently skipped by the kernels."""
         total = int(np.asarray(counts, dtype=np.int64).sum())
@@ -58,7 +83,8 @@ class HipBackend:
         eng = self.engine
         N = x.shape[1]
         X = self.to_device(x)
-        qd = self.torch.from_numpy(np.ascontiguousarray(q, dtype=np.float32).reshape(-1)).to(self.device)
+        qd = q.reshape(-1) if self.torch.is_tensor(q) else \
+            self.torch.from_numpy(np.ascontiguousarray(q, dtype=np.float32).reshape(-1)).to(self.device)
         if saliency == 1:
             o32, _ = eng.score_s1(X, N, S, qd)
         elif saliency == 2:

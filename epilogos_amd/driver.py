@@ -71,6 +71,12 @@ class _Dist:
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
         return t.cpu().numpy().reshape(counts.shape)
 
+    def all_reduce_tensor(self, t):
+        """SUM-all-reduce a tensor in place where it lives (device tensors go over RCCL/xGMI)."""
+        if self.dist:
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        return t
+
     def barrier(self):
         if self.dist:
             self.dist.barrier()
@@ -162,19 +168,24 @@ def run_single_group(files, numStates, saliency, outputDir, fileTag, verbose=Fal
     rows, my_parts, tables = _plan_and_read(files, d, tm)
 
     # STEP 1: local counts over my bin ranges
-    counts = None
-    for x, _ in tables:
-        c = be.expected_counts(x, numStates, saliency)
-        counts = c if counts is None else counts + c
-    if counts is None:   # a rank without bins still takes part in the collective
-        N = readStates(file1Path=files[0], rowsToCalc=(0, 1), verbose=False).shape[1]
-        shape = {1: (numStates,), 2: (numStates, numStates), 3: (N, N, numStates, numStates)}[saliency]
+    N = tables[0][0].shape[1] if tables else readStates(file1Path=files[0], rowsToCalc=(0, 1), verbose=False).shape[1]
+    shape = {1: (numStates,), 2: (numStates, numStates), 3: (N, N, numStates, numStates)}[saliency]
+    if hasattr(be, "counts_begin"):              # product backend: counts stay in HBM through all-reduce and normalise
+        acc = be.counts_begin(numStates, saliency, N)
+        for x, _ in tables:
+            be.counts_add(acc, x, numStates, saliency)
+        tm.lap("expected counts")
+        d.all_reduce_tensor(acc)                 # the one exchange step; a rank without bins contributes zeros
+        q_score, q = be.counts_finish(acc, shape)
+        del acc
+    else:
         counts = np.zeros(shape, dtype=np.int32 if saliency == 3 else np.int64)
-    tm.lap("expected counts")
-    # the one exchange step
-    counts = d.all_reduce_counts(counts, device=device)
-    # STEP 2: identical normalisation on every rank
-    q = be.normalise(counts)
+        for x, _ in tables:
+            counts = counts + be.expected_counts(x, numStates, saliency)
+        tm.lap("expected counts")
+        counts = d.all_reduce_counts(counts, device=device)
+        q = be.normalise(counts)                 # STEP 2: identical normalisation on every rank
+        q_score = q
     if d.rank == 0:
         np.save(outputDir / "exp_freq_{}.npy".format(fileTag), q, allow_pickle=False)
     tm.lap("all-reduce + normalise")
@@ -184,7 +195,7 @@ def run_single_group(files, numStates, saliency, outputDir, fileTag, verbose=Fal
     t_sc = t_wr = 0.0
     for (fi, lo, hi), (x, loc) in zip(my_parts, tables):
         t0 = tm.time()
-        sc = be.scores(x, numStates, saliency, q)
+        sc = be.scores(x, numStates, saliency, q_score)
         t1 = tm.time()
         stem = fileStem(files[fi])
         writeScores(sc, outputDir / ".part_scores_{}_{}_{:012d}.gz".format(fileTag, stem, lo), loc)
