@@ -52,6 +52,31 @@ def main():
            "first_line": np.frombuffer(lines[0], dtype=np.uint8), "last_line": np.frombuffer(lines[-2], dtype=np.uint8),
            "colsum_f64": scores.astype(np.float64).sum(axis=0), "rows_997": scores[::997].copy(),
            "absmax": np.float32(np.abs(scores).max())}
+    # ---- S2 on the same matrix
+    ex.main(f, "null", S, 2, out, "chr1s2", 8, False)
+    res["s2_counts"] = np.load(out / "temp_exp_freq_chr1s2_matrix_chr1.npy")
+    ec.main(out, out / "exp_freq_chr1s2.npy", "chr1s2", False)
+    res["s2_exp"] = np.load(out / "exp_freq_chr1s2.npy")
+    sc.main(f, "null", S, 2, out, out / "exp_freq_chr1s2.npy", "chr1s2", 8, S - 1, -1, False)
+    s2 = np.load(out / "temp_scores_chr1s2_matrix_chr1.npz", allow_pickle=True)["scoreArr"]
+    with gzip.open(out / "scores_chr1s2_matrix_chr1.txt.gz", "rb") as g:
+        text = g.read()
+    res.update({"s2_text_sha256": np.frombuffer(hashlib.sha256(text).digest(), dtype=np.uint8), "s2_text_bytes": np.int64(len(text)),
+                "s2_colsum_f64": s2.astype(np.float64).sum(axis=0), "s2_rows_997": s2[::997].copy()})
+    # ---- paired S1: biosamples 0-4 against 5-9 (the deltas are deterministic, the null shuffle is not)
+    (work / "A").mkdir(); (work / "B").mkdir()
+    df.iloc[:, list(range(3)) + list(range(3, 8))].to_csv(work / "A" / "matrix_chr1.txt", sep="\t", header=False, index=False)
+    df.iloc[:, list(range(3)) + list(range(8, 13))].to_csv(work / "B" / "matrix_chr1.txt", sep="\t", header=False, index=False)
+    fa, fb = work / "A" / "matrix_chr1.txt", work / "B" / "matrix_chr1.txt"
+    ex.main(fa, fb, S, 1, out, "pair", 8, False)
+    res["pair_counts"] = np.load(out / "temp_exp_freq_pair_matrix_chr1.npy")
+    ec.main(out, out / "exp_freq_pair.npy", "pair", False)
+    res["pair_exp"] = np.load(out / "exp_freq_pair.npy")
+    sc.main(fa, fb, S, 1, out, out / "exp_freq_pair.npy", "pair", 8, S - 1, -1, False)
+    with gzip.open(out / "pairwiseDelta_pair_matrix_chr1.txt.gz", "rb") as g:
+        text = g.read()
+    res.update({"pair_text_sha256": np.frombuffer(hashlib.sha256(text).digest(), dtype=np.uint8), "pair_text_bytes": np.int64(len(text)),
+                "pair_quiescent_count": np.int64(np.load(out / "temp_quiescence_pair_matrix_chr1.npz")["quiescenceArr"].sum())})
     np.savez_compressed(HERE / "chr1_full.npz", **res)
     print({k: getattr(v, "shape", None) for k, v in res.items()}, (HERE / "chr1_full.npz").stat().st_size)
 

@@ -54,6 +54,64 @@ def test_oracle_and_writer_match_reference_on_full_chr1(g, tmp_path):
     assert hashlib.sha256(text).digest() == g["text_sha256"].tobytes()      # 1.2 M lines, byte for byte the reference's file
 
 
+def test_oracle_s2_and_paired_match_reference_on_full_chr1(g, tmp_path):
+    x = g["x"]
+    R = x.shape[0]
+    loc = _locations(g, R)
+    c2 = onp.expected_s2(x, S)
+    assert np.array_equal(c2, g["s2_counts"])
+    q2 = onp.normalise(c2)
+    assert np.array_equal(q2, g["s2_exp"])
+    s2 = np.concatenate([onp.score_s2(x[lo:lo + 100000], q2, S) for lo in range(0, R, 100000)]).astype(np.float32)
+    assert np.array_equal(s2[::997], g["s2_rows_997"])
+    assert np.array_equal(s2.astype(np.float64).sum(axis=0), g["s2_colsum_f64"])
+    text = _text(tmp_path, loc, s2)
+    assert len(text) == int(g["s2_text_bytes"]) and hashlib.sha256(text).digest() == g["s2_text_sha256"].tobytes()
+    # paired S1: biosamples 0-4 against 5-9, background over all ten
+    xa, xb = x[:, :5], x[:, 5:]
+    cp = onp.expected_s1(x, S)
+    assert np.array_equal(cp, g["pair_counts"])
+    qp = onp.normalise(cp)
+    assert np.array_equal(qp, g["pair_exp"])
+    delta, _ = onp.pair_finish(onp.score_s1(xa, qp, S).astype(np.float32), onp.score_s1(xb, qp, S).astype(np.float32))
+    text = _text(tmp_path, loc, delta)
+    assert len(text) == int(g["pair_text_bytes"]) and hashlib.sha256(text).digest() == g["pair_text_sha256"].tobytes()
+    assert int(onp.quiescent_mask(xa, xb, S - 1).sum()) == int(g["pair_quiescent_count"])
+
+
+@pytest.mark.gpu
+def test_hip_s2_and_paired_on_full_chr1(g):
+    import torch
+    from epilogos_amd import engine
+    engine.require_gpu()
+    x = g["x"]
+    R, N = x.shape
+    X = engine.states_to_device(x)
+    H, _ = engine.bin_hist(X, N, S)
+    c2 = engine.hist_s2_from_binhist(H, S)
+    assert np.array_equal(c2.cpu().numpy().reshape(S, S), g["s2_counts"])
+    q2 = engine.normalise(c2)
+    assert np.array_equal(q2.cpu().numpy().reshape(S, S), g["s2_exp"])
+    o32, o64 = engine.score_s2_from_binhist(H, N, S, q2, want32=True, want64=True)
+    got = o32.cpu().numpy()
+    np.testing.assert_allclose(got[::997], g["s2_rows_997"], rtol=1e-6, atol=1e-12)       # the reference's own rows
+    np.testing.assert_allclose(got.astype(np.float64).sum(axis=0), g["s2_colsum_f64"], rtol=1e-9)
+    for lo in (0, 600000, R - 50000):                                                    # float64 against the oracle
+        ref = onp.score_s2(x[lo:lo + 50000], g["s2_exp"], S)
+        np.testing.assert_allclose(o64.cpu().numpy()[lo:lo + 50000], ref, rtol=1e-6, atol=1e-12)
+    # paired
+    XA, XB = engine.states_to_device(x[:, :5]), engine.states_to_device(x[:, 5:])
+    qp = torch.from_numpy(g["pair_exp"]).cuda()
+    sa, _ = engine.score_s1(XA, 5, S, qp)
+    sb, _ = engine.score_s1(XB, 5, S, qp)
+    delta, _ = engine.pair_finish(sa, sb)
+    ref_delta, _ = onp.pair_finish(onp.score_s1(x[:, :5], g["pair_exp"], S).astype(np.float32),
+                                   onp.score_s1(x[:, 5:], g["pair_exp"], S).astype(np.float32))
+    np.testing.assert_allclose(delta.cpu().numpy(), ref_delta, rtol=0, atol=2e-7)
+    m = engine.quiescent(XA, 5, XB, 5, S - 1)
+    assert int(m.sum().item()) == int(g["pair_quiescent_count"])
+
+
 @pytest.mark.gpu
 def test_hip_on_full_chr1(g, tmp_path):
     import torch
