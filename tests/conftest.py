@@ -19,6 +19,16 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_sessionstart(session):
+    """The shared libraries are build products (git-ignored): build whichever is missing before the first test needs it
+    (hipcc cross-compiles gfx950 without a GPU; __graft_entry__.build() does the same)."""
+    from epilogos_amd import build
+    if not build.LIB_PATH.exists():
+        build.build_library(force=False, verbose=False)
+    if not build.IO_LIB_PATH.exists():
+        build.build_io_library(force=False, verbose=False)
+
+
 def free_port():
     """A TCP port that is free right now, for torch.distributed.run rendezvous in the multi-process tests."""
     import socket
