@@ -57,12 +57,16 @@ def expected_s3(x, S):
     int32[N,N,S,S]."""
     x = np.asarray(x)
     R, N = x.shape
-    onehot = np.zeros((R, N * S), dtype=np.int64)
-    rows = np.repeat(np.arange(R), N)
-    cols = (np.arange(N)[None, :] * S + x).reshape(-1)
-    valid = ((x >= 0) & (x < S)).reshape(-1)
-    onehot[rows[valid], cols[valid]] = 1
-    C = (onehot.T @ onehot).reshape(N, S, N, S).transpose(0, 2, 1, 3).copy()
+    G = np.zeros((N * S, N * S), dtype=np.int64)
+    for lo in range(0, R, 65536):                 # one-hot Gram matrix in float64 BLAS: 0/1 products, sums < 2^53, exact
+        xc = x[lo:lo + 65536]
+        onehot = np.zeros((xc.shape[0], N * S), dtype=np.float64)
+        rows = np.repeat(np.arange(xc.shape[0]), N)
+        cols = (np.arange(N)[None, :] * S + xc).reshape(-1)
+        valid = ((xc >= 0) & (xc < S)).reshape(-1)
+        onehot[rows[valid], cols[valid]] = 1.0
+        G += np.rint(onehot.T @ onehot).astype(np.int64)
+    C = G.reshape(N, S, N, S).transpose(0, 2, 1, 3).copy()
     C[np.arange(N), np.arange(N)] = 0
     return C.astype(np.int32)
 

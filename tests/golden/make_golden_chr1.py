@@ -77,6 +77,14 @@ def main():
         text = g.read()
     res.update({"pair_text_sha256": np.frombuffer(hashlib.sha256(text).digest(), dtype=np.uint8), "pair_text_bytes": np.int64(len(text)),
                 "pair_quiescent_count": np.int64(np.load(out / "temp_quiescence_pair_matrix_chr1.npz")["quiescenceArr"].sum())})
+    # ---- S3 on the same matrix (float32 sequential accumulation in the reference: compared with a tolerance)
+    ex.main(f, "null", S, 3, out, "chr1s3", 8, False)
+    res["s3_counts"] = np.load(out / "temp_exp_freq_chr1s3_matrix_chr1.npy")
+    ec.main(out, out / "exp_freq_chr1s3.npy", "chr1s3", False)
+    res["s3_exp"] = np.load(out / "exp_freq_chr1s3.npy")
+    sc.main(f, "null", S, 3, out, out / "exp_freq_chr1s3.npy", "chr1s3", 8, S - 1, -1, False)
+    s3 = np.load(out / "temp_scores_chr1s3_matrix_chr1.npz", allow_pickle=True)["scoreArr"]
+    res.update({"s3_colsum_f64": s3.astype(np.float64).sum(axis=0), "s3_rows_997": s3[::997].copy()})
     np.savez_compressed(HERE / "chr1_full.npz", **res)
     print({k: getattr(v, "shape", None) for k, v in res.items()}, (HERE / "chr1_full.npz").stat().st_size)
 

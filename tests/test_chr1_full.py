@@ -79,6 +79,38 @@ def test_oracle_s2_and_paired_match_reference_on_full_chr1(g, tmp_path):
     assert int(onp.quiescent_mask(xa, xb, S - 1).sum()) == int(g["pair_quiescent_count"])
 
 
+def test_oracle_s3_matches_reference_on_full_chr1(g):
+    x = g["x"]
+    c3 = onp.expected_s3(x, S)
+    assert np.array_equal(c3, g["s3_counts"]) and c3.dtype == np.int32
+    q3 = onp.normalise(c3)
+    assert np.array_equal(q3, g["s3_exp"])
+    rows = np.arange(0, x.shape[0], 997)
+    s3 = onp.score_s3_f64(x[rows], q3, S)
+    # the reference adds 90 float32 terms per bin one after the other; the oracle sums the same float32 table in float64
+    np.testing.assert_allclose(s3, g["s3_rows_997"], rtol=1e-4, atol=5e-6)
+
+
+@pytest.mark.gpu
+def test_hip_s3_on_full_chr1(g):
+    import torch
+    from epilogos_amd import engine
+    engine.require_gpu()
+    x = g["x"]
+    R, N = x.shape
+    X = engine.states_to_device(x)
+    c3 = engine.hist_s3(X, N, S)
+    assert np.array_equal(c3.cpu().numpy().reshape(N, N, S, S), g["s3_counts"])
+    q3 = engine.normalise(c3)
+    assert np.array_equal(q3.cpu().numpy().reshape(N, N, S, S), g["s3_exp"])
+    o32, o64 = engine.score_s3(X, N, S, q3, want32=True, want64=True)
+    got = o32.cpu().numpy()
+    np.testing.assert_allclose(got[::997], g["s3_rows_997"], rtol=1e-4, atol=5e-6)       # the reference's own rows
+    np.testing.assert_allclose(got.astype(np.float64).sum(axis=0), g["s3_colsum_f64"], rtol=1e-5)
+    rows = np.arange(0, R, 997)
+    np.testing.assert_allclose(o64.cpu().numpy()[rows], onp.score_s3_f64(x[rows], g["s3_exp"], S), rtol=2e-6, atol=1e-9)
+
+
 @pytest.mark.gpu
 def test_hip_s2_and_paired_on_full_chr1(g):
     import torch
