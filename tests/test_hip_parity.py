@@ -72,7 +72,7 @@ def test_bin_hist_other_state_models(eng, S_):
     assert np.array_equal(_np(counts), h_ref.sum(axis=0))
 
 
-@pytest.mark.parametrize("S_,N", [(15, 127), (15, 833), (25, 200), (25, 1000), (18, 1000), (18, 1024), (18, 1025)])
+@pytest.mark.parametrize("S_,N", [(15, 127), (15, 833), (25, 200), (25, 1000), (18, 1000), (18, 1024), (18, 1025), (18, 1698), (18, 2500), (15, 4097)])
 def test_bin_hist_fast_paths_of_other_models(eng, S_, N):
     """15- and 25-state ChromHMM models (reference data/state_metadata) and N in (896, 1024] take templated kernels."""
     x = synth_states(300, N, S=S_, seed=S_ + N, uniform=True)
