@@ -141,6 +141,7 @@ constexpr int S3S_ACH = 4;                        // biosamples a per staging ph
 constexpr int S3S_LD = 33;
 constexpr int S3S_TAB = 32 * S3S_LD * 4;          // bytes of one padded table
 constexpr int S3S_DUMMY = 31 * S3S_LD + 32;       // a slot no gather reads (column 32)
+constexpr double S3S_FIX = 1125899906842624.0;    // 2^50: fixed-point unit of the score cells (see the end of k_s3_score)
 
 // Everything the loop touches is unconditional: XT4 holds 4*state (31 -> 124 for "not a state" and for padded bins),
 // the table has zero rows for a >= N and a zero diagonal a == b, invalid staging elements go to a dummy LDS slot and
@@ -254,12 +255,22 @@ __global__ __launch_bounds__(S3S_THREADS, STG <= 6 ? 3 : 2) void k_s3_score(cons
     for (int u = 0; u < S3S_BPT; ++u) {
         const long row = r0 + u;
         const u32 xb = ((xbw[u >> 2] >> (8 * (u & 3))) & 0xffu) >> 2;
-        if (row < R && xb < (u32)S) atomicAdd(&out64[row * S + xb], acc[u]);
+        // The 833 blocks (one per b) of a slice add into the same [bin, state] cells in whatever order they finish.  The
+        // cells are therefore 64-bit FIXED-POINT integers (2^-50 units): integer addition is associative, so the score is
+        // bit-identical from run to run and for any partition of the bins, like S1 and S2.  |score| < 2^13 by a wide
+        // margin (real values stay below ~20); rounding a contribution costs <= 2^-51, 833 of them < 4e-13 absolute.
+        if (row < R && xb < (u32)S)
+            atomicAdd(reinterpret_cast<u64*>(&out64[row * S + xb]), (u64)__double2ll_rn(acc[u] * S3S_FIX));
     }
 }
 
-__global__ __launch_bounds__(256) void k_f64_to_f32(const double* __restrict__ in, long n, float* __restrict__ out) {
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) out[i] = (float)in[i];
+// fixed-point cells -> float64 in place and / or float32
+__global__ __launch_bounds__(256) void k_s3_fix_finish(double* __restrict__ cells, long n, int want64, float* __restrict__ out32) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const double v = (double)reinterpret_cast<const long long*>(cells)[i] * (1.0 / S3S_FIX);
+        if (want64) cells[i] = v;
+        if (out32) out32[i] = (float)v;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -333,11 +344,11 @@ int score_s3_impl(const int8_t* X8, int64_t R, int32_t N, int64_t ldx, int32_t S
     else if (stg <= 10) hipLaunchKernelGGL(k_s3_score<10>, grid, block, 0, st, XT, Rp, (long)R, N, Nceil, S, T, acc);
     else hipLaunchKernelGGL(k_s3_score<16>, grid, block, 0, st, XT, Rp, (long)R, N, Nceil, S, T, acc);
     EPG_LAUNCH_CHECK("k_s3_score");
-    if (out32) {
+    {
         long blocks = ((long)R * S + 255) / 256;
         if (blocks > num_cus() * 8L) blocks = num_cus() * 8L;
-        hipLaunchKernelGGL(k_f64_to_f32, dim3((unsigned)blocks), dim3(256), 0, st, acc, (long)R * S, out32);
-        EPG_LAUNCH_CHECK("k_f64_to_f32");
+        hipLaunchKernelGGL(k_s3_fix_finish, dim3((unsigned)blocks), dim3(256), 0, st, acc, (long)R * S, out64 ? 1 : 0, out32);
+        EPG_LAUNCH_CHECK("k_s3_fix_finish");
     }
     return EPG_OK;
 }

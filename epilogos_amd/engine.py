@@ -79,13 +79,18 @@ def hist_s2_from_binhist(H, S, counts=None):
     return counts
 
 
-def hist_s3(X, N, S, counts=None):
+def hist_s3(X, N, S, counts=None, use_workspace=True):
+    """counts int32 [N*N*S*S] += biosample-pair state co-occurrences.  With a workspace (room for the transposed matrix)
+    the matrix-core kernel runs; without one the ABI falls back to the LDS-counter kernel (same integers)."""
     R, ldx = _check_states(X, N)
     if counts is None:
         counts = zeros_counts(N * N * S * S, dtype=torch.int32, device=X.device)
-    nbytes = _abi.call("epg_ws_bytes", 3, R, N, S)
-    ws = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=X.device)
-    _abi.call("epg_hist_s3", _ptr(X), R, N, ldx, S, _ptr(counts), _ptr(ws), ws.numel(), _stream())
+    if use_workspace:
+        nbytes = _abi.call("epg_ws_bytes", 3, R, N, S)
+        ws = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=X.device)
+        _abi.call("epg_hist_s3", _ptr(X), R, N, ldx, S, _ptr(counts), _ptr(ws), ws.numel(), _stream())
+    else:
+        _abi.call("epg_hist_s3", _ptr(X), R, N, ldx, S, _ptr(counts), None, 0, _stream())
     return counts
 
 

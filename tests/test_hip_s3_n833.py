@@ -1,0 +1,110 @@
+"""GPU parity of the S3 path at the BASELINE.json shape: 833 biosamples x 18 states (config 4).
+
+At N = 833 the matrix-core expected kernel runs 157 x 157 block pairs of 96 (sample, state) rows with a ragged last block
+(14 994 = 156 * 96 + 18), a K split combined by int32 atomics and the eight-wave shared-A path; the LDS-counter kernel runs
+three bin slices (R > 2 * 65 535); the score kernel streams 209 phases of four biosamples with Nceil = 836 zero rows and its
+blocks (one per biosample) meet in the same output cells.  None of that is reached by the N <= 129 cases of
+test_hip_s3_null.py.  Reference: expected.py:183-200 (s3Calc), scores.py:474-504 (s3Score).
+
+The oracle is the CPU restatement (oracle/oracle_np.py): the full 14 994 x 14 994 co-occurrence matrix through a float32
+syrk (exact integers), scores of scattered bins through the closed-form float64 sum.
+"""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+
+from oracle import oracle_np as onp
+from tests.conftest import synth_states
+
+pytestmark = pytest.mark.gpu
+S, N = 18, 833
+R = 2 * 65536 + 37                      # three slices of the LDS kernel, not a multiple of any tile / K step
+BAD = ((70001, 416, -1), (R - 1, 832, 25), (5, 0, 31))   # bytes that are not states: skipped in every pair they are part of
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from epilogos_amd import engine
+    engine.require_gpu()
+    return engine
+
+
+@pytest.fixture(scope="module")
+def case(eng):
+    x = synth_states(R, N, seed=833)
+    for r, c, v in BAD:
+        x[r, c] = v
+    X = eng.states_to_device(x)
+    c_mfma = eng.hist_s3(X, N, S)                          # matrix-core path (workspace for the transposed matrix)
+    c_lds = eng.hist_s3(X, N, S, use_workspace=False)      # LDS-counter path
+    torch.cuda.synchronize()
+    return {"x": x, "X": X, "mfma": c_mfma, "lds": c_lds}
+
+
+@pytest.fixture(scope="module")
+def oracle_counts(case):
+    return onp.expected_s3(case["x"], S)                   # int32 [833, 833, 18, 18]
+
+
+def test_s3_counts_two_kernels_agree(case):
+    assert case["mfma"].dtype == torch.int32
+    assert torch.equal(case["mfma"], case["lds"])
+
+
+def test_s3_counts_invariants(case):
+    c = case["mfma"].view(N, N, S, S)
+    valid = torch.from_numpy(((case["x"] >= 0) & (case["x"] < S))).cuda()
+    nvalid = valid.sum(dim=1).to(torch.int64)              # valid states per bin
+    assert int(c.sum(dtype=torch.int64)) == int((nvalid * (nvalid - 1)).sum())     # ordered pairs of valid states
+    assert int(torch.diagonal(c, dim1=0, dim2=1).abs().sum()) == 0                 # a == b stays zero (expected.py:185)
+    assert torch.equal(c, c.permute(1, 0, 3, 2))                                   # C[a,b,i,j] == C[b,a,j,i]
+
+
+def test_s3_counts_oracle_n833(case, oracle_counts):
+    got = case["mfma"].cpu().numpy().reshape(N, N, S, S)
+    assert np.array_equal(got, oracle_counts)
+
+
+def test_s3_counts_accumulate(eng, case, oracle_counts):
+    c = case["mfma"].clone()
+    eng.hist_s3(case["X"], N, S, counts=c)                 # += like expectedCombination.py:30-35
+    assert torch.equal(c, 2 * case["mfma"])
+
+
+def test_s3_exp_freq_n833(eng, case, oracle_counts):
+    q = eng.normalise(case["mfma"]).cpu().numpy().reshape(N, N, S, S)
+    assert np.array_equal(q, onp.normalise(oracle_counts))  # bit-exact float32 (expectedCombination.py:42)
+
+
+def test_s3_scores_n833(eng, case, oracle_counts):
+    x = case["x"]
+    qd = eng.normalise(case["mfma"])
+    o32, o64 = eng.score_s3(case["X"], N, S, qd, want32=True, want64=True)
+    o32b, o64b = eng.score_s3(case["X"], N, S, qd, want32=True, want64=True)
+    o32c, _ = eng.score_s3(case["X"], N, S, qd, want32=True, want64=False)
+    torch.cuda.synchronize()
+    # fixed-point accumulation: run-to-run bit-identical (like S1 / S2), float32 the rounding of the float64
+    assert torch.equal(o64, o64b) and torch.equal(o32, o32b) and torch.equal(o32, o32c)
+    assert torch.equal(o32, o64.to(torch.float32))
+    assert bool(torch.isfinite(o64).all())
+    # 96 scattered bins (first, last, both sides of every 4096-bin block border of the score kernel's slices) against the
+    # float64 closed form; rows holding a byte that is not a state are left out (the reference's gather is undefined there)
+    rng = np.random.default_rng(7)
+    rows = set(rng.integers(0, R, size=80).tolist()) | {0, 1, 4095, 4096, 8191, 8192, 65535, 65536, 131071, 131072, R - 2}
+    rows -= {r for r, _, _ in BAD}
+    rows = np.array(sorted(rows))
+    q = qd.cpu().numpy().reshape(N, N, S, S)
+    ref = onp.score_s3_f64(x[rows], q, S)
+    np.testing.assert_allclose(o64.cpu().numpy()[rows], ref, rtol=2e-6, atol=1e-9)
+    np.testing.assert_allclose(o32.cpu().numpy()[rows], ref.astype(np.float32), rtol=3e-6, atol=1e-9)
+    # a byte that is not a state adds nothing: the bin's total is that of its valid biosamples (checked against the oracle
+    # on the matrix with that biosample's column dropped for the bin: same as removing its terms)
+    r, cidx, _ = BAD[0]
+    xr = x[r].copy()
+    a_idx, b_idx = np.nonzero(~np.eye(N, dtype=bool))
+    keep = (a_idx != cidx) & (b_idx != cidx)
+    T = onp.s3_table(q, N).astype(np.float64)
+    want = np.zeros(S)
+    np.add.at(want, xr[b_idx[keep]], T[a_idx[keep], b_idx[keep], xr[a_idx[keep]], xr[b_idx[keep]]])
+    np.testing.assert_allclose(o64.cpu().numpy()[r], want, rtol=2e-6, atol=1e-9)
