@@ -31,6 +31,8 @@ PROTOTYPES = {
     "epg_hist_s1": (C.c_int, [_p, _i64, _i32, _i64, _i32, _p, _p]),
     "epg_hist_s2": (C.c_int, [_p, _i64, _i32, _i64, _i32, _p, _p, _i64, _p]),
     "epg_hist_s2_from_binhist": (C.c_int, [_p, _i64, _i32, _p, _p]),
+    "epg_hist_s2_from_binhist_pair": (C.c_int, [_p, _p, _i64, _i32, _p, _p]),
+    "epg_combine_score_s1": (C.c_int, [_p, _i32, _p, _i64, _i32, _i32, _p, _p, _p, _p, _i64, _p]),
     "epg_hist_s3": (C.c_int, [_p, _i64, _i32, _i64, _i32, _p, _p, _i64, _p]),
     "epg_normalise_i64": (C.c_int, [_p, _i64, _p, _p, _i64, _p]),
     "epg_normalise_i32": (C.c_int, [_p, _i64, _p, _p, _i64, _p]),

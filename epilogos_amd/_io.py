@@ -31,6 +31,8 @@ def load():
     lib.epgio_table_rows.argtypes = [p]
     lib.epgio_table_cols.restype = i32
     lib.epgio_table_cols.argtypes = [p]
+    lib.epgio_table_state_range.restype = C.c_int
+    lib.epgio_table_state_range.argtypes = [p, C.POINTER(i32), C.POINTER(i32)]
     lib.epgio_table_copy_states.restype = C.c_int
     lib.epgio_table_copy_states.argtypes = [p, p, i64]
     lib.epgio_table_locations.restype = p
@@ -99,8 +101,10 @@ class Locations:
         return Locations(np.frombuffer(b"".join(rows), dtype=np.uint8).copy(), off)
 
 
-def read_table(path, rows=None, threads=0, ldx=None):
-    """Parse rows [lo, hi) of a TSV(.gz) matrix file.  Returns (int8 states [R, ldx or N], Locations)."""
+def read_table(path, rows=None, threads=0, ldx=None, alloc=None, with_range=False):
+    """Parse rows [lo, hi) of a TSV(.gz) matrix file.  Returns (int8 states [R, ldx or N], Locations) and, with_range, the
+    (lowest, highest) state value as written in the file.  alloc(R, N) -> int8 array [R, width >= N] lets the caller own
+    the destination (e.g. a pinned, row-padded staging buffer); columns >= N are filled with -1."""
     lib = load()
     lo, hi = (0, -1) if rows is None else rows
     h = lib.epgio_open_table(str(path).encode(), lo, hi, threads)
@@ -108,10 +112,19 @@ def read_table(path, rows=None, threads=0, ldx=None):
         raise EpilogosIOError(_err())
     try:
         R, N = lib.epgio_table_rows(h), lib.epgio_table_cols(h)
-        width = N if ldx is None else ldx
-        states = np.empty((R, width), dtype=np.int8)
+        if alloc is not None:
+            states = alloc(R, N)
+            if states.dtype != np.int8 or states.ndim != 2 or states.shape[0] != R or states.shape[1] < N \
+                    or (R and states.strides != (states.shape[1], 1)):
+                raise ValueError("alloc must return a C-contiguous int8 [R, width >= N] array")
+            width = states.shape[1]
+        else:
+            width = N if ldx is None else ldx
+            states = np.empty((R, width), dtype=np.int8)
         if lib.epgio_table_copy_states(h, states.ctypes.data, width) != 0:
             raise EpilogosIOError(_err())
+        slo, shi = C.c_int32(0), C.c_int32(0)
+        lib.epgio_table_state_range(h, C.byref(slo), C.byref(shi))
         offp = C.c_void_p()
         locp = lib.epgio_table_locations(h, C.byref(offp))
         off = np.ctypeslib.as_array(C.cast(offp, C.POINTER(C.c_int64)), shape=(R + 1,)).copy()
@@ -119,6 +132,8 @@ def read_table(path, rows=None, threads=0, ldx=None):
                 if R else np.zeros(0, dtype=np.uint8))
     finally:
         lib.epgio_close_table(h)
+    if with_range:
+        return states, Locations(blob, off), (int(slo.value), int(shi.value))
     return states, Locations(blob, off)
 
 

@@ -67,8 +67,9 @@ class HipBackend:
         return qd, qd.cpu().numpy().reshape(shape)
 
     def check_counts(self, counts, R, N, saliency):
-        """Every state byte must have been counted: a byte outside [0, S) is silently skipped by the kernels."""
-        total = int(np.asarray(counts, dtype=np.int64).sum())
+        """Every state byte must have been counted: a byte outside [0, S) is silently skipped by the kernels.  `counts` is
+        the count array or its already computed total."""
+        total = int(counts) if np.ndim(counts) == 0 else int(np.asarray(counts, dtype=np.int64).sum())
         want = R * N if saliency == 1 else R * N * (N - 1)
         if total != want:
             raise ValueError("input contains states outside 1..numStates (counted %d of %d)" % (total, want))
@@ -128,6 +129,171 @@ class HipBackend:
         else:
             raise ValueError("Please ensure that saliency metric is either 1 or 2 for Pairwise Epilogos")
         return na.cpu().numpy(), nb.cpu().numpy()
+
+
+    # ---- device-resident sessions of the genome-wide driver (driver.py): every part is uploaded ONCE, its per-bin
+    # histograms (S1/S2) or its state matrix (S3, paired) stay in HBM between the count pass and the score pass
+    def open_single(self, S, saliency):
+        return _HipSingleSession(self, S, saliency)
+
+    def open_paired(self, S, saliency, quiescentState, groupSize, seed):
+        return _HipPairedSession(self, S, saliency, quiescentState, groupSize, seed)
+
+
+class _HipSession:
+    """Shared plumbing: ordered pinned staging, one asynchronous upload per matrix, the count accumulator."""
+
+    def __init__(self, be, S, saliency):
+        self.be, self.S, self.sal = be, S, saliency
+        self.torch, self.eng, self.device = be.torch, be.engine, be.device
+        self.pool = be.engine.PinnedPool(int(__import__("os").environ.get("EPILOGOS_PINNED_BUFFERS", "4")))
+        self.copy_stream = self.torch.cuda.Stream(device=self.device)
+        self.held = {}                                   # ticket -> pinned buffer handed to the parser
+        self.acc = None
+        self.q = None
+        self.parts = []
+        self.n_uploads = 0
+        self.upload_bytes = 0
+
+    def alloc(self, ticket):
+        """-> alloc(R, N) for _io.read_table / helpers.readTable: a pinned, row-padded destination for part `ticket`."""
+        def make(R, N):
+            ldx = self.eng.padded_width(N)
+            buf = self.pool.acquire(ticket, R * ldx)
+            self.held[ticket] = buf
+            return buf[:R * ldx].view(R, ldx).numpy()
+        return make
+
+    def skip(self, ticket):
+        if ticket not in self.held:
+            self.pool.skip(ticket)
+
+    def _upload(self, arr, N, ticket):
+        """One H2D copy of the staged matrix (pinned -> HBM on the copy stream); the staging buffer goes back to the pool."""
+        R = arr.shape[0]
+        buf = self.held.pop(ticket, None)
+        if buf is None:                                  # not staged through alloc(): pageable fallback of the same layout
+            self.pool.skip(ticket)
+            X = self.eng.states_to_device(arr[:, :N], device=self.device)
+        else:
+            self.copy_stream.wait_stream(self.torch.cuda.current_stream())
+            X, ev = self.eng.upload_states(buf, R, arr.shape[1], self.copy_stream, device=self.device)
+            self.torch.cuda.current_stream().wait_event(ev)
+            ev.synchronize()
+            self.pool.release(buf)
+        self.n_uploads += 1
+        self.upload_bytes += X.numel()
+        return X
+
+    def _acc(self, n, dtype=None):
+        if self.acc is None:
+            self.acc = self.torch.zeros(n, dtype=dtype or self.torch.int64, device=self.device)
+        return self.acc
+
+    def all_reduce(self, d):
+        d.all_reduce_tensor(self.acc)                    # RCCL over xGMI: the tensor never leaves HBM
+
+    def _finish(self, total_rows, N, shape):
+        """Count check (the reference dies on a state outside the model, expected.py:113; here such a byte is counted
+        nowhere, so the total comes out short), then STEP 2 on the device."""
+        total = int(self.acc.sum(dtype=self.torch.int64).item())
+        self.be.check_counts(total, total_rows, N, self.sal)
+        self.q = self.eng.normalise(self.acc)
+        self.acc = None
+        return self.q.cpu().numpy().reshape(shape)
+
+
+class _HipSingleSession(_HipSession):
+    def add_part(self, arr, N, ticket):
+        eng, S = self.eng, self.S
+        X = self._upload(arr, N, ticket)
+        self.N = N
+        if self.sal == 1:
+            H, _ = eng.bin_hist(X, N, S, counts=self._acc(S))
+            self.parts.append(H)
+        elif self.sal == 2:
+            H, _ = eng.bin_hist(X, N, S, want_counts=False)
+            eng.hist_s2_from_binhist(H, S, counts=self._acc(S * S))
+            self.parts.append(H)
+        elif self.sal == 3:
+            eng.hist_s3(X, N, S, counts=self._acc(N * N * S * S, self.torch.int32))
+            self.parts.append(X)
+        else:
+            raise ValueError("Please ensure that saliency metric is either 1, 2, or 3")
+        return len(self.parts) - 1
+
+    def ensure_acc(self, N):
+        S = self.S                                       # a rank without bins still takes part in the all-reduce
+        self._acc({1: S, 2: S * S, 3: N * N * S * S}[self.sal], self.torch.int32 if self.sal == 3 else None)
+
+    def finish(self, total_rows, N):
+        S = self.S
+        return self._finish(total_rows, N, {1: (S,), 2: (S, S), 3: (N, N, S, S)}[self.sal])
+
+    def scores(self, pid):
+        eng, S, N = self.eng, self.S, self.N
+        D = self.parts[pid]
+        self.parts[pid] = None                           # the part's device data is released with its scores
+        if self.sal == 1:
+            o32, _ = eng.score_s1_from_binhist(D, N, S, self.q)
+        elif self.sal == 2:
+            o32, _ = eng.score_s2_from_binhist(D, N, S, self.q)
+        else:
+            o32, _ = eng.score_s3(D, N, S, self.q)
+        return o32.cpu().numpy()
+
+
+class _HipPairedSession(_HipSession):
+    def __init__(self, be, S, saliency, quiescentState, groupSize, seed):
+        if saliency not in (1, 2):
+            raise ValueError("Please ensure that saliency metric is either 1 or 2 for Pairwise Epilogos")
+        super().__init__(be, S, saliency)
+        self.qstate, self.groupSize, self.seed = quiescentState, groupSize, seed
+
+    def add_part(self, arrA, NA, ticketA, arrB, NB, ticketB, row0):
+        eng, S = self.eng, self.S
+        XA = self._upload(arrA, NA, ticketA)
+        XB = self._upload(arrB, NB, ticketB)
+        self.NA, self.NB = NA, NB
+        if self.sal == 1:                                # counts over [A|B] = counts of A + counts of B (helpers.py:173)
+            HA, _ = eng.bin_hist(XA, NA, S, counts=self._acc(S))
+            HB, _ = eng.bin_hist(XB, NB, S, counts=self._acc(S))
+        else:
+            HA, _ = eng.bin_hist(XA, NA, S, want_counts=False)
+            HB, _ = eng.bin_hist(XB, NB, S, want_counts=False)
+            eng.hist_s2_from_binhist_pair(HA, HB, S, counts=self._acc(S * S))
+        self.parts.append((XA, XB, HA, HB, row0))
+        return len(self.parts) - 1
+
+    def ensure_acc(self, N):
+        self._acc(self.S if self.sal == 1 else self.S * self.S)
+
+    def finish(self, total_rows, N):
+        S = self.S
+        return self._finish(total_rows, N, (S,) if self.sal == 1 else (S, S))
+
+    def results(self, pid):
+        eng, S, NA, NB, q = self.eng, self.S, self.NA, self.NB, self.q
+        XA, XB, HA, HB, row0 = self.parts[pid]
+        self.parts[pid] = None
+        ga, gb = (NA, NB) if self.groupSize == -1 else (self.groupSize, self.groupSize)
+        HnA, HnB = eng.null_hist(XA, NA, XB, NB, S, ga, gb, self.seed, row0)
+        if self.sal == 1:
+            sA, _ = eng.score_s1_from_binhist(HA, NA, S, q)
+            sB, _ = eng.score_s1_from_binhist(HB, NB, S, q)
+            nA, _ = eng.score_s1_from_binhist(HnA, ga, S, q)
+            nB, _ = eng.score_s1_from_binhist(HnB, gb, S, q)
+        else:                                            # quirk Q9: null halves keep the original groups' permutation counts
+            sA, _ = eng.score_s2_from_binhist(HA, NA, S, q, perms=NA * (NA - 1))
+            sB, _ = eng.score_s2_from_binhist(HB, NB, S, q, perms=NB * (NB - 1))
+            nA, _ = eng.score_s2_from_binhist(HnA, max(ga, NA), S, q, perms=NA * (NA - 1))
+            nB, _ = eng.score_s2_from_binhist(HnB, max(gb, NB), S, q, perms=NB * (NB - 1))
+        delta, _ = eng.pair_finish(sA, sB, want_dist=False)
+        _, null = eng.pair_finish(nA, nB)
+        rdist, mdiff = eng.pair_metrics(delta, roundtrip=True)     # what STEP 4 would recompute from the text
+        quies = eng.quiescent(XA, NA, XB, NB, self.qstate)
+        return {"delta": delta.cpu().numpy(), "null": null.cpu().numpy(), "quies": quies.cpu().numpy().astype(bool),
+                "rdist": rdist.cpu().numpy(), "mdiff": mdiff.cpu().numpy()}
 
 
 def get():

@@ -34,7 +34,8 @@ int score_s1_impl(const int8_t*, int64_t, int32_t, int64_t, int32_t, const float
 int score_s1_from_hist_impl(const uint16_t*, int64_t, int32_t, int32_t, const float*, double*, float*, void*, int64_t, hipStream_t);
 int normalise_i64_impl(const int64_t*, int64_t, float*, void*, int64_t, hipStream_t);
 int normalise_i32_impl(const int32_t*, int64_t, float*, void*, int64_t, hipStream_t);
-int hist_s2_from_binhist_impl(const uint16_t*, int64_t, int32_t, int64_t*, hipStream_t);
+int hist_s2_from_binhist_impl(const uint16_t*, const uint16_t*, int64_t, int32_t, int64_t*, hipStream_t);
+int combine_score_s1_impl(int64_t*, int32_t, const uint16_t*, int64_t, int32_t, int32_t, float*, double*, float*, void*, int64_t, hipStream_t);
 int64_t s2_table_bytes(int, int);
 int score_s2_from_hist_impl(const uint16_t*, int64_t, int32_t, int32_t, int64_t, const float*, double*, float*, void*, int64_t, hipStream_t);
 int pair_finish_impl(const float*, const float*, int64_t, int32_t, float*, float*, hipStream_t);
@@ -80,7 +81,17 @@ int epg_hist_s1(const int8_t* X, int64_t R, int32_t N, int64_t ldx, int32_t S, i
 }
 
 int epg_hist_s2_from_binhist(const uint16_t* H, int64_t R, int32_t S, int64_t* counts, void* stream) {
-    return hist_s2_from_binhist_impl(H, R, S, counts, (hipStream_t)stream);
+    return hist_s2_from_binhist_impl(H, nullptr, R, S, counts, (hipStream_t)stream);
+}
+
+int epg_hist_s2_from_binhist_pair(const uint16_t* HA, const uint16_t* HB, int64_t R, int32_t S, int64_t* counts, void* stream) {
+    if (R > 0 && !HB) return fail(EPG_ERR_INVALID_ARG, "hist_s2_pair: HB is NULL");
+    return hist_s2_from_binhist_impl(HA, HB, R, S, counts, (hipStream_t)stream);
+}
+
+int epg_combine_score_s1(int64_t* counts, int32_t rezero, const uint16_t* H, int64_t R, int32_t N, int32_t S, float* q,
+                         double* out64, float* out32, void* ws, int64_t ws_bytes, void* stream) {
+    return combine_score_s1_impl(counts, rezero, H, R, N, S, q, out64, out32, ws, ws_bytes, (hipStream_t)stream);
 }
 
 int epg_hist_s2(const int8_t* X, int64_t R, int32_t N, int64_t ldx, int32_t S, int64_t* counts, void* ws, int64_t ws_bytes,
@@ -89,7 +100,7 @@ int epg_hist_s2(const int8_t* X, int64_t R, int32_t N, int64_t ldx, int32_t S, i
     uint16_t* H = reinterpret_cast<uint16_t*>(ws);
     int rc = bin_hist_impl(X, R, N, ldx, S, H, nullptr, (hipStream_t)stream);
     if (rc) return rc;
-    return hist_s2_from_binhist_impl(H, R, S, counts, (hipStream_t)stream);
+    return hist_s2_from_binhist_impl(H, nullptr, R, S, counts, (hipStream_t)stream);
 }
 
 int epg_hist_s3(const int8_t* X, int64_t R, int32_t N, int64_t ldx, int32_t S, int32_t* counts, void* ws, int64_t ws_bytes,

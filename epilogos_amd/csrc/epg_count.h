@@ -10,8 +10,11 @@
 // state -- runs at the same speed as uniform data).
 //
 // Bytes that are not states (row padding, chunks past the row end, rows past R) are forced to 0xFF, which has
-// bit 4 and bits 2..3 set and therefore decodes to state 31: never counted for S <= 31.  For the same reason a
-// negative / out-of-range input byte is simply not counted (the expected pass notices sum(counts) != R*N).
+// bits 0..4 set and therefore decodes to state 31: never counted for S <= 31.  Only bits 0..4 of a byte are decoded:
+// an input byte b is counted as state b & 31 when that is < S and not at all otherwise.  So -1 (0xFF) and S..31 are
+// "not a state" (the count check sum(counts) != R*N reports them), while a byte in 32..254 whose low five bits are < S
+// aliases that state -- the contract of the ABI is bytes in 0..31 or 0xFF; the host parser (epg_io.cpp) stores anything
+// outside 0..30 as -1 so that files cannot produce an aliasing byte.
 #pragma once
 #include "epg_common.h"
 

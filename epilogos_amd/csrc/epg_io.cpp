@@ -63,6 +63,7 @@ struct epgio_table {
     std::vector<int8_t> states;     // [rows * cols]
     std::vector<char> loc;          // concatenated "chr\tstart\tend"
     std::vector<int64_t> loc_off;   // [rows + 1]
+    int32_t state_lo = 0, state_hi = 0;   // smallest / largest state value as written in the file (1-based); 0, 0 when empty
 };
 
 extern "C" {
@@ -147,6 +148,7 @@ epgio_table* epgio_open_table(const char* path, int64_t row_lo, int64_t row_hi, 
     // pass 1: location text lengths; pass 2 (after prefix sum): states + location text.  Both per segment.
     std::vector<int> err(T, 0);
     std::vector<int64_t> bad_row(T, -1);
+    std::vector<int> vlo(T, 1 << 30), vhi(T, -(1 << 30));
     auto for_rows = [&](int i, auto&& fn) {
         const char* p = seg[i];
         int64_t r = seg_first[i];
@@ -193,13 +195,26 @@ epgio_table* epgio_open_table(const char* path, int64_t row_lo, int64_t row_hi, 
                         while (q < nl && *q >= '0' && *q <= '9') { v = v * 10 + (*q - '0'); ++q; any = true; if (v > 100000) break; }
                         if (q < nl && *q == '\r') ++q;
                         if (!any || (q < nl && *q != '\t')) { err[i] = 1; if (bad_row[i] < 0) bad_row[i] = r; return; }
-                        v = (neg ? -v : v) - 1;             // file states are 1-based (helpers.py:155)
-                        out[c++] = (int8_t)(v < -128 ? -128 : (v > 127 ? 127 : v));
+                        v = neg ? -v : v;
+                        if (v < vlo[i]) vlo[i] = v;
+                        if (v > vhi[i]) vhi[i] = v;
+                        v -= 1;                             // file states are 1-based (helpers.py:155)
+                        // the kernels decode five bits and treat 31 as "not a state": anything outside 0..30 is stored as
+                        // -1 so that it cannot alias a state; the caller sees it in epgio_table_state_range and in the
+                        // count check (sum of counts != rows * columns)
+                        out[c++] = (int8_t)((v < 0 || v > 30) ? -1 : v);
                     }
                     if (c != cols || q != nl) { err[i] = 1; if (bad_row[i] < 0) bad_row[i] = r; }
                 });
             });
         for (auto& x : th) x.join();
+    }
+    for (int i = 0; i < T; ++i) {
+        if (vlo[i] <= vhi[i]) {
+            if (t->state_lo == 0 && t->state_hi == 0) { t->state_lo = vlo[i]; t->state_hi = vhi[i]; }
+            t->state_lo = std::min(t->state_lo, vlo[i]);
+            t->state_hi = std::max(t->state_hi, vhi[i]);
+        }
     }
     for (int i = 0; i < T; ++i)
         if (err[i]) {
@@ -212,6 +227,13 @@ epgio_table* epgio_open_table(const char* path, int64_t row_lo, int64_t row_hi, 
 
 int64_t epgio_table_rows(const epgio_table* t) { return t ? t->rows : fail("null table"); }
 int32_t epgio_table_cols(const epgio_table* t) { return t ? t->cols : fail("null table"); }
+
+int epgio_table_state_range(const epgio_table* t, int32_t* lo, int32_t* hi) {
+    if (!t) return fail("null table");
+    if (lo) *lo = t->state_lo;
+    if (hi) *hi = t->state_hi;
+    return 0;
+}
 
 int epgio_table_copy_states(const epgio_table* t, int8_t* out, int64_t ldx) {
     if (!t || !out || ldx < t->cols) return fail("copy_states: bad argument");

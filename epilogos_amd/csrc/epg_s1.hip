@@ -100,7 +100,8 @@ __global__ __launch_bounds__(256) void k_bin_hist(const char* __restrict__ X, lo
 }
 
 // Any S <= 127, any N, any alignment, never reads past a row's N bytes: one wave per bin, LDS atomics.
-// Used for the matrix's last row when ldx < 16*ceil(N/16) (the fast kernel's last chunk would over-read).
+// Used for the matrix's last row(s) when ldx < 16*ceil(N/16) (the fast kernel's last chunk would over-read).  Decodes
+// the low five bits of a byte like the fast kernel (see epg_count.h) so that both treat every byte value alike.
 __global__ __launch_bounds__(256) void k_bin_hist_safe(const char* __restrict__ X, long row_begin, long row_end, int N,
                                                         long ldx, int S, u16* __restrict__ H, u64* __restrict__ counts) {
     __shared__ u32 s_h[4][128];
@@ -110,7 +111,7 @@ __global__ __launch_bounds__(256) void k_bin_hist_safe(const char* __restrict__ 
         __builtin_amdgcn_wave_barrier();
         const char* rp = X + row * ldx;
         for (int n = lane; n < N; n += 64) {
-            const int v = (unsigned char)rp[n];
+            const int v = (unsigned char)rp[n] & 31;
             if (v < S) atomicAdd(&s_h[wave][v], 1u);
         }
         __builtin_amdgcn_wave_barrier();
@@ -288,7 +289,10 @@ static void dispatch_bin_hist_ng(const char* X, long R, int N, long ldx, int Sou
 // rows the fast kernel may touch: all of them unless its 16-byte last chunk could run past the allocation
 static long fast_rows(long R, int N, long ldx) {
     const long chunks = (N + 15) / 16;
-    return ldx >= 16 * chunks ? R : R - 1;
+    const long over = 16 * chunks - ldx;           // bytes a row's last chunk reaches past the row pitch
+    if (over <= 0) return R;
+    const long unsafe = (over + ldx - 1) / ldx;    // trailing rows whose last chunk would end past X + R*ldx (N < 16: several)
+    return R > unsafe ? R - unsafe : 0;
 }
 
 int bin_hist_impl(const int8_t* X8, int64_t R, int32_t N, int64_t ldx, int32_t S, uint16_t* H, int64_t* counts,
@@ -314,7 +318,7 @@ int bin_hist_impl(const int8_t* X8, int64_t R, int32_t N, int64_t ldx, int32_t S
         EPG_LAUNCH_CHECK("k_bin_hist");
     }
     if (Rf < R) {
-        hipLaunchKernelGGL(k_bin_hist_safe, dim3(1), dim3(256), 0, st, X, Rf, (long)R, N, ldx, S, H, cnt);
+        hipLaunchKernelGGL(k_bin_hist_safe, dim3((unsigned)((R - Rf + 3) / 4 < 1024 ? (R - Rf + 3) / 4 : 1024)), dim3(256), 0, st, X, Rf, (long)R, N, ldx, S, H, cnt);
         EPG_LAUNCH_CHECK("k_bin_hist_safe");
     }
     return EPG_OK;
@@ -347,7 +351,7 @@ static int64_t s1_table_bytes(int N, int S) { return align_up((int64_t)(N + 1) *
 
 int64_t s1_ws_bytes(int64_t R, int N, int S) {
     // table + room for a cached histogram (used when the fused kernel does not cover this S)
-    return s1_table_bytes(N, S) + align_up(R * S * 2, 256);
+    return s1_table_bytes(N, S) + 256 + align_up(R * S * 2, 256);
 }
 
 static int build_s1_table(const float* q, int N, int S, void* ws, double** T64, float** T32, hipStream_t st) {
@@ -359,18 +363,15 @@ static int build_s1_table(const float* q, int N, int S, void* ws, double** T64, 
     return EPG_OK;
 }
 
-int score_s1_from_hist_impl(const uint16_t* H, int64_t R, int32_t N, int32_t S, const float* q, double* out64,
-                            float* out32, void* ws, int64_t ws_bytes, hipStream_t st) {
-    if (R < 0 || N < 1 || S < 1) return fail(EPG_ERR_INVALID_ARG, "score_s1: bad shape");
-    if (R == 0) return EPG_OK;
-    if (!H || !q || !ws) return fail(EPG_ERR_INVALID_ARG, "score_s1_from_binhist: NULL argument");
-    if (ws_bytes < s1_table_bytes(N, S)) return fail(EPG_ERR_WORKSPACE, "score_s1: workspace %lld < %lld bytes", (long long)ws_bytes, (long long)s1_table_bytes(N, S));
+static int check_score_from_hist_args(const uint16_t* H, const double* out64, const float* out32) {
     if ((reinterpret_cast<uintptr_t>(H) & 7) != 0) return fail(EPG_ERR_INVALID_ARG, "score_s1_from_binhist: H must be 8-byte aligned");
     if ((out32 && (reinterpret_cast<uintptr_t>(out32) & 15)) || (out64 && (reinterpret_cast<uintptr_t>(out64) & 15)))
         return fail(EPG_ERR_INVALID_ARG, "score_s1_from_binhist: outputs must be 16-byte aligned");
-    double* T64; float* T32;
-    int rc = build_s1_table(q, N, S, ws, &T64, &T32, st);
-    if (rc) return rc;
+    return EPG_OK;
+}
+
+static int launch_score_s1_from_hist(const uint16_t* H, int64_t R, int32_t S, const double* T64, const float* T32, double* out64,
+                                     float* out32, hipStream_t st) {
     const long total = (long)R * S;
     long nb = (total / 4 + 1023) / 1024;
     if (nb > num_cus() * 8L) nb = num_cus() * 8L;      // 8 blocks/CU measured best (16: +5 %); nt stores: no gain
@@ -380,6 +381,80 @@ int score_s1_from_hist_impl(const uint16_t* H, int64_t R, int32_t N, int32_t S, 
     if (out64) hipLaunchKernelGGL((k_score_s1_from_hist<double>), dim3(blocks), dim3(256), 0, st, H, total, S, T64, out64);
     EPG_LAUNCH_CHECK("k_score_s1_from_hist");
     return EPG_OK;
+}
+
+int score_s1_from_hist_impl(const uint16_t* H, int64_t R, int32_t N, int32_t S, const float* q, double* out64,
+                            float* out32, void* ws, int64_t ws_bytes, hipStream_t st) {
+    if (R < 0 || N < 1 || S < 1) return fail(EPG_ERR_INVALID_ARG, "score_s1: bad shape");
+    if (R == 0) return EPG_OK;
+    if (!H || !q || !ws) return fail(EPG_ERR_INVALID_ARG, "score_s1_from_binhist: NULL argument");
+    if (ws_bytes < s1_table_bytes(N, S)) return fail(EPG_ERR_WORKSPACE, "score_s1: workspace %lld < %lld bytes", (long long)ws_bytes, (long long)s1_table_bytes(N, S));
+    int rc = check_score_from_hist_args(H, out64, out32);
+    if (rc) return rc;
+    double* T64; float* T32;
+    rc = build_s1_table(q, N, S, ws, &T64, &T32, st);
+    if (rc) return rc;
+    return launch_score_s1_from_hist(H, R, S, T64, T32, out64, out32, st);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// STEP 2 and the S1 table of STEP 3 in ONE single-block launch (a whole S1 job on a 1.9 M-bin shard is ~0.35 ms of kernel
+// time: a memset, two normalise kernels and the table kernel, each with its ~1.7 us boundary and its host call, were a
+// measurable part of it): q = float32(double(C) / double(sum C)) (expectedCombination.py:42), T[c, s] = kl(c / N, q[s])
+// (scores.py:343,550), and optionally counts = 0 for the next job's accumulation.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_s1_combine(u64* __restrict__ counts, int rezero, int N, int S, float* __restrict__ q,
+                                                      double* __restrict__ T64, float* __restrict__ T32) {
+    __shared__ long long s_c[32];
+    __shared__ double s_q[32];
+    const int t = threadIdx.x;
+    if (t < S) s_c[t] = (long long)counts[t];
+    __syncthreads();
+    if (t < S) {
+        long long tot = 0;
+        for (int s = 0; s < S; ++s) tot += s_c[s];
+        const float qf = (float)((double)s_c[t] / (double)tot);
+        q[t] = qf;
+        s_q[t] = (double)qf;
+        if (rezero) counts[t] = 0;
+    }
+    __syncthreads();
+    const int n = (N + 1) * S;
+    for (int e = t; e < n; e += 1024) {
+        const int c = e / S, s = e - c * S;
+        const double v = kl_term((double)c / (double)N, s_q[s]);
+        T64[e] = v;
+        T32[e] = (float)v;
+    }
+}
+
+template <typename IT>
+static int normalise_impl(const IT* C, int64_t n, float* q, void* ws, int64_t ws_bytes, hipStream_t st);
+
+int combine_score_s1_impl(int64_t* counts, int32_t rezero, const uint16_t* H, int64_t R, int32_t N, int32_t S, float* q,
+                          double* out64, float* out32, void* ws, int64_t ws_bytes, hipStream_t st) {
+    if (R < 0 || N < 1 || S < 1) return fail(EPG_ERR_INVALID_ARG, "combine_score_s1: bad shape R=%lld N=%d S=%d", (long long)R, N, S);
+    if (S > 31) return fail(EPG_ERR_UNSUPPORTED, "combine_score_s1: S=%d > 31 not supported by this build", S);
+    if (!counts || !q || !ws || (R > 0 && !H)) return fail(EPG_ERR_INVALID_ARG, "combine_score_s1: NULL argument");
+    if (ws_bytes < s1_table_bytes(N, S)) return fail(EPG_ERR_WORKSPACE, "combine_score_s1: workspace %lld < %lld bytes", (long long)ws_bytes, (long long)s1_table_bytes(N, S));
+    int rc = check_score_from_hist_args(H, out64, out32);
+    if (rc) return rc;
+    double* T64 = reinterpret_cast<double*>(ws);
+    float* T32 = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + align_up((int64_t)(N + 1) * S * 8, 256));
+    if ((long)(N + 1) * S <= (1L << 18)) {
+        hipLaunchKernelGGL(k_s1_combine, dim3(1), dim3(1024), 0, st, reinterpret_cast<u64*>(counts), rezero, N, S, q, T64, T32);
+        EPG_LAUNCH_CHECK("k_s1_combine");
+    } else {                                               // a table too long for one block: the separate kernels
+        if (ws_bytes < s1_table_bytes(N, S) + 256) return fail(EPG_ERR_WORKSPACE, "combine_score_s1: workspace too small");
+        void* tot = reinterpret_cast<char*>(ws) + s1_table_bytes(N, S);
+        rc = normalise_impl<long long>(reinterpret_cast<const long long*>(counts), S, q, tot, 256, st);
+        if (rc) return rc;
+        if (rezero) EPG_HIP(hipMemsetAsync(counts, 0, (size_t)S * 8, st));
+        rc = build_s1_table(q, N, S, ws, &T64, &T32, st);
+        if (rc) return rc;
+    }
+    if (R == 0) return EPG_OK;
+    return launch_score_s1_from_hist(H, R, S, T64, T32, out64, out32, st);
 }
 
 int score_s1_impl(const int8_t* X8, int64_t R, int32_t N, int64_t ldx, int32_t S, const float* q, double* out64,

@@ -18,7 +18,10 @@ constexpr int S2H_ROLES = 3;                 // 256 threads x 3 >= S(S+1)/2 + S 
 constexpr int S2H_LD = S2H_PAIRS + 1;        // row stride of the pair matrix in words: odd, rows start on different banks
 typedef unsigned short v2u16 __attribute__((ext_vector_type(2)));
 
-__global__ __launch_bounds__(256) void k_s2_hist_from_binhist(const u16* __restrict__ H, long R, int S,
+// H2 (may be NULL): a second histogram array of the same shape, added bin by bin before the products -- the counts of the
+// column concatenation [A|B] of paired mode (helpers.py:173) from the two groups' histograms (halves cannot carry: a
+// bin's count over both groups is at most N_A + N_B <= 65535).
+__global__ __launch_bounds__(256) void k_s2_hist_from_binhist(const u16* __restrict__ H, const u16* __restrict__ H2, long R, int S,
                                                                u64* __restrict__ counts) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     u16* s_raw = reinterpret_cast<u16*>(smem);                                   // [S2H_BATCH][S]
@@ -52,10 +55,20 @@ __global__ __launch_bounds__(256) void k_s2_hist_from_binhist(const u16* __restr
         if (batch >= nb || w >= nw) return v;
         const long off = batch * (256L * S) + 16L * w;
         const char* src = reinterpret_cast<const char*>(H) + off;
-        if (off + 16 <= total_bytes) return *reinterpret_cast<const uint4*>(src);
+        if (off + 16 <= total_bytes) {
+            v = *reinterpret_cast<const uint4*>(src);
+            if (H2) {
+                const uint4 v2 = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(H2) + off);
+                v.x += v2.x; v.y += v2.y; v.z += v2.z; v.w += v2.w;
+            }
+            return v;
+        }
         u16 t[8] = {0, 0, 0, 0, 0, 0, 0, 0};                                       // the words around the end of H
         for (int k = 0; k < 8; ++k)
-            if (off + 2 * k < total_bytes) t[k] = *reinterpret_cast<const u16*>(src + 2 * k);
+            if (off + 2 * k < total_bytes) {
+                t[k] = *reinterpret_cast<const u16*>(src + 2 * k);
+                if (H2) t[k] = (u16)(t[k] + *reinterpret_cast<const u16*>(reinterpret_cast<const char*>(H2) + off + 2 * k));
+            }
         return make_uint4(t[0] | (u32)t[1] << 16, t[2] | (u32)t[3] << 16, t[4] | (u32)t[5] << 16, t[6] | (u32)t[7] << 16);
     };
     uint4 pre0 = fetch(blockIdx.x, threadIdx.x), pre1 = fetch(blockIdx.x, threadIdx.x + 256);
@@ -383,15 +396,15 @@ __global__ __launch_bounds__(256) void k_quiescent(const char* __restrict__ XA, 
 // ---------------------------------------------------------------------------------------------------------------
 // host-side dispatch
 // ---------------------------------------------------------------------------------------------------------------
-int hist_s2_from_binhist_impl(const uint16_t* H, int64_t R, int32_t S, int64_t* counts, hipStream_t st) {
+int hist_s2_from_binhist_impl(const uint16_t* H, const uint16_t* H2, int64_t R, int32_t S, int64_t* counts, hipStream_t st) {
     if (R < 0 || S < 1 || S > 31) return fail(EPG_ERR_INVALID_ARG, "hist_s2: bad shape R=%lld S=%d", (long long)R, S);
     if (R == 0) return EPG_OK;
     if (!H || !counts) return fail(EPG_ERR_INVALID_ARG, "hist_s2: NULL argument");
     const long nb = (R + S2H_BATCH - 1) / S2H_BATCH;
-    if (reinterpret_cast<uintptr_t>(H) & 15) return fail(EPG_ERR_INVALID_ARG, "hist_s2: H must be 16-byte aligned");
+    if ((reinterpret_cast<uintptr_t>(H) & 15) || (reinterpret_cast<uintptr_t>(H2) & 15)) return fail(EPG_ERR_INVALID_ARG, "hist_s2: H must be 16-byte aligned");
     long blocks = nb < num_cus() * 8L ? nb : num_cus() * 8L;
     const size_t shmem = (((size_t)S2H_BATCH * S * 2 + 15) & ~(size_t)15) + (size_t)S * S2H_LD * 4;
-    hipLaunchKernelGGL(k_s2_hist_from_binhist, dim3((int)blocks), dim3(256), shmem, st, H, (long)R, S,
+    hipLaunchKernelGGL(k_s2_hist_from_binhist, dim3((int)blocks), dim3(256), shmem, st, H, H2, (long)R, S,
                        reinterpret_cast<u64*>(counts));
     EPG_LAUNCH_CHECK("k_s2_hist_from_binhist");
     return EPG_OK;

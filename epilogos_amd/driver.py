@@ -5,18 +5,28 @@ The bins of all input files, concatenated in file order, are split with the refe
 (helpers.py:116-118): rank g of G owns global bins [g*R//G, (g+1)*R//G).  Pass 1 counts locally, one
 all-reduce(SUM) over torch.distributed (backend nccl = RCCL over xGMI on GPUs; gloo in the CPU tests) makes the
 counts global, every rank normalises identically, pass 2 scores locally with no further communication.  Integer
-sums make the result independent of G and of the reduction order.  Outputs keep the reference's names: every rank
-writes gzip members for its bin ranges and rank 0 concatenates them per chromosome (a multi-member gzip file is
-a valid gzip file)."""
+sums make the result independent of G and of the reduction order.
+
+Data flow of a rank (the pipeline bench.py times, plus the host ends):
+  parser threads (files in parallel, native inflate + parse straight into pinned, row-padded staging buffers)
+  -> ONE asynchronous H2D copy per part -> count pass (k_bin_hist ...) whose per-bin histograms (S1/S2) or state matrix
+  (S3, paired) STAY in HBM -> all-reduce -> count check + normalise -> score pass from the resident data -> D2H of the
+  float32 scores -> native "%.5f" + gzip writer threads.  Host memory holds the parts in flight, not the genome.
+Outputs keep the reference's names.  A file that lies inside one rank's range is written by that rank under its final
+name; a file cut by a range border is written as gzip members named from the partition plan (file index + first row)
+and concatenated by rank 0 (a multi-member gzip file is a valid gzip file).  The arrays STEP 4 needs travel to rank 0
+through torch.distributed send/recv, not through the file system."""
 import os
 import shutil
+from concurrent.futures import ThreadPoolExecutor
+from contextlib import closing
 from pathlib import Path
 
 import numpy as np
 
 from . import _io
 from . import backend as _backend
-from .helpers import countRows, fileStem, readLocations, readStates, readTable, splitRows
+from .helpers import countRows, fileStem, readStates, readTable, splitRows
 from .scores import writeScores
 
 
@@ -50,6 +60,13 @@ class _Timer:
             print("    [timing] %-34s %7.2f s" % (label, now - self.t), flush=True)
             self.t = now
 
+    def note(self, text):
+        if self.on:
+            print("    [timing] " + text, flush=True)
+
+
+_DTYPES = [np.float32, np.uint8, np.int64, np.int32, np.bool_]
+
 
 class _Dist:
     """Thin wrapper so that the single-process case needs no process group."""
@@ -59,15 +76,20 @@ class _Dist:
         self.dist = dist if dist.is_available() and dist.is_initialized() else None
         self.rank = self.dist.get_rank() if self.dist else 0
         self.world = self.dist.get_world_size() if self.dist else 1
+        self.comm_device = None
+        if self.dist and self.dist.get_backend() == "nccl":         # RCCL moves device tensors only
+            import torch
+            self.comm_device = torch.device("cuda", torch.cuda.current_device())
 
     def all_reduce_counts(self, counts, device=None):
-        """SUM-all-reduce an integer numpy array; on GPUs the tensor lives on the device so RCCL moves it over xGMI."""
+        """SUM-all-reduce an integer numpy array (host-array backends; the product backend reduces its device tensor)."""
         if not self.dist:
             return counts
         import torch
         t = torch.from_numpy(np.ascontiguousarray(counts))
-        if device is not None:
-            t = t.to(device)
+        dev = device if device is not None else self.comm_device
+        if dev is not None:
+            t = t.to(dev)
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
         return t.cpu().numpy().reshape(counts.shape)
 
@@ -81,77 +103,248 @@ class _Dist:
         if self.dist:
             self.dist.barrier()
 
+    # point-to-point hand-over of result arrays to rank 0: a small header (dtype, shape), then the bytes
+    def _tensor(self, arr):
+        import torch
+        t = torch.from_numpy(arr)
+        return t.to(self.comm_device) if self.comm_device is not None else t
 
+    def send_arrays(self, arrays, dst):
+        import torch
+        for a in arrays:
+            a = np.ascontiguousarray(a)
+            if a.ndim > 2:
+                raise ValueError("send_arrays: at most two dimensions")
+            shape = list(a.shape) + [1] * (2 - a.ndim)
+            head = np.array([_DTYPES.index(a.dtype.type), a.ndim] + shape, dtype=np.int64)
+            self.dist.send(self._tensor(head), dst)
+            if a.size:
+                self.dist.send(self._tensor(a.reshape(-1).view(np.uint8)), dst)
+
+    def recv_arrays(self, n, src):
+        import torch
+        out = []
+        for _ in range(n):
+            head = torch.zeros(4, dtype=torch.int64, device=self.comm_device)
+            self.dist.recv(head, src)
+            code, ndim, d0, d1 = (int(v) for v in head.cpu().tolist())
+            dtype = np.dtype(_DTYPES[code])
+            shape = (d0, d1)[:ndim]
+            nbytes = int(np.prod(shape)) * dtype.itemsize
+            if nbytes:
+                buf = torch.empty(nbytes, dtype=torch.uint8, device=self.comm_device)
+                self.dist.recv(buf, src)
+                out.append(buf.cpu().numpy().view(dtype).reshape(shape))
+            else:
+                out.append(np.zeros(shape, dtype=dtype))
+        return out
+
+
+# ---- sessions over a host-array backend (the oracle-backed stand-in of the CPU tests): same protocol as the device-
+# resident sessions of backend.HipBackend, arithmetic through the backend's array methods
+class _HostSession:
+    def __init__(self, be, S, saliency):
+        self.be, self.S, self.sal = be, S, saliency
+        self.counts, self.parts, self.q = None, [], None
+        self.n_uploads = 0
+
+    def alloc(self, ticket):
+        return None
+
+    def skip(self, ticket):
+        pass
+
+    def _add_counts(self, c):
+        self.counts = c if self.counts is None else self.counts + c
+
+    def all_reduce(self, d):
+        self.counts = d.all_reduce_counts(self.counts)
+
+    def _finish(self, total_rows, N, shape):
+        self.be.check_counts(self.counts, total_rows, N, self.sal)
+        self.q = self.be.normalise(self.counts)
+        return self.q
+
+
+class _HostSingleSession(_HostSession):
+    def add_part(self, arr, N, ticket):
+        x = arr[:, :N]
+        self._add_counts(self.be.expected_counts(x, self.S, self.sal))
+        self.parts.append(x)
+        return len(self.parts) - 1
+
+    def ensure_acc(self, N):
+        if self.counts is None:                        # a rank without bins still takes part in the all-reduce
+            S = self.S
+            self.counts = np.zeros({1: (S,), 2: (S, S), 3: (N, N, S, S)}[self.sal], dtype=np.int32 if self.sal == 3 else np.int64)
+
+    def finish(self, total_rows, N):
+        S = self.S
+        return self._finish(total_rows, N, {1: (S,), 2: (S, S), 3: (N, N, S, S)}[self.sal])
+
+    def scores(self, pid):
+        x, self.parts[pid] = self.parts[pid], None
+        return self.be.scores(x, self.S, self.sal, self.q)
+
+
+class _HostPairedSession(_HostSession):
+    def __init__(self, be, S, saliency, quiescentState, groupSize, seed):
+        super().__init__(be, S, saliency)
+        self.qstate, self.groupSize, self.seed = quiescentState, groupSize, seed
+
+    def add_part(self, arrA, NA, ticketA, arrB, NB, ticketB, row0):
+        xa, xb = arrA[:, :NA], arrB[:, :NB]
+        self._add_counts(self.be.expected_counts(np.concatenate((xa, xb), axis=1), self.S, self.sal))
+        self.parts.append((xa, xb, row0))
+        return len(self.parts) - 1
+
+    def ensure_acc(self, N):
+        if self.counts is None:
+            self.counts = np.zeros((self.S,) if self.sal == 1 else (self.S, self.S), dtype=np.int64)
+
+    def finish(self, total_rows, N):
+        return self._finish(total_rows, N, (self.S,) if self.sal == 1 else (self.S, self.S))
+
+    def results(self, pid):
+        be, S, sal, q = self.be, self.S, self.sal, self.q
+        (xa, xb, row0), self.parts[pid] = self.parts[pid], None
+        n1, n2 = xa.shape[1], xb.shape[1]
+        s1 = be.scores(xa, S, sal, q, perms=n1 * (n1 - 1))
+        s2 = be.scores(xb, S, sal, q, perms=n2 * (n2 - 1))
+        na, nb = be.null_scores(xa, xb, S, sal, q, self.groupSize, self.seed, row0=row0)
+        delta, _ = be.pair_finish(s1, s2)
+        _, null = be.pair_finish(na, nb)
+        rdist, mdiff = be.pair_metrics(delta, roundtrip=True)      # what STEP 4 would recompute from the text
+        return {"delta": delta, "null": null, "quies": be.quiescent(xa, xb, self.qstate), "rdist": rdist, "mdiff": mdiff}
+
+
+def _open_single(be, S, saliency):
+    return be.open_single(S, saliency) if hasattr(be, "open_single") else _HostSingleSession(be, S, saliency)
+
+
+def _open_paired(be, S, saliency, quiescentState, groupSize, seed):
+    if hasattr(be, "open_paired"):
+        return be.open_paired(S, saliency, quiescentState, groupSize, seed)
+    return _HostPairedSession(be, S, saliency, quiescentState, groupSize, seed)
+
+
+# ---- input side
 def _count_rows(files):
     """countRows of every file (a gunzip pass each), files in parallel: the native counter releases the GIL."""
-    from concurrent.futures import ThreadPoolExecutor
     with ThreadPoolExecutor(max_workers=max(1, min(16, len(files)))) as pool:
         return list(pool.map(countRows, files))
 
 
-def _read_parts(files, parts):
-    """readTable of every (file, lo, hi) of this rank, files in parallel (gz inflate is serial per file); hi = None
-    reads to the last complete line, which is what countRows counts (helpers.py:94)."""
-    from concurrent.futures import ThreadPoolExecutor
-    with ThreadPoolExecutor(max_workers=max(1, min(8, len(parts)))) as pool:
-        return list(pool.map(lambda part: readTable(files[part[0]], None if part[2] is None else (part[1], part[2])), parts))
+def _check_range(path, rng, numStates):
+    """The reference indexes a numStates-long array with (file value - 1) and dies on anything outside the model
+    (expected.py:113 IndexError); a state model smaller than the data must not run to completion here either."""
+    lo, hi = rng
+    if (lo, hi) != (0, 0) and (lo < 1 or hi > numStates):
+        raise ValueError("{}: state values {}..{} are outside the {}-state model (1..{})".format(path, lo, hi, numStates, numStates))
 
 
-def _plan_and_read(files, d, tm):
-    """(rows per file, this rank's parts, their parsed tables).  A single rank reads whole files and takes the row counts
-    from the parse instead of a separate gunzip pass per file."""
-    if d.world == 1:
-        tables = _read_parts(files, [(fi, 0, None) for fi in range(len(files))])
-        rows = [t[0].shape[0] for t in tables]
-        tm.lap("parse (row counts included)")
-        return rows, [(fi, 0, rows[fi]) for fi in range(len(files))], tables
-    rows = _count_rows(files)
-    tm.lap("count rows")
-    parts = plan_partition(rows, d.world)[d.rank]
-    tables = _read_parts(files, parts)
-    tm.lap("parse")
-    return rows, parts, tables
+def _stream_parts(jobs, sess, numStates):
+    """jobs: [(path, lo, hi or None)].  Parses ahead in threads (inflate is serial per file, files run in parallel; the
+    native parser releases the GIL) and yields (ticket, states [rows, width], N, Locations) in job order.  Destinations
+    come from the session (pinned staging, handed out in ticket order, which also bounds the host memory in flight)."""
+    workers = max(1, min(int(os.environ.get("EPILOGOS_PARSE_WORKERS", "8")), len(jobs)))
+
+    def read(ticket):
+        path, lo, hi = jobs[ticket]
+        N = [None]
+        alloc0 = sess.alloc(ticket)
+
+        def alloc(R, n):
+            N[0] = n
+            return alloc0(R, n) if alloc0 is not None else np.empty((R, n), dtype=np.int8)
+        try:
+            arr, loc, rng = readTable(path, None if hi is None else (lo, hi), alloc=alloc, with_range=True)
+        except BaseException:
+            sess.skip(ticket)
+            raise
+        return arr, N[0], loc, rng
+
+    pool = ThreadPoolExecutor(max_workers=workers)
+    try:
+        futs = [pool.submit(read, t) for t in range(len(jobs))]
+        for t, f in enumerate(futs):
+            arr, N, loc, rng = f.result()
+            _check_range(jobs[t][0], rng, numStates)
+            yield t, arr, N, loc
+    except BaseException:
+        if hasattr(sess, "pool"):
+            sess.pool.abort()
+        for f in futs:
+            f.cancel()
+        raise
+    finally:
+        pool.shutdown(wait=True)
 
 
-def _publish(outputDir, kind, fileTag, stem, lo, rank, payload, mine):
-    """Hand a part's arrays to rank 0: kept in memory on rank 0 itself, an uncompressed .npz part file otherwise."""
-    if rank == 0:
-        mine.setdefault(stem, []).append((lo, payload))
-    else:
-        np.savez(outputDir / ".part_{}_{}_{}_{:012d}.npz".format(kind, fileTag, stem, lo), **payload)
+def _columns_of(path):
+    return readStates(file1Path=path, rowsToCalc=(0, 1), verbose=False).shape[1]
 
 
-def _collect(outputDir, kind, fileTag, stem, mine):
-    """All parts of one file in bin order (rank 0): its own from memory, the other ranks' from their part files."""
-    parts = list(mine.get(stem, []))
-    prefix = ".part_{}_{}_{}_".format(kind, fileTag, stem)
-    for p in outputDir.glob(prefix + "*.npz"):
-        with np.load(p) as z:
-            parts.append((int(p.name[len(prefix):-4]), {k: z[k] for k in z.files}))
-        os.remove(p)
-    parts.sort(key=lambda t: t[0])
-    return [pl for _, pl in parts]
+def _part_name(kind, fileTag, fi, lo):
+    return ".part_{}_{}_f{:04d}_{:012d}.gz".format(kind, fileTag, fi, lo)
+
+
+def _clean_parts(outputDir, kind, fileTag):
+    """Part files of a crashed earlier run with the same tag must not be mistaken for this run's."""
+    import re
+    pat = re.compile(r"^\.part_{}_{}_f\d{{4}}_\d{{12}}\.gz$".format(re.escape(kind), re.escape(fileTag)))
+    for p in outputDir.iterdir():
+        if pat.match(p.name):
+            p.unlink()
+
+
+def _assemble_text(outputDir, kind, final_name, fileTag, fi, owners, rows_fi):
+    """Rank 0: a file cut by range borders is the concatenation of its parts' gzip members, in row order, by the exact
+    names the plan gives; a file with one owner was written under its final name already."""
+    if len(owners) == 1 and owners[0] == (0, rows_fi):
+        return
+    with open(outputDir / final_name, "wb") as out:
+        for lo, _hi in owners:
+            p = outputDir / _part_name(kind, fileTag, fi, lo)
+            with open(p, "rb") as src:
+                shutil.copyfileobj(src, out)
+            p.unlink()
 
 
 def _cat(arrs, empty):
     return np.concatenate(arrs) if arrs else empty
 
 
-def _cat_locations(parts):
-    blobs = [pl["loc_blob"] for pl in parts]
+def _cat_locations(locs):
+    blobs = [np.asarray(l.blob) for l in locs]
     offs, base = [np.zeros(1, dtype=np.int64)], 0
-    for pl in parts:
-        offs.append(pl["loc_off"][1:] + base)
-        base += int(pl["loc_off"][-1])
+    for l in locs:
+        offs.append(np.asarray(l.offsets[1:]) + base)
+        base += int(l.offsets[-1])
     return _io.Locations(_cat(blobs, np.zeros(0, dtype=np.uint8)), np.concatenate(offs))
 
 
-def _cat_gzip_members(outputDir, name, pattern):
-    with open(outputDir / name, "wb") as out:
-        for p in sorted(outputDir.glob(pattern)):
-            with open(p, "rb") as src:
-                shutil.copyfileobj(src, out)
-            os.remove(p)
+def _gather_parts(d, plans, my_payloads, n_arrays):
+    """Rank 0 collects every part's arrays in plan order: {(file, lo): [arrays]}; the other ranks send theirs."""
+    if d.rank != 0:
+        for payload in my_payloads:
+            d.send_arrays(payload, 0)
+        return None
+    got = {}
+    for r, parts in enumerate(plans):
+        for k, (fi, lo, hi) in enumerate(parts):
+            got[(fi, lo)] = my_payloads[k] if r == 0 else d.recv_arrays(n_arrays, r)
+    return got
+
+
+def _plan(files, d, tm, known_rows=None):
+    """(rows per file or None, jobs of this rank).  A single rank reads whole files and learns the row counts from the
+    parse instead of a separate gunzip pass per file."""
+    if d.world == 1:
+        return None, [(fi, 0, None) for fi in range(len(files))]
+    rows = _count_rows(files)
+    tm.lap("count rows")
+    return rows, plan_partition(rows, d.world)[d.rank]
 
 
 def run_single_group(files, numStates, saliency, outputDir, fileTag, verbose=False, backend=None, device=None,
@@ -165,56 +358,63 @@ def run_single_group(files, numStates, saliency, outputDir, fileTag, verbose=Fal
     files = [Path(f) for f in files]
     outputDir = Path(outputDir)
     tm = _Timer(d.rank)
-    rows, my_parts, tables = _plan_and_read(files, d, tm)
+    if d.rank == 0:
+        _clean_parts(outputDir, "scores", fileTag)
+    d.barrier()
+    rows, my_parts = _plan(files, d, tm)
+    sess = _open_single(be, numStates, saliency)
 
-    # STEP 1: local counts over my bin ranges
-    N = tables[0][0].shape[1] if tables else readStates(file1Path=files[0], rowsToCalc=(0, 1), verbose=False).shape[1]
-    shape = {1: (numStates,), 2: (numStates, numStates), 3: (N, N, numStates, numStates)}[saliency]
-    if hasattr(be, "counts_begin"):              # product backend: counts stay in HBM through all-reduce and normalise
-        acc = be.counts_begin(numStates, saliency, N)
-        for x, _ in tables:
-            be.counts_add(acc, x, numStates, saliency)
-        tm.lap("expected counts")
-        d.all_reduce_tensor(acc)                 # the one exchange step; a rank without bins contributes zeros
-        q_score, q = be.counts_finish(acc, shape)
-        del acc
-    else:
-        counts = np.zeros(shape, dtype=np.int32 if saliency == 3 else np.int64)
-        for x, _ in tables:
-            counts = counts + be.expected_counts(x, numStates, saliency)
-        tm.lap("expected counts")
-        counts = d.all_reduce_counts(counts, device=device)
-        q = be.normalise(counts)                 # STEP 2: identical normalisation on every rank
-        q_score = q
+    # STEP 1: every part of this rank is parsed, uploaded once and counted; what the score pass needs stays resident
+    pids, locs, N = [], [], None
+    with closing(_stream_parts([(files[fi], lo, hi) for fi, lo, hi in my_parts], sess, numStates)) as stream:
+        for t, arr, n, loc in stream:
+            N = n
+            pids.append(sess.add_part(arr, n, t))
+            locs.append(loc)
+    if rows is None:
+        rows = [len(l) for l in locs]
+        my_parts = [(fi, 0, rows[fi]) for fi in range(len(files))]
+    plans = plan_partition(rows, d.world) if d.world > 1 else [my_parts]
+    if N is None:
+        N = _columns_of(files[0])
+    tm.lap("parse + upload + expected counts")
+    sess.ensure_acc(N)
+    sess.all_reduce(d)                                # the one exchange step; a rank without bins contributes zeros
+    q = sess.finish(int(sum(rows)), N)                # count check, STEP 2: identical normalisation on every rank
     if d.rank == 0:
         np.save(outputDir / "exp_freq_{}.npy".format(fileTag), q, allow_pickle=False)
-    tm.lap("all-reduce + normalise")
+    tm.lap("all-reduce + check + normalise")
 
-    # STEP 3: local scores, written as gzip members per (file, range)
-    mine = {}
-    t_sc = t_wr = 0.0
-    for (fi, lo, hi), (x, loc) in zip(my_parts, tables):
-        t0 = tm.time()
-        sc = be.scores(x, numStates, saliency, q_score)
-        t1 = tm.time()
-        stem = fileStem(files[fi])
-        writeScores(sc, outputDir / ".part_scores_{}_{}_{:012d}.gz".format(fileTag, stem, lo), loc)
-        _publish(outputDir, "scores", fileTag, stem, lo, d.rank, {"scores": sc, "loc_blob": loc.blob, "loc_off": loc.offsets}, mine)
-        t_sc += t1 - t0
-        t_wr += tm.time() - t1
-    if tm.on:
-        print("    [timing] %-34s %7.2f s\n    [timing] %-34s %7.2f s" % ("scores (upload + kernels + download)", t_sc, "write text", t_wr), flush=True)
-        tm.t = tm.time()
+    # STEP 3: scores from the resident data; text is formatted and compressed by writer threads while the next part scores
+    payloads = []
+    with ThreadPoolExecutor(max_workers=2) as writer:
+        jobs = []
+        for k, (fi, lo, hi) in enumerate(my_parts):
+            sc = sess.scores(pids[k])
+            whole = lo == 0 and hi == rows[fi]
+            name = "scores_{}_{}.txt.gz".format(fileTag, fileStem(files[fi])) if whole else _part_name("scores", fileTag, fi, lo)
+            jobs.append(writer.submit(writeScores, sc, outputDir / name, locs[k]))
+            payloads.append([sc, np.asarray(locs[k].blob), np.asarray(locs[k].offsets)])
+        tm.lap("scores (kernels + download)")
+        for j in jobs:
+            j.result()
+    tm.lap("write text (overlapped tail)")
+    tm.note("H2D uploads: %d for %d part(s)" % (getattr(sess, "n_uploads", 0), len(my_parts)))
     d.barrier()
+    got = _gather_parts(d, plans, payloads, 3)
     results = None
     if d.rank == 0:
         results = {}
-        for f in files:
+        for fi, f in enumerate(files):
             stem = fileStem(f)
-            _cat_gzip_members(outputDir, "scores_{}_{}.txt.gz".format(fileTag, stem), ".part_scores_{}_{}_*.gz".format(fileTag, stem))
-            parts = _collect(outputDir, "scores", fileTag, stem, mine)
-            scoreArr = _cat([pl["scores"] for pl in parts], np.zeros((0, numStates), dtype=np.float32))
-            loc = _cat_locations(parts)
+            owners = sorted((lo, hi) for parts in plans for (pf, lo, hi) in parts if pf == fi)
+            _assemble_text(outputDir, "scores", "scores_{}_{}.txt.gz".format(fileTag, stem), fileTag, fi, owners, rows[fi])
+            if not owners:                             # an empty input file still gets its (empty) output
+                writeScores(np.zeros((0, numStates), dtype=np.float32), outputDir / "scores_{}_{}.txt.gz".format(fileTag, stem),
+                            _io.Locations(np.zeros(0, dtype=np.uint8), np.zeros(1, dtype=np.int64)))
+            parts = [got[(fi, lo)] for lo, _ in owners]
+            scoreArr = _cat([p[0] for p in parts], np.zeros((0, numStates), dtype=np.float32))
+            loc = _cat_locations([_io.Locations(p[1], p[2]) for p in parts])
             chrName = loc.slice(0, 1).to_object_array()[0, 0] if len(loc) else ""
             results[stem] = (chrName, scoreArr, loc)
             if keep_temp_scores:
@@ -228,9 +428,10 @@ def run_single_group(files, numStates, saliency, outputDir, fileTag, verbose=Fal
 def run_paired_groups(files1, files2, numStates, saliency, outputDir, fileTag, quiescentState, groupSize, nullSeed,
                       verbose=False, backend=None, device=None, keep_temps=True):
     """STEP 1-3 of paired mode (reference run.py:205-221,258-279 + scores.py:172-256) over the bin-range partition.
-    Background counts are taken over the column concatenation [A|B] (helpers.py:173), all-reduced once; each rank then
-    scores A, B and the two shuffled null groups of its bins.  The null shuffle is keyed by (seed, global bin index), so
-    the outputs do not depend on the number of GPUs.  Returns (exp_freq, results); results (rank 0) maps file stem ->
+    Background counts are taken over the column concatenation [A|B] (helpers.py:173) -- from the two groups' own
+    histograms, each group is uploaded once -- all-reduced once; each rank then scores A, B and the two shuffled null
+    groups of its bins from the resident data.  The null shuffle is keyed by (seed, global bin index), so the outputs
+    do not depend on the number of GPUs.  Returns (exp_freq, results); results (rank 0) maps file stem ->
     dict(chrName, locations, nullDistances, quiescenceArr, distances, maxDiff) for an in-process STEP 4; keep_temps
     also writes temp_nullDistances / temp_quiescence (the reference's, scores.py:246-255) and temp_pairMetrics (the
     side-car of this engine's STEP 4)."""
@@ -239,57 +440,79 @@ def run_paired_groups(files1, files2, numStates, saliency, outputDir, fileTag, q
     files1, files2 = [Path(f) for f in files1], [Path(f) for f in files2]
     outputDir = Path(outputDir)
     tm = _Timer(d.rank)
-    rows, my_parts, ta = _plan_and_read(files1, d, tm)
-    file_start = np.concatenate([[0], np.cumsum(rows)]).astype(np.int64)
-    tb = _read_parts(files2, my_parts)                       # the second group follows the first one's row ranges
-    tm.lap("parse group 2")
-    counts, chunks = None, []
-    for (fi, lo, hi), (xa, loc), (xb, _) in zip(my_parts, ta, tb):
-        if xb.shape[0] != xa.shape[0]:
-            raise ValueError("paired inputs differ in length: {} vs {}".format(files1[fi], files2[fi]))
-        chunks.append((xa, xb, loc))
-        c = be.expected_counts(np.concatenate((xa, xb), axis=1), numStates, saliency)
-        counts = c if counts is None else counts + c
-    del ta, tb
-    if counts is None:
-        counts = np.zeros((numStates,) if saliency == 1 else (numStates, numStates), dtype=np.int64)
-    counts = d.all_reduce_counts(counts, device=device)
-    q = be.normalise(counts)
+    if d.rank == 0:
+        _clean_parts(outputDir, "pairwiseDelta", fileTag)
+    d.barrier()
+    rows, my_parts = _plan(files1, d, tm)
+    sess = _open_paired(be, numStates, saliency, quiescentState, groupSize, nullSeed)
+
+    # group 1 and group 2 of a part are jobs 2k and 2k + 1; the second group follows the first one's row ranges
+    jobs = []
+    for fi, lo, hi in my_parts:
+        jobs += [(files1[fi], lo, hi), (files2[fi], lo, hi)]
+    locs, NA, NB, seen = [], None, None, 0
+    with closing(_stream_parts(jobs, sess, numStates)) as stream:
+        for k, (fi, lo, hi) in enumerate(my_parts):
+            ta, xa, NA, loc = next(stream)
+            tb, xb, NB, _ = next(stream)
+            if xb.shape[0] != xa.shape[0]:
+                raise ValueError("paired inputs differ in length: {} vs {}".format(files1[fi], files2[fi]))
+            # global bin index of the part's first row (keys the null shuffle): from the plan, or -- one rank reading whole
+            # files in order -- the rows seen so far
+            row0 = int(sum(rows[:fi])) + lo if rows is not None else seen
+            sess.add_part(xa, NA, ta, xb, NB, tb, row0)
+            locs.append(loc)
+            seen += len(loc)
+    if rows is None:                                   # single rank: row counts come from the parse
+        rows = [len(l) for l in locs]
+        my_parts = [(fi, 0, rows[fi]) for fi in range(len(files1))]
+    plans = plan_partition(rows, d.world) if d.world > 1 else [my_parts]
+    if NA is None:
+        NA, NB = _columns_of(files1[0]), _columns_of(files2[0])
+    tm.lap("parse + upload + expected counts")
+    sess.ensure_acc(NA + NB)
+    sess.all_reduce(d)
+    q = sess.finish(int(sum(rows)), NA + NB)
     if d.rank == 0:
         np.save(outputDir / "exp_freq_{}.npy".format(fileTag), q, allow_pickle=False)
-    tm.lap("expected counts + all-reduce")
+    tm.lap("all-reduce + check + normalise")
 
-    mine = {}
-    for (fi, lo, hi), (xa, xb, loc) in zip(my_parts, chunks):
-        n1, n2 = xa.shape[1], xb.shape[1]
-        s1 = be.scores(xa, numStates, saliency, q, perms=n1 * (n1 - 1))
-        s2 = be.scores(xb, numStates, saliency, q, perms=n2 * (n2 - 1))
-        na, nb = be.null_scores(xa, xb, numStates, saliency, q, groupSize, nullSeed, row0=int(file_start[fi] + lo))
-        delta, _ = be.pair_finish(s1, s2)
-        _, dist = be.pair_finish(na, nb)
-        real_dist, maxdiff = be.pair_metrics(delta, roundtrip=True)      # what STEP 4 would recompute from the text
-        quies = be.quiescent(xa, xb, quiescentState)
-        stem = fileStem(files1[fi])
-        writeScores(delta, outputDir / ".part_pairwiseDelta_{}_{}_{:012d}.gz".format(fileTag, stem, lo), loc)
-        _publish(outputDir, "pair", fileTag, stem, lo, d.rank,
-                 {"null": dist, "quies": quies, "rdist": real_dist, "mdiff": maxdiff, "loc_blob": loc.blob, "loc_off": loc.offsets}, mine)
+    payloads = []
+    with ThreadPoolExecutor(max_workers=2) as writer:
+        wjobs = []
+        for k, (fi, lo, hi) in enumerate(my_parts):
+            res = sess.results(k)
+            whole = lo == 0 and hi == rows[fi]
+            name = ("pairwiseDelta_{}_{}.txt.gz".format(fileTag, fileStem(files1[fi])) if whole
+                    else _part_name("pairwiseDelta", fileTag, fi, lo))
+            wjobs.append(writer.submit(writeScores, res["delta"], outputDir / name, locs[k]))
+            payloads.append([np.asarray(res["null"], dtype=np.float32), np.asarray(res["quies"], dtype=np.bool_),
+                             np.asarray(res["rdist"], dtype=np.float32), np.asarray(res["mdiff"], dtype=np.int32),
+                             np.asarray(locs[k].blob), np.asarray(locs[k].offsets)])
+        for j in wjobs:
+            j.result()
     tm.lap("scores, nulls, deltas + write text")
+    tm.note("H2D uploads: %d for %d part(s) x 2 groups" % (getattr(sess, "n_uploads", 0), len(my_parts)))
     d.barrier()
+    got = _gather_parts(d, plans, payloads, 6)
     results = None
     if d.rank == 0:
         results = {}
-        for f in files1:
+        for fi, f in enumerate(files1):
             stem = fileStem(f)
-            _cat_gzip_members(outputDir, "pairwiseDelta_{}_{}.txt.gz".format(fileTag, stem),
-                              ".part_pairwiseDelta_{}_{}_*.gz".format(fileTag, stem))
-            parts = _collect(outputDir, "pair", fileTag, stem, mine)
-            loc = _cat_locations(parts)
+            owners = sorted((lo, hi) for parts in plans for (pf, lo, hi) in parts if pf == fi)
+            _assemble_text(outputDir, "pairwiseDelta", "pairwiseDelta_{}_{}.txt.gz".format(fileTag, stem), fileTag, fi, owners, rows[fi])
+            if not owners:
+                writeScores(np.zeros((0, numStates), dtype=np.float32), outputDir / "pairwiseDelta_{}_{}.txt.gz".format(fileTag, stem),
+                            _io.Locations(np.zeros(0, dtype=np.uint8), np.zeros(1, dtype=np.int64)))
+            parts = [got[(fi, lo)] for lo, _ in owners]
+            loc = _cat_locations([_io.Locations(p[4], p[5]) for p in parts])
             chrName = loc.slice(0, 1).to_object_array()[0, 0] if len(loc) else ""
             res = {"chrName": chrName, "locations": loc,
-                   "nullDistances": _cat([pl["null"] for pl in parts], np.zeros(0, dtype=np.float32)),
-                   "quiescenceArr": _cat([pl["quies"] for pl in parts], np.zeros(0, dtype=bool)).astype(bool),
-                   "distances": _cat([pl["rdist"] for pl in parts], np.zeros(0, dtype=np.float32)).astype(np.float32),
-                   "maxDiff": _cat([pl["mdiff"] for pl in parts], np.zeros(0, dtype=np.int32)).astype(np.int32)}
+                   "nullDistances": _cat([p[0] for p in parts], np.zeros(0, dtype=np.float32)).astype(np.float32),
+                   "quiescenceArr": _cat([p[1] for p in parts], np.zeros(0, dtype=bool)).astype(bool),
+                   "distances": _cat([p[2] for p in parts], np.zeros(0, dtype=np.float32)).astype(np.float32),
+                   "maxDiff": _cat([p[3] for p in parts], np.zeros(0, dtype=np.int32)).astype(np.int32)}
             results[stem] = res
             if keep_temps:
                 np.savez_compressed(outputDir / "temp_nullDistances_{}_{}.npz".format(fileTag, stem), chrName=np.array([chrName]),

@@ -79,6 +79,16 @@ def hist_s2_from_binhist(H, S, counts=None):
     return counts
 
 
+def hist_s2_from_binhist_pair(HA, HB, S, counts=None):
+    """S2 counts of the column concatenation [A|B] from the two groups' histograms (helpers.py:173)."""
+    if HA.shape != HB.shape:
+        raise ValueError("paired histograms must have the same shape")
+    if counts is None:
+        counts = zeros_counts(S * S, device=HA.device)
+    _abi.call("epg_hist_s2_from_binhist_pair", _ptr(HA), _ptr(HB), HA.shape[0], S, _ptr(counts), _stream())
+    return counts
+
+
 def hist_s3(X, N, S, counts=None, use_workspace=True):
     """counts int32 [N*N*S*S] += biosample-pair state co-occurrences.  With a workspace (room for the transposed matrix)
     the matrix-core kernel runs; without one the ABI falls back to the LDS-counter kernel (same integers)."""
@@ -138,6 +148,20 @@ def score_s1_from_binhist(H, N, S, q, want32=True, want64=False, out32=None, out
     _abi.call("epg_score_s1_from_binhist", _ptr(H), R, N, S, _ptr(q), _ptr(o64), _ptr(o32), _ptr(ws), ws.numel(),
               _stream())
     return o32, o64
+
+
+def combine_score_s1(counts, H, N, S, q=None, want32=True, want64=False, out32=None, out64=None, ws=None, rezero=False):
+    """STEP 2 + STEP 3 of an S1 job in one ABI call: q = normalise(counts) (the all-reduced int64[S] vector), then the
+    scores of the cached histograms H.  Returns (q, out32, out64)."""
+    R = H.shape[0]
+    o32, o64 = _outs(R, S, H.device, want32, want64, out32, out64)
+    if q is None:
+        q = torch.empty(S, dtype=torch.float32, device=H.device)
+    if ws is None:
+        ws = _ws(1, 0, N, S, H.device)
+    _abi.call("epg_combine_score_s1", _ptr(counts), 1 if rezero else 0, _ptr(H), R, N, S, _ptr(q), _ptr(o64), _ptr(o32),
+              _ptr(ws), ws.numel(), _stream())
+    return q, o32, o64
 
 
 def score_s2(X, N, S, q, perms=None, want32=True, want64=False):
@@ -204,6 +228,66 @@ def null_hist(XA, NA, XB, NB, S, ga, gb, seed, row0=0):
     _abi.call("epg_null_hist", _ptr(XA), NA, ldxa, _ptr(XB), NB, ldxb, R, S, ga, gb, seed, row0, _ptr(HA), _ptr(HB),
               _stream())
     return HA, HB
+
+
+class PinnedPool:
+    """A few page-locked host staging buffers handed out IN TICKET ORDER (ticket k waits until tickets < k were served
+    and a buffer is free), so that parser threads running ahead of the consumer can neither exhaust the pool nor starve
+    the part the consumer is waiting for.  Buffers grow to the largest request and are reused for the whole run."""
+
+    def __init__(self, n_buffers=3):
+        import threading
+        self.cv = threading.Condition()
+        self.free = [None] * n_buffers          # None = not allocated yet
+        self.next = 0
+        self.aborted = False
+
+    def abort(self):
+        """The consumer gave up (an error): wake every waiting parser thread instead of leaving it blocked."""
+        with self.cv:
+            self.aborted = True
+            self.cv.notify_all()
+
+    def acquire(self, ticket, nbytes):
+        with self.cv:
+            self.cv.wait_for(lambda: self.aborted or (self.next == ticket and len(self.free) > 0))
+            if self.aborted:
+                raise RuntimeError("staging pool aborted")
+            buf = self.free.pop()
+            self.next += 1
+            self.cv.notify_all()
+        if buf is None or buf.numel() < nbytes:
+            buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.int8, pin_memory=True)
+        return buf
+
+    def skip(self, ticket):
+        """A part that failed before asking for its buffer must not block the tickets behind it."""
+        with self.cv:
+            self.cv.wait_for(lambda: self.aborted or self.next >= ticket)
+            if self.next == ticket:
+                self.next += 1
+            self.cv.notify_all()
+
+    def release(self, buf):
+        with self.cv:
+            self.free.append(buf)
+            self.cv.notify_all()
+
+
+def upload_states(pinned, R, ldx, copy_stream, device="cuda"):
+    """Asynchronous H2D copy of a staged [R, ldx] int8 matrix on `copy_stream`.  Returns (X, event): the current stream
+    must wait for the event before reading X; the staging buffer may be reused once the event has completed."""
+    X = torch.empty((R, ldx), dtype=torch.int8, device=device)
+    if R == 0:
+        ev = torch.cuda.Event()
+        ev.record(copy_stream)
+        return X, ev
+    with torch.cuda.stream(copy_stream):
+        X.copy_(pinned[:R * ldx].view(R, ldx), non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(copy_stream)
+    X.record_stream(copy_stream)
+    return X, ev
 
 
 def hist_to_numpy(H):

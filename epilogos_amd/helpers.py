@@ -46,21 +46,23 @@ def _cache_paths(path):
     st = os.stat(path)
     key = hashlib.sha1("{}|{}|{}".format(os.path.abspath(path), st.st_size, st.st_mtime_ns).encode()).hexdigest()[:20]
     base = Path(root) / "{}_{}".format(Path(path).name.split(".")[0], key)
-    return [Path(str(base) + ext) for ext in (".states.npy", ".locblob.npy", ".locoff.npy")]
+    return [Path(str(base) + ext) for ext in (".states.npy", ".locblob.npy", ".locoff.npy", ".range.npy")]
 
 
-def readTable(path, rowsToCalc=None):
+def readTable(path, rowsToCalc=None, alloc=None, with_range=False):
     """Rows [lo, hi) of a matrix file through the native multi-threaded parser: int8 0-based states
     [rows, N] and the rows' first three columns as written (a _io.Locations).  With EPILOGOS_CACHE_DIR set (the command
     line's --cache-dir) the parsed file is kept as an int8 [R, N] .npy plus the coordinate side-car and later runs on the
-    same input memory-map it instead of inflating and parsing ~1.7 KB of text per bin again."""
+    same input memory-map it instead of inflating and parsing ~1.7 KB of text per bin again.
+    alloc(R, N) -> int8 [R, width >= N] supplies the destination (the driver's pinned, row-padded staging; columns >= N
+    are set to -1); with_range also returns the (lowest, highest) state value of the WHOLE file as written (1-based)."""
     cache = _cache_paths(path)
     if cache is None:
-        return _io.read_table(Path(path), rowsToCalc)
+        return _io.read_table(Path(path), rowsToCalc, alloc=alloc, with_range=with_range)
     if not all(c.exists() for c in cache):
-        states, loc = _io.read_table(Path(path), None)
+        states, loc, rng = _io.read_table(Path(path), None, with_range=True)
         cache[0].parent.mkdir(parents=True, exist_ok=True)
-        for c, arr in zip(cache, (states, loc.blob, loc.offsets)):
+        for c, arr in zip(cache, (states, loc.blob, loc.offsets, np.array(rng, dtype=np.int64))):
             tmp = Path(str(c) + ".tmp%d.npy" % os.getpid())              # atomic: ranks may fill the cache concurrently
             np.save(tmp, arr, allow_pickle=False)
             os.replace(tmp, c)
@@ -69,7 +71,17 @@ def readTable(path, rowsToCalc=None):
     lo, hi = (0, states.shape[0]) if rowsToCalc is None else (max(rowsToCalc[0], 0), min(rowsToCalc[1], states.shape[0]))
     hi = max(hi, lo)
     part = loc.slice(lo, hi)
-    return np.ascontiguousarray(states[lo:hi]), _io.Locations(np.ascontiguousarray(part.blob), np.ascontiguousarray(part.offsets))
+    if alloc is None:
+        out = np.ascontiguousarray(states[lo:hi])
+    else:
+        out = alloc(hi - lo, states.shape[1])
+        out[:, :states.shape[1]] = states[lo:hi]
+        out[:, states.shape[1]:] = -1
+    ploc = _io.Locations(np.ascontiguousarray(part.blob), np.ascontiguousarray(part.offsets))
+    if with_range:
+        rng = np.load(cache[3])
+        return out, ploc, (int(rng[0]), int(rng[1]))
+    return out, ploc
 
 
 def _read_int8(path, rowsToCalc):

@@ -74,7 +74,7 @@ def maxMean(chrom, start, end, score, roiWidth, maxRegions):
             hits[a:b] = True
             chosen.append(m)
     chosen = np.array(sorted(chosen), dtype=np.int64)        # back to genomic order, then best first (stable)
-    final = chosen[np.lexsort((-rmax[chosen], -rmean[chosen], -rmax[chosen]))]
+    final = chosen[np.lexsort((-sc[chosen], -rmean[chosen], -rmax[chosen]))]    # helpers.py:272: by max, mean, centre score
     return (np.asarray(chrom)[orig[final]], w_start[final], w_end[final], rmax[final], orig[final])
 
 

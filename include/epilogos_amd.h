@@ -18,8 +18,10 @@
  *     There is no host/CPU implementation behind this ABI: without a HIP device the calls fail with EPG_ERR_HIP.
  *   - X is the state matrix: row-major int8 [R, ldx], one row per genomic bin, one byte per biosample, 0-based
  *     states (file value - 1, helpers.py:154-155); only the first N bytes of a row are read as states
- *     (ldx >= N; the fast path wants X and ldx 16-byte aligned, any ldx >= N is accepted).  A byte outside
- *     [0, S) is not counted in any state (the expected pass detects it: sum(counts) != R*N).
+ *     (ldx >= N; the fast path wants X and ldx 16-byte aligned, any ldx >= N is accepted).  State bytes must be in
+ *     0..31 or 0xFF (-1): a byte in [S, 31] or 0xFF is "not a state" and is counted nowhere (the expected pass detects
+ *     it: sum(counts) != R*N); the S1/S2 kernels decode only the low five bits, so other byte values are outside the
+ *     contract (libepilogos_io's parser stores every file value outside 1..31 as -1).
  *   - `counts` outputs ACCUMULATE (+=) so that per-chromosome calls sum into one vector exactly like
  *     expectedCombination.py:30-35; zero them first.  They are what the single RCCL all-reduce runs on.
  *   - One host thread per device; calls on different devices/streams are independent.
@@ -64,6 +66,11 @@ int epg_hist_s1(const int8_t* X, int64_t R, int32_t N, int64_t ldx, int32_t S, i
 int epg_hist_s2(const int8_t* X, int64_t R, int32_t N, int64_t ldx, int32_t S, int64_t* counts,
                 void* ws, int64_t ws_bytes, void* stream);
 int epg_hist_s2_from_binhist(const uint16_t* H, int64_t R, int32_t S, int64_t* counts, void* stream);
+/* Paired mode: the S2 counts of the column concatenation [A|B] (helpers.py:173 readStates, expBool) from the two
+ * groups' per-bin histograms, h = HA + HB bin by bin -- neither the concatenated matrix nor a summed histogram is
+ * materialised.  (S1 counts of [A|B] are simply epg_bin_hist of A and of B into the same counts.) */
+int epg_hist_s2_from_binhist_pair(const uint16_t* HA, const uint16_t* HB, int64_t R, int32_t S, int64_t* counts,
+                                  void* stream);
 int epg_hist_s3(const int8_t* X, int64_t R, int32_t N, int64_t ldx, int32_t S, int32_t* counts,
                 void* ws, int64_t ws_bytes, void* stream);
 
@@ -86,6 +93,13 @@ int epg_score_s1(const int8_t* X, int64_t R, int32_t N, int64_t ldx, int32_t S, 
 /* Same from cached per-bin histograms; N is the divisor (group width, scores.py:343). */
 int epg_score_s1_from_binhist(const uint16_t* H, int64_t R, int32_t N, int32_t S, const float* q,
                               double* out64, float* out32, void* ws, int64_t ws_bytes, void* stream);
+
+/* STEP 2 + STEP 3 of an S1 job in one call (two launches): q = normalise(counts) as epg_normalise_i64 -- counts is the
+ * global, already all-reduced int64[S] vector -- written to q[S]; then the scores of this shard's cached histograms
+ * as epg_score_s1_from_binhist.  rezero != 0 additionally leaves counts zeroed for the next job's accumulation
+ * (expectedCombination.py:30-42 + scores.py:259-344).  R may be 0 (only q is produced). */
+int epg_combine_score_s1(int64_t* counts, int32_t rezero, const uint16_t* H, int64_t R, int32_t N, int32_t S, float* q,
+                         double* out64, float* out32, void* ws, int64_t ws_bytes, void* stream);
 
 /* S2: p[i,j] = (h_i*h_j - [i==j]*h_i) / perms, score[b, j] = sum_i kl(p[i,j], q[i,j]) in ascending i
  *     -- scores.py:347-452 s2Score/rowObsS2.  perms = N*(N-1) of the ORIGINAL group (scores.py:371,397-398). */

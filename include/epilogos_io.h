@@ -37,7 +37,12 @@ int64_t epgio_count_rows(const char* path);
 epgio_table* epgio_open_table(const char* path, int64_t row_lo, int64_t row_hi, int32_t threads);
 int64_t epgio_table_rows(const epgio_table* t);
 int32_t epgio_table_cols(const epgio_table* t);          /* number of state columns N */
-/* Copy the 0-based int8 states (file value - 1) into out[r * ldx + c]; bytes c >= N of a row are set to -1. */
+/* Smallest and largest state value of the parsed rows AS WRITTEN IN THE FILE (1-based); 0, 0 for an empty table.  The
+ * reference indexes a numStates-long array with value - 1 (expected.py:113) and dies on anything outside 1..numStates;
+ * callers compare this range with their state model. */
+int epgio_table_state_range(const epgio_table* t, int32_t* lo, int32_t* hi);
+/* Copy the 0-based int8 states (file value - 1) into out[r * ldx + c]; bytes c >= N of a row are set to -1.  A value
+ * outside 0..30 (the engine's models have at most 31 states) is stored as -1 = "not a state". */
 int epgio_table_copy_states(const epgio_table* t, int8_t* out, int64_t ldx);
 /* Verbatim text of the first three columns of every row, each terminated by '\n' ("chr\tstart\tend\n"),
  * concatenated; offsets[r]..offsets[r+1] delimit row r (newline included).  Valid until epgio_close_table. */

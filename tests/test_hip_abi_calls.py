@@ -105,3 +105,51 @@ def test_bin_hist_random_geometry(abi, seed):
     h = onp.bin_hist(x, S)
     assert np.array_equal(engine.hist_to_numpy(H).astype(np.int64), h), (R, N, pitch, off)
     assert np.array_equal(counts.cpu().numpy(), h.sum(axis=0))
+
+
+def test_combine_score_s1_and_pair_hist_direct(abi):
+    """epg_combine_score_s1 (STEP 2 + STEP 3 in one call) equals normalise + score_s1_from_binhist bit for bit and can
+    leave the counts zeroed; epg_hist_s2_from_binhist_pair equals the counts of the concatenated matrix."""
+    from epilogos_amd import engine
+    R, NA, NB = 3001, 37, 22
+    xa, xb = synth_states(R, NA, seed=5), synth_states(R, NB, seed=6)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    XA, XB = engine.states_to_device(xa), engine.states_to_device(xb)
+    HA, cA = engine.bin_hist(XA, NA, S)
+    HB, _ = engine.bin_hist(XB, NB, S)
+    # --- combine
+    q_ref = engine.normalise(cA)
+    o32_ref, o64_ref = engine.score_s1_from_binhist(HA, NA, S, q_ref, want32=True, want64=True)
+    counts = cA.clone()
+    q = torch.empty(S, dtype=torch.float32, device="cuda")
+    o32, o64 = torch.empty_like(o32_ref), torch.empty_like(o64_ref)
+    ws = torch.empty(abi.call("epg_ws_bytes", 1, 0, NA, S), dtype=torch.uint8, device="cuda")
+    abi.call("epg_combine_score_s1", _p(counts), 0, _p(HA), R, NA, S, _p(q), _p(o64), _p(o32), _p(ws), ws.numel(), st)
+    assert torch.equal(q, q_ref) and torch.equal(o32, o32_ref) and torch.equal(o64, o64_ref) and torch.equal(counts, cA)
+    assert np.array_equal(q.cpu().numpy(), onp.normalise(onp.expected_s1(xa, S)))
+    np.testing.assert_allclose(o64.cpu().numpy(), onp.score_s1(xa, q.cpu().numpy(), S), rtol=1e-11, atol=0)
+    abi.call("epg_combine_score_s1", _p(counts), 1, _p(HA), R, NA, S, _p(q), None, _p(o32), _p(ws), ws.numel(), st)
+    assert torch.equal(o32, o32_ref) and int(counts.abs().sum()) == 0           # rezero: ready for the next job
+    with pytest.raises(abi.EpilogosHipError) as e:
+        abi.call("epg_combine_score_s1", _p(counts), 0, _p(HA), R, NA, S, _p(q), None, _p(o32), _p(ws), 16, st)
+    assert e.value.code == -4
+    # --- S2 counts of [A|B] from the two groups' histograms
+    c2 = torch.zeros(S * S, dtype=torch.int64, device="cuda")
+    abi.call("epg_hist_s2_from_binhist_pair", _p(HA), _p(HB), R, S, _p(c2), st)
+    assert np.array_equal(c2.cpu().numpy().reshape(S, S), onp.expected_s2(np.concatenate([xa, xb], axis=1), S))
+    with pytest.raises(abi.EpilogosHipError):
+        abi.call("epg_hist_s2_from_binhist_pair", _p(HA), None, R, S, _p(c2), st)
+
+
+def test_combine_score_s1_long_table(abi):
+    """(N + 1) * S beyond the single-block table kernel: the separate kernels run, same results."""
+    from epilogos_amd import engine
+    R, N, S_ = 64, 20000, 15
+    x = synth_states(R, N, S=S_, seed=9)
+    X = engine.states_to_device(x)
+    H, c = engine.bin_hist(X, N, S_)
+    q_ref = engine.normalise(c)
+    o32_ref, _ = engine.score_s1_from_binhist(H, N, S_, q_ref)
+    counts = c.clone()
+    q, o32, _ = engine.combine_score_s1(counts, H, N, S_, rezero=True)
+    assert torch.equal(q, q_ref) and torch.equal(o32, o32_ref) and int(counts.abs().sum()) == 0

@@ -255,7 +255,7 @@ def test_cli_single_mode(tmp_path, golden_real, fake_backend, state_info):
         res = CliRunner().invoke(main, ["-l", "-i", str(ind), "-j", str(state_info), "-o", str(out2), "--cache-dir", str(tmp_path / "cache")])
         assert res.exit_code == 0, res.output
         assert _decompressed(out2 / "scores_in10_s1_matrix_chr1.txt.gz") == g["s1_text"].tobytes()
-    assert len(list((tmp_path / "cache").glob("matrix_chr1_*.npy"))) == 3
+    assert len(list((tmp_path / "cache").glob("matrix_chr1_*.npy"))) == 4       # states, location blob + offsets, state range
     os.environ.pop("EPILOGOS_CACHE_DIR", None)
     # STEP 4 ran: the reference's regions of interest, and its clean-up of exp_freq / temp_scores (quirk Q4)
     from tests.conftest import load_golden
@@ -329,3 +329,68 @@ def test_cli_argument_errors(tmp_path, state_info, fake_backend):
     write_tsv(b / "other.txt", np.zeros((4, 3), dtype=np.int8))
     r = run("-l", "-m", "paired", "-a", str(ind), "-b", str(b), "-o", str(tmp_path / "o2"), "-j", str(state_info))
     assert isinstance(r.exception, FileNotFoundError)                                                   # no same-named file in -b
+
+
+def test_stem_that_prefixes_another_stem(tmp_path, golden_real, fake_backend):
+    """hg19 has chr1 next to chr1_gl000191_random: a file's parts are named from the partition plan (file index + first
+    row), never rediscovered by a prefix glob; part files left by a crashed run with the same tag are removed."""
+    x = golden_real["x"]
+    ind, out = tmp_path / "in", tmp_path / "out"
+    ind.mkdir(); out.mkdir()
+    write_tsv(ind / "m_chr1.txt.gz", x[:30], chrom="chr1")
+    write_tsv(ind / "m_chr1_gl000191_random.txt.gz", x[30:50], chrom="chr1_gl000191_random")
+    (out / ".part_scores_t_s1_f0000_000000000007.gz").write_bytes(b"stale")        # leftover of an earlier crash
+    files = sorted(ind.glob("*"))
+    _, results = driver.run_single_group(files, S, 1, out, "t_s1")
+    a = _decompressed(out / "scores_t_s1_m_chr1.txt.gz").splitlines()
+    b = _decompressed(out / "scores_t_s1_m_chr1_gl000191_random.txt.gz").splitlines()
+    assert len(a) == 30 and len(b) == 20
+    assert all(l.startswith(b"chr1\t") for l in a) and all(l.startswith(b"chr1_gl000191_random\t") for l in b)
+    assert results["m_chr1"][1].shape == (30, S) and results["m_chr1_gl000191_random"][1].shape == (20, S)
+    assert not list(out.glob(".part_*"))
+
+
+def test_two_rank_gloo_prefix_stems(tmp_path, golden_real):
+    """The same layout over two ranks: the range border cuts the first file, its gzip members are concatenated by exact
+    name, and the arrays for STEP 4 reach rank 0 through send/recv."""
+    x = golden_real["x"]
+    ind = tmp_path / "in"
+    ind.mkdir()
+    write_tsv(ind / "m_chr1.txt", x[:700], chrom="chr1")
+    write_tsv(ind / "m_chr1_gl000191_random.txt", x[700:1000], chrom="chr1_gl000191_random")
+    outs = {}
+    for world in (1, 2):
+        out = tmp_path / ("out%d" % world)
+        out.mkdir()
+        port = str(free_port())
+        env = dict(os.environ, PYTHONPATH=str(ROOT), MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+               "--master-addr", "127.0.0.1", "--master-port", port, str(ROOT / "tests" / "gloo_worker.py"), str(ind), str(out)]
+        res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+        assert res.returncode == 0, res.stdout + res.stderr
+        outs[world] = out
+    for stem, n in (("m_chr1", 700), ("m_chr1_gl000191_random", 300)):
+        one, two = _decompressed(outs[1] / ("scores_t_s1_%s.txt.gz" % stem)), _decompressed(outs[2] / ("scores_t_s1_%s.txt.gz" % stem))
+        assert one == two and len(one.splitlines()) == n
+        z1 = np.load(outs[1] / ("temp_scores_t_s1_%s.npz" % stem), allow_pickle=True)
+        z2 = np.load(outs[2] / ("temp_scores_t_s1_%s.npz" % stem), allow_pickle=True)
+        assert np.array_equal(z1["scoreArr"], z2["scoreArr"]) and np.array_equal(z1["locationArr"], z2["locationArr"])
+    assert not list(outs[2].glob(".part_*"))
+
+
+def test_cli_rejects_states_outside_the_model(tmp_path, golden_real, fake_backend, state_info):
+    """The reference dies with an IndexError when the data holds a state the -j model does not have (expected.py:113); the
+    command line here must not run to completion either -- neither for a value just above the model nor for one that would
+    alias a valid state in the kernels' five-bit decode (18 + 32)."""
+    from click.testing import CliRunner
+    from epilogos_amd.run import main
+    for bad in (S, S + 32, -1):                       # 0-based: file values 19, 51, 0
+        ind, out = tmp_path / ("in%d" % bad), tmp_path / ("out%d" % bad)
+        ind.mkdir()
+        x = golden_real["x"][:40].astype(np.int64).copy()
+        x[17, 3] = bad
+        write_tsv(ind / "matrix_chr1.txt", x)
+        res = CliRunner().invoke(main, ["-l", "-i", str(ind), "-j", str(state_info), "-o", str(out)])
+        assert res.exit_code != 0
+        assert isinstance(res.exception, ValueError) and "outside the 18-state model" in str(res.exception)
+        assert not list(out.glob("scores_*"))
