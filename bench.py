@@ -6,13 +6,16 @@ bench.py -- S1 scoring throughput of the MI355X engine on the BASELINE.json work
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-One "step" = one whole S1 job over this rank's shard of bins, inputs resident in HBM:
+One "step" = one whole S1 job over this rank's shard of bins, inputs resident in HBM (three launches + the collective):
     K1 per-bin histogram + state counts  ->  (N > 1: one RCCL all-reduce of the int64[18] count vector)
-    -> normalise to exp_freq (float32)   ->  S1 score table + score pass -> float32 [bins, 18] scores.
-Workload at every N: `--bins` (15,000,000 = whole-genome scale) synthetic bins x 833 biosamples x 18 states PER GPU
-(weak scaling: a GPU always holds a genome-sized contiguous bin range; the global matrix is N of them, partitioned
-by the reference's splitRows rule, helpers.py:116-118).  Synthetic states are i.i.d. with the empirical chr1 state
-frequencies, generated on device per fixed global chunk seed.
+    -> [normalise to exp_freq (float32) + S1 score table] in one single-block kernel -> score pass -> float32 [bins, 18].
+Workload: `--bins` (15,000,000 = whole-genome scale) synthetic bins x 833 biosamples x 18 states.
+  --scaling strong (default; what BASELINE.json's north_star quotes): the `--bins` matrix is ONE genome,
+      split over the ranks by the reference's splitRows rule (helpers.py:116-118): rank g holds bins
+      [g*R//G, (g+1)*R//G); value = R * steps / max-over-ranks time.
+  --scaling weak: every rank holds `--bins` bins (a genome-sized shard per GPU), the global matrix is G of them.
+Synthetic states are i.i.d. with the empirical chr1 state frequencies, generated on device per fixed
+global chunk seed, so the matrix does not depend on the GPU count.
 
 Prints ONE JSON line on rank 0 (contract in the task statement), with `roofline` for the dominant kernel
 (k_bin_hist, HBM-bound, 833 algorithmic bytes per bin) and `cpu_baseline` (the per-bin numpy loop of
@@ -37,23 +40,55 @@ SUB_BINS = 1 << 17
 HBM_PEAK_GBPS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
-def cpu_baseline(n_biosamples, n_states, target_seconds=12.0):
-    """Per-bin numpy loop (the reference's `-l` S1 loop shape) on all host cores, bounded sample.  Runs BEFORE the
-    process touches the GPU (it forks workers)."""
+def host_cores():
+    """(cores this process may use, how that was determined): the scheduler affinity capped by the cgroup CPU quota
+    (the GPU boxes expose 256 hardware threads to a container that may run 16 of them at a time)."""
+    aff = len(os.sched_getaffinity(0))
+    quota = None
+    try:
+        q, per = Path("/sys/fs/cgroup/cpu.max").read_text().split()[:2]
+        if q != "max":
+            quota = max(1, int(float(q) / float(per)))
+    except Exception:
+        pass
+    if quota is not None and quota < aff:
+        return quota, "cgroup cpu.max quota %d of %d schedulable hardware threads" % (quota, aff)
+    return aff, "%d schedulable hardware threads (no smaller cgroup quota)" % aff
+
+
+def cpu_baseline(n_biosamples, n_states, target_seconds=10.0):
+    """Per-bin numpy loop (the reference's `-l` S1 loop shape) on the host: first ONE worker (the per-core rate the
+    calibration in DESIGN.md / BASELINE.md quotes), then as many forked workers as the process may actually run at once.
+    Bounded samples, before the process touches the GPU (it forks)."""
     from oracle import rowloop_baseline as rb
     from oracle import oracle_np as onp
-    cores = len(os.sched_getaffinity(0))
+    cores, how = host_cores()
     rng = np.random.default_rng(1234)
     p = FREQS[:n_states] / FREQS[:n_states].sum()
-    sample = max(cores * 1000, 100_000)                      # distinct bins held in RAM (int8), >= 1000 per worker
+    sample = max(cores * 2000, 50_000)                       # distinct bins held in RAM (int8), >= 2000 per worker
     x = rng.choice(n_states, size=(sample, n_biosamples), p=p).astype(np.int8)
     q = onp.normalise(onp.expected_s1(x[:2000], n_states))
+    bps1, secs1, _, bins1 = rb.timed_pool_run(x, q, n_states, 1, seconds=min(4.0, target_seconds))
     bps, secs, cores, bins = rb.timed_pool_run(x, q, n_states, cores, seconds=target_seconds)
     return {"value": round(bps / 1e6, 6), "unit": "Mbins/s", "cores": cores, "kind": "port",
-            "sample": "%d bin-scorings in %.1f s wall over %d distinct synthetic bins x %d biosamples (same state "
-                      "frequencies as the GPU workload): per-bin numpy loop of oracle/rowloop_baseline.py (np.unique + "
-                      "numpy.ma p*log2(p/q), the reference's -l S1 loop shape, scores.py:309-344,539-550) on %d forked "
-                      "workers" % (bins, secs, sample, n_biosamples, cores)}
+            "one_worker_bins_per_s": round(bps1, 1), "per_core_bins_per_s": round(bps / cores, 1),
+            "parallel_efficiency": round(bps / (cores * bps1), 3),
+            "sample": "%d bin-scorings in %.1f s wall (plus %d in %.1f s on one worker) over %d distinct synthetic bins x %d "
+                      "biosamples (same state frequencies as the GPU workload): per-bin numpy loop of oracle/rowloop_baseline.py "
+                      "(np.unique + numpy.ma p*log2(p/q), the reference's -l S1 loop shape, scores.py:309-344,539-550) on %d "
+                      "forked workers = %s" % (bins, secs, bins1, secs1, sample, n_biosamples, cores, how)}
+
+
+def k1_source_sha():
+    """Hash of the sources k_bin_hist is built from: profiles/hbm_traffic.json records the hash its PMC numbers were
+    taken with, and a number measured on other kernel code is not reported."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in ("epg_count.h", "epg_common.h"):
+        h.update((ROOT / "epilogos_amd" / "csrc" / name).read_bytes())
+    src = (ROOT / "epilogos_amd" / "csrc" / "epg_s1.hip").read_text()
+    h.update(src[:src.index("// Any S <= 127")].encode())    # store_staged + k_bin_hist
+    return h.hexdigest()[:16]
 
 
 def generate_shard(torch, X, n_biosamples, n_states, bin0, dist="chr1"):
@@ -101,7 +136,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--bins", type=int, default=15_000_000, help="bins per GPU")
+    ap.add_argument("--bins", type=int, default=15_000_000, help="bins of the genome (strong) / per GPU (weak)")
+    ap.add_argument("--scaling", choices=["strong", "weak"], default=None,
+                    help="default strong: ONE --bins genome split over the GPUs")
     ap.add_argument("--biosamples", type=int, default=833)
     ap.add_argument("--states", type=int, default=18)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -118,7 +155,15 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
         raise SystemExit("WORLD_SIZE=%d does not match --gpus %d" % (world, args.gpus))
-    N, S, R = args.biosamples, args.states, args.bins
+    scaling = args.scaling or "strong"              # one GPU: the two coincide
+    N, S = args.biosamples, args.states
+    if scaling == "strong":                  # the reference's splitRows rule on ONE genome (helpers.py:116-118)
+        bin0, bin1 = rank * args.bins // world, (rank + 1) * args.bins // world
+        R_global = args.bins
+    else:
+        bin0, bin1 = rank * args.bins, (rank + 1) * args.bins
+        R_global = args.bins * world
+    R = bin1 - bin0
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -148,27 +193,29 @@ def main():
         X = flat[:R * N].view(R, N)
     else:
         X = engine.alloc_states(R, N, device=dev)
-    generate_shard(torch, X, N, S, rank * R, dist=args.dist)
+    generate_shard(torch, X, N, S, bin0, dist=args.dist)
     H = torch.empty((R, S), dtype=torch.int16, device=dev)
     counts = torch.zeros(S, dtype=torch.int64, device=dev)
     q = torch.empty(S, dtype=torch.float32, device=dev)
     out32 = torch.empty((R, S), dtype=torch.float32, device=dev)
-    ws_norm = torch.empty(256, dtype=torch.uint8, device=dev)
     ws_s1 = engine.workspace(1, 0, N, S, device=dev)
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
           for _ in range(args.steps)]
 
-    def step(k=None):
-        counts.zero_()
+    last_counts = torch.zeros(S, dtype=torch.int64, device=dev)
+
+    def step(k=None, keep=False):
         if k is not None:
             ev[k][0].record()
-        engine.bin_hist(X, N, S, counts=counts, H=H)                       # STEP 1: expected pass
+        engine.bin_hist(X, N, S, counts=counts, H=H)                       # STEP 1: expected pass (counts start zeroed)
         if k is not None:
             ev[k][1].record()
         if world > 1:
             dist.all_reduce(counts, op=dist.ReduceOp.SUM)                  # the single collective (144 bytes)
-        engine.normalise(counts, q=q, ws=ws_norm)                          # STEP 2: combination
-        engine.score_s1_from_binhist(H, N, S, q, out32=out32, ws=ws_s1)    # STEP 3: score pass
+        if keep:
+            last_counts.copy_(counts)                                      # outside the timed steps: for the sanity check
+        # STEP 2 + STEP 3: normalise + table in one single-block kernel (it leaves counts zeroed for the next job), score pass
+        engine.combine_score_s1(counts, H, N, S, q=q, out32=out32, ws=ws_s1, rezero=True)
         if k is not None:
             ev[k][2].record()
 
@@ -178,6 +225,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    step(keep=True)                                                        # untimed: sanity of one whole job
     for _ in range(args.warmup):
         step()
     fence()
@@ -188,8 +236,9 @@ def main():
     dt = time.perf_counter() - t0
 
     # sanity of the last step (cheap, outside the timed region): every state byte counted, scores finite
-    total = int(counts.sum().item())
-    assert total == world * R * N, "state counts %d != bins*biosamples %d" % (total, world * R * N)
+    total = int(last_counts.sum().item())
+    assert total == R_global * N, "state counts %d != bins*biosamples %d" % (total, R_global * N)
+    assert int(counts.abs().sum().item()) == 0                             # every job left the accumulator zeroed
     assert bool(torch.isfinite(out32[:: max(R // 4096, 1)]).all())
 
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -203,29 +252,38 @@ def main():
 
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
-        value = world * R * args.steps / dt / 1e6
+        value = R_global * args.steps / dt / 1e6
         achieved = R * N / (hist_ms * 1e-3) / 1e9
-        traffic = None
+        # HBM bytes per launch from the PMC passes of tools/profile_bench.sh (rocprofv3 cannot run inside this process):
+        # reported only when they were taken on this very kernel source and this shape
+        traffic, traffic_note = None, "no PMC record for this shape"
         tfile = ROOT / "profiles" / "hbm_traffic.json"
         if tfile.exists():
             try:
-                traffic = json.loads(tfile.read_text()).get("k_bin_hist_bytes_per_launch_%d_%d" % (R, N))
-            except Exception:
-                traffic = None
+                rec = json.loads(tfile.read_text())
+                if rec.get("k1_source_sha") != k1_source_sha():
+                    traffic_note = "PMC record is for other kernel source (%s), not reported" % rec.get("k1_source_sha")
+                else:
+                    traffic = rec.get("k_bin_hist_bytes_per_launch_%d_%d" % (R, N))
+                    traffic_note = rec.get("source") if traffic is not None else traffic_note
+            except Exception as e:
+                traffic_note = "unreadable PMC record: %r" % (e,)
         line = {
             "metric": "Mbins scored/sec (S1, 18-state, 833 biosamples)",
             "value": round(value, 3), "unit": "Mbins/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "S1 saliency, whole-genome scale: %d bins x %d biosamples x %d states per GPU, "
-                                   "expected pass + count all-reduce + normalise + score pass per step" % (R, N, S),
-                       "bins_per_gpu": R, "biosamples": N, "states": S, "saliency": 1, "state_distribution": args.dist,
+            "config": {"workload": "S1 saliency, whole-genome scale: %d bins x %d biosamples x %d states %s, "
+                                   "expected pass + count all-reduce + normalise + score pass per step"
+                                   % (args.bins, N, S, "split over the GPUs (splitRows)" if scaling == "strong" else "per GPU"),
+                       "bins_total": R_global, "bins_per_gpu": R, "biosamples": N, "states": S, "saliency": 1,
+                       "state_distribution": args.dist,
                        "row_pitch_bytes": int(X.stride(0)),
                        "partition": "contiguous bin ranges per GPU (helpers.splitRows rule), one RCCL all-reduce of int64[%d]" % S},
             "roofline": {"bound": "hbm", "kernel": "k_bin_hist", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": traffic_note,
                          "algorithmic_bytes_per_bin": N, "avg_launch_ms": round(hist_ms, 4)},
-            "kernels_ms": {"k_bin_hist": round(hist_ms, 4), "allreduce+normalise+table+score_from_hist": round(rest_ms, 4)},
+            "kernels_ms": {"k_bin_hist": round(hist_ms, 4), "allreduce+combine(normalise,table)+score_from_hist": round(rest_ms, 4)},
             "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)

@@ -50,6 +50,19 @@ __device__ __forceinline__ u32 quad_sum(u32 v) {
     return v;
 }
 
+// Store `nbytes` (a multiple of 2) staged in the wave's LDS buffer to `dst` (16-byte aligned): whole 16-byte chunks
+// with dwordx4 stores -- consecutive lanes, consecutive chunks, so every store instruction covers whole 128-byte
+// lines -- then a dword tail and, for an odd number of uint16 (odd S, odd number of rows), the last two bytes.
+__device__ __forceinline__ void store_staged(const char* lds, char* dst, int nbytes, int lane) {
+    const int nchunks = nbytes >> 4;
+    for (int c = lane; c < nchunks; c += 64)
+        *reinterpret_cast<uint4*>(dst + 16 * c) = *reinterpret_cast<const uint4*>(lds + 16 * c);
+    const int tail0 = nchunks << 4;
+    for (int o = tail0 + 4 * lane; o + 4 <= nbytes; o += 256)
+        *reinterpret_cast<u32*>(dst + o) = *reinterpret_cast<const u32*>(lds + o);
+    if ((nbytes & 2) && lane == 0) *reinterpret_cast<u16*>(dst + nbytes - 2) = *reinterpret_cast<const u16*>(lds + nbytes - 2);
+}
+
 // kl(p, q) = p * log2(p / q) with the reference's masked-zero semantics (scores.py:550):
 // 0 where q == 0, 0 where p/q <= 0.
 __device__ __forceinline__ double kl_term(double p, double q) {

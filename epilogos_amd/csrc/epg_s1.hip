@@ -8,19 +8,6 @@ namespace epg {
 // K1: X[R, ldx] int8 -> H[R, S] uint16 (+ counts[S] += column sums).  HBM-bound: N bytes read, 2*S written per bin.
 // Restates np.unique(row, return_counts=True) of scores.py:341/444 and expected.py:111-113,152.
 // ---------------------------------------------------------------------------------------------------------------
-// Store `nbytes` (a multiple of 2) staged in the wave's LDS buffer to `dst` (16-byte aligned): whole 16-byte chunks
-// with dwordx4 stores -- consecutive lanes, consecutive chunks, so every store instruction covers whole 128-byte
-// lines -- then a dword tail and, for an odd number of uint16 (odd S, odd number of rows), the last two bytes.
-__device__ __forceinline__ void store_staged(const char* lds, char* dst, int nbytes, int lane) {
-    const int nchunks = nbytes >> 4;
-    for (int c = lane; c < nchunks; c += 64)
-        *reinterpret_cast<uint4*>(dst + 16 * c) = *reinterpret_cast<const uint4*>(lds + 16 * c);
-    const int tail0 = nchunks << 4;
-    for (int o = tail0 + 4 * lane; o + 4 <= nbytes; o += 256)
-        *reinterpret_cast<u32*>(dst + o) = *reinterpret_cast<const u32*>(lds + o);
-    if ((nbytes & 2) && lane == 0) *reinterpret_cast<u16*>(dst + nbytes - 2) = *reinterpret_cast<const u16*>(lds + nbytes - 2);
-}
-
 // SC = number of states the counting core decodes (a template parameter: its loops live in registers); Sout <= SC = the
 // state model's size = columns of H.  A model between two instantiations runs on the next larger one and only its own
 // columns are stored (an occurrence of a state >= Sout is "not a state", like in the reference's inputs it cannot occur).

@@ -1,6 +1,8 @@
 // S2 path (state-pair saliency) from cached per-bin histograms, plus the paired-mode extras.  gfx950 only.
 #include "epg_common.h"
 
+#include <stdlib.h>
+
 namespace epg {
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -148,7 +150,9 @@ __global__ void k_s2_tables(const float* __restrict__ q, int S, long perms, int 
     if (t <= maxc) LH[t] = t > 0 ? log2((double)t) : 0.0;
     if (t < S * S) {
         const double qd = (double)q[t];
-        LPQ[t] = qd == 0.0 ? LPQ_MASKED : log2((double)perms * qd);
+        const double v = qd == 0.0 ? LPQ_MASKED : log2((double)perms * qd);
+        LPQ[t] = v;
+        LPQ[S * S + 1 + (t % S) * S + t / S] = v;   // LPQT[j][i] = LPQ[i][j]: a column of LPQ as 8*S contiguous bytes
     }
     if (t == 0) {                                   // LPQ[S*S] = number of masked (q == 0) entries: selects the score kernel
         int nz = 0;
@@ -284,6 +288,100 @@ __global__ __launch_bounds__(256) void k_score_s2_fast(const u16* __restrict__ H
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// S2 score, one LANE per bin (no q == 0; S = 15 / 18 / 25).  With p = num / P and log2(p/q) = log2(num) - LPQ[i,j]
+// (LPQ = log2(P q)), num = h_i h_j (i != j) or h_j (h_j - 1) (i == j), the sum over i collapses to
+//     score[j] = h_j / P * ( A - G_j + LPQ[j,j] + LH[h_j] (n - h_j - 1) + (h_j - 1) LH[h_j - 1] )
+//     A = sum_i h_i LH[h_i],  n = sum_i h_i,  G_j = sum_i h_i LPQ[i,j]
+// (h_i = 0 and h_j = 0 give exact zeros like the reference's masked terms).  Everything that depends on (i, j) is the
+// S x S matrix-vector product G = h . LPQ.  LPQ does not depend on the bin, so with a lane per bin its entries are
+// WAVE-UNIFORM: they are read with scalar loads (column j of LPQ = 8*S contiguous bytes of the transposed copy) and enter
+// v_fma_f64 as SGPR operands -- one float64 FMA per (i, j) and nothing else in the inner loop: no LDS broadcast, no idle
+// lanes (the (bin, j)-per-lane kernel above runs 54 of 64 lanes and spends three float64 operations plus one LDS read per
+// term: 1.40 ms for 15 M bins at S = 18).  A lane reads its bin's 2*S bytes of H directly (the wave's rows are one
+// contiguous span) one iteration ahead, gathers LH[h_i] from the log table in LDS, and stages its S outputs in LDS so
+// that the wave writes whole lines.  Float64 throughout; differs from the reference's i-ascending sum by ~1e-13 relative.
+// ---------------------------------------------------------------------------------------------------------------
+template <int S>
+__device__ __forceinline__ void load_hrow(const u16* __restrict__ H, long row, long R, u32 (&w)[(S + 1) / 2]) {
+    constexpr int ND = (S + 1) / 2;
+    if (row >= R) {
+#pragma unroll
+        for (int m = 0; m < ND; ++m) w[m] = 0;
+        return;
+    }
+    const char* p = reinterpret_cast<const char*>(H + row * S);          // 2*S bytes, 2-byte aligned (4 for even S)
+    if constexpr ((S & 1) == 0) {
+#pragma unroll
+        for (int m = 0; m < ND; ++m) __builtin_memcpy(&w[m], p + 4 * m, 4);
+    } else {
+#pragma unroll
+        for (int m = 0; m < ND - 1; ++m) __builtin_memcpy(&w[m], p + 4 * m, 4);
+        w[ND - 1] = *reinterpret_cast<const u16*>(p + 4 * (ND - 1));       // the last state stands alone: never read past the row
+    }
+}
+
+template <int S, typename OT, bool LDS_LH>
+__global__ __launch_bounds__(256) void k_score_s2_bin(const u16* __restrict__ H, long R, double inv_perms, int maxc,
+                                                       const double* __restrict__ gLH, const double* __restrict__ gLPQ,
+                                                       OT* __restrict__ out) {
+    if (gLPQ[S * S] != 0.0) return;                  // some q == 0: the general kernel runs instead
+    constexpr int ND = (S + 1) / 2;
+    constexpr int ROWB = S * (int)sizeof(OT);
+    __shared__ __attribute__((aligned(16))) char s_stage[4][64 * ROWB];
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double* s_LH = reinterpret_cast<double*>(smem);
+    if (LDS_LH) {
+        for (int e = threadIdx.x; e <= maxc; e += 256) s_LH[e] = gLH[e];
+        __syncthreads();
+    }
+    const double* LH = LDS_LH ? s_LH : gLH;
+    const double* __restrict__ LPQT = gLPQ + S * S + 1;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long ntiles = (R + 63) >> 6;
+    const long stride = (long)gridDim.x * 4;
+    long tile = (long)blockIdx.x * 4 + wave;
+    u32 wnext[ND];
+    load_hrow<S>(H, tile * 64 + lane, tile < ntiles ? R : 0, wnext);
+    for (; tile < ntiles; tile += stride) {
+        u32 w[ND];
+#pragma unroll
+        for (int m = 0; m < ND; ++m) w[m] = wnext[m];
+        load_hrow<S>(H, (tile + stride) * 64 + lane, tile + stride < ntiles ? R : 0, wnext);   // travels while this tile is scored
+        double hd[S], lh[S];
+        double A = 0.0, n = 0.0;
+#pragma unroll
+        for (int i = 0; i < S; ++i) {
+            u32 h = (i & 1) ? w[i >> 1] >> 16 : w[i >> 1] & 0xffffu;
+            h = h > (u32)maxc ? (u32)maxc : h;       // cannot happen for consistent inputs; keeps the gather in bounds
+            hd[i] = (double)h;
+            lh[i] = LH[h];
+            A = fma(hd[i], lh[i], A);
+            n += hd[i];
+        }
+        OT* srow = reinterpret_cast<OT*>(&s_stage[wave][lane * ROWB]);
+        // LPQ is re-read through the scalar cache for every tile: as a loop invariant its 2*S*S dwords would be hoisted,
+        // would not fit the 102 SGPRs and would be spilled to VGPR lanes (618 v_readlane per tile in the first build)
+        const double* lpq = LPQT;
+        asm volatile("" : "+s"(lpq));
+#pragma unroll
+        for (int j = 0; j < S; ++j) {
+            double G = 0.0;
+#pragma unroll
+            for (int i = 0; i < S; ++i) G = fma(hd[i], lpq[j * S + i], G);        // scalar operand: LPQ is wave-uniform
+            const u32 hj = (j & 1) ? w[j >> 1] >> 16 : w[j >> 1] & 0xffffu;
+            const double lhm1 = LH[hj ? (hj > (u32)maxc ? (u32)maxc : hj) - 1 : 0];
+            const double br = ((A - G) + lpq[j * S + j]) + fma(lh[j], n - hd[j] - 1.0, (hd[j] - 1.0) * lhm1);
+            srow[j] = (OT)(hj ? hd[j] * inv_perms * br : 0.0);
+        }
+        __builtin_amdgcn_wave_barrier();
+        const long row0 = tile * 64;
+        const int rows = (int)(R - row0 < 64 ? R - row0 : 64);
+        store_staged(s_stage[wave], reinterpret_cast<char*>(out) + row0 * ROWB, rows * ROWB, lane);
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // paired extras
 // ---------------------------------------------------------------------------------------------------------------
 // delta = a - b; dist[b] = sum_s delta^2 * sign(sum_s delta) in float32, with numpy's pairwise_sum order for a
@@ -410,7 +508,7 @@ int hist_s2_from_binhist_impl(const uint16_t* H, const uint16_t* H2, int64_t R, 
     return EPG_OK;
 }
 
-int64_t s2_table_bytes(int maxc, int S) { return align_up((int64_t)(maxc + 1) * 8, 256) + align_up((int64_t)(S * S + 1) * 8, 256); }
+int64_t s2_table_bytes(int maxc, int S) { return align_up((int64_t)(maxc + 1) * 8, 256) + align_up((int64_t)(2 * S * S + 1) * 8, 256); }
 
 int score_s2_from_hist_impl(const uint16_t* H, int64_t R, int32_t N, int32_t S, int64_t perms, const float* q,
                             double* out64, float* out32, void* ws, int64_t ws_bytes, hipStream_t st) {
@@ -436,8 +534,21 @@ int score_s2_from_hist_impl(const uint16_t* H, int64_t R, int32_t N, int32_t S, 
     EPG_LAUNCH_CHECK("k_score_s2_from_hist");
     const bool lds_lh = N < 4096;
     const size_t lh_bytes = lds_lh ? (size_t)(N + 1) * 8 : 0;
+    // EPG_S2_SCORE=pair selects the older (bin, j)-per-lane kernel for A/B measurements; default: one lane per bin
+    static const bool use_pair = [] { const char* e = getenv("EPG_S2_SCORE"); return e && e[0] == 'p'; }();
+    const long ntiles = (R + 63) / 64;
+    long bblocks = (ntiles + 3) / 4;
+    if (bblocks > num_cus() * 4L) bblocks = num_cus() * 4L;
 #define EPG_S2_FAST(SV)                                                                                                         \
-    if (S == SV && lds_lh) {                                                                                                    \
+    if (S == SV && !use_pair) {                                                                                                 \
+        if (lds_lh) {                                                                                                           \
+            if (out32) hipLaunchKernelGGL((k_score_s2_bin<SV, float, true>), dim3((int)bblocks), dim3(256), lh_bytes, st, H, (long)R, inv, N, LH, LPQ, out32);   \
+            if (out64) hipLaunchKernelGGL((k_score_s2_bin<SV, double, true>), dim3((int)bblocks), dim3(256), lh_bytes, st, H, (long)R, inv, N, LH, LPQ, out64);  \
+        } else {                                                                                                                \
+            if (out32) hipLaunchKernelGGL((k_score_s2_bin<SV, float, false>), dim3((int)bblocks), dim3(256), 0, st, H, (long)R, inv, N, LH, LPQ, out32);   \
+            if (out64) hipLaunchKernelGGL((k_score_s2_bin<SV, double, false>), dim3((int)bblocks), dim3(256), 0, st, H, (long)R, inv, N, LH, LPQ, out64);  \
+        }                                                                                                                       \
+    } else if (S == SV && lds_lh) {                                                                                             \
         if (out32) hipLaunchKernelGGL((k_score_s2_fast<SV, float, true>), dim3((int)blocks), dim3(256), lh_bytes, st, H, (long)R, inv, N, LH, LPQ, out32);   \
         if (out64) hipLaunchKernelGGL((k_score_s2_fast<SV, double, true>), dim3((int)blocks), dim3(256), lh_bytes, st, H, (long)R, inv, N, LH, LPQ, out64);  \
     } else if (S == SV) {                                                                                                       \

@@ -199,3 +199,31 @@ def test_driver_uploads_each_part_once_and_rejects_bad_states(tmp_path, golden_r
     sess.add_part(np.ascontiguousarray(xb), xb.shape[1], 0)
     with pytest.raises(ValueError):
         sess.finish(100, xb.shape[1])
+
+
+def test_bench_strong_scaling_two_ranks_on_one_gpu(tmp_path):
+    """bench.py's multi-rank mode (gloo transport, both ranks on cuda:0): the default is the STRONG split north_star quotes --
+    ONE `--bins` genome cut by the splitRows rule -- value counts the genome once, the all-reduced counts cover every bin
+    (bench.py asserts sum == bins * biosamples), and --scaling weak holds `--bins` per rank."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parents[1]
+    lines = {}
+    for mode in ("strong", "weak"):
+        port = str(free_port())
+        env = dict(os.environ, PYTHONPATH=str(root), MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", port, str(root / "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--bins", "300001",
+               "--backend", "gloo", "--no-cpu-baseline"] + ([] if mode == "strong" else ["--scaling", "weak"])
+        res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=str(root))
+        assert res.returncode == 0, res.stdout + res.stderr
+        lines[mode] = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][-1])
+    s, w = lines["strong"], lines["weak"]
+    assert s["scaling"] == "strong" and s["n_gpus"] == 2 and s["config"]["bins_total"] == 300001 and s["config"]["bins_per_gpu"] == 150000
+    assert w["scaling"] == "weak" and w["config"]["bins_total"] == 600002 and w["config"]["bins_per_gpu"] == 300001
+    for l in (s, w):
+        assert abs(l["value"] - l["config"]["bins_total"] / l["ms_per_step"] / 1e3) < 1e-2 * l["value"]
+        assert l["roofline"]["bound"] == "hbm" and l["unit"] == "Mbins/s"

@@ -71,6 +71,11 @@ if bench and traffic:
         total = t.get("FETCH_SIZE", 0) + t.get("WRITE_SIZE", 0)
         tfile = dst / "hbm_traffic.json"
         d = json.loads(tfile.read_text()) if tfile.exists() else {}
+        sys.path.insert(0, str(root))
+        import bench as _bench
+        if d.get("k1_source_sha") != _bench.k1_source_sha():      # numbers of other kernel code do not carry over
+            d = {}
+        d["k1_source_sha"] = _bench.k1_source_sha()
         d["k_bin_hist_bytes_per_launch_%d_%d" % (R, N)] = total
         d["source"] = "profiles/%s_summary.md: FETCH_SIZE*1024*2 (gfx950 wide-read correction, MI355X_MICROARCH.md HBM section) + WRITE_SIZE*1024, separate --pmc passes" % label
         tfile.write_text(json.dumps(d, indent=1) + "\n")
