@@ -41,6 +41,8 @@ def load():
     lib.epgio_close_table.argtypes = [p]
     lib.epgio_write_scores.restype = C.c_int
     lib.epgio_write_scores.argtypes = [C.c_char_p, p, p, p, i64, i32, i32, i32]
+    lib.epgio_write_states.restype = C.c_int
+    lib.epgio_write_states.argtypes = [C.c_char_p, C.c_char_p, i64, i64, p, i64, i32, i64, i32, i32]
     lib.epgio_write_metrics.restype = C.c_int
     lib.epgio_write_metrics.argtypes = [C.c_char_p, p, p, p, p, p, p, p, p, p, p, p, i64, i32, i32]
     lib.epgio_format_f5.restype = i64
@@ -145,6 +147,19 @@ def write_scores(path, locations, scores, threads=0, gzip_level=6):
     blob = np.ascontiguousarray(locations.blob)
     off = np.ascontiguousarray(locations.offsets, dtype=np.int64)
     rc = load().epgio_write_scores(str(path).encode(), blob.ctypes.data, off.ctypes.data, scores.ctypes.data, R, S,
+                                   threads, gzip_level)
+    if rc != 0:
+        raise EpilogosIOError(_err())
+
+
+def write_states(path, chrom, states, start0=0, step=200, n_cols=None, threads=0, gzip_level=1):
+    """Write an int8 [R, width] matrix of 0-based states in the reference's input format (1-based text, .gz by name)."""
+    states = np.asarray(states)
+    if states.dtype != np.int8 or states.ndim != 2 or (states.shape[0] and states.strides != (states.shape[1], 1)):
+        raise ValueError("states must be a C-contiguous int8 [R, width] array")
+    R, ldx = states.shape
+    N = ldx if n_cols is None else n_cols
+    rc = load().epgio_write_states(str(path).encode(), str(chrom).encode(), start0, step, states.ctypes.data, R, N, ldx,
                                    threads, gzip_level)
     if rc != 0:
         raise EpilogosIOError(_err())

@@ -164,14 +164,15 @@ __device__ __forceinline__ void count_row(const char* rowp, int j, const RowGeom
 // Measured alternatives that were NOT faster and were removed: (a) refilling group t of the next tile right after
 // counting it, with inline-asm loads and hand-counted vmcnt (2.46 vs 2.33 ms); (b) flat line-granular loads staged
 // through LDS so that no 128-byte line is requested twice (2.40 ms); (c) nt / sc1 / sc0 sc1 loads (3.1-3.4 ms).
-template <int S, int NG, typename Epilogue, typename Finish>
+// NW = counting waves per block (4, or 3 when the block's last wave is a dedicated store wave)
+template <int S, int NG, int NW = 4, typename Epilogue, typename Finish>
 __device__ __forceinline__ void tile_loop(const char* __restrict__ X, long R, int N, long ldx, Epilogue&& epilogue, Finish&& finish) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int j = lane & 3, b = lane >> 2;
     const RowGeom g = make_geom(N);
     const long nsuper = (R + 31) >> 5;
-    for (long st = (long)blockIdx.x * 4 + wave; st < nsuper; st += (long)gridDim.x * 4) {
+    for (long st = (long)blockIdx.x * NW + wave; st < nsuper; st += (long)gridDim.x * NW) {
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
             const long row = st * 32 + half * 16 + b;

@@ -30,10 +30,25 @@ bool ends_with_gz(const char* path) {
     return n >= 2 && path[n - 2] == 'g' && path[n - 1] == 'z';   // the reference's test: name.endswith("gz")
 }
 
+// threads to use when the caller says 0: the hardware threads, capped by the cgroup CPU quota (a container may see 256
+// hardware threads and be allowed 16 of them at a time) and by 64
 int n_threads(int32_t req) {
     if (req > 0) return req;
-    const unsigned hc = std::thread::hardware_concurrency();
-    return hc ? (int)std::min(hc, 64u) : 4;
+    static const int cached = [] {
+        unsigned hc = std::thread::hardware_concurrency();
+        if (!hc) hc = 4;
+        if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+            char q[64];
+            long long per = 0;
+            if (fscanf(f, "%63s %lld", q, &per) == 2 && strcmp(q, "max") != 0 && per > 0) {
+                const long long quota = (atoll(q) + per - 1) / per;
+                if (quota >= 1 && (unsigned)quota < hc) hc = (unsigned)quota;
+            }
+            fclose(f);
+        }
+        return (int)std::min(hc, 64u);
+    }();
+    return cached;
 }
 
 // whole (decompressed) file in memory; gzread also passes plain files through unchanged
@@ -367,6 +382,65 @@ int epgio_write_scores(const char* path, const char* loc, const int64_t* loc_off
         for (auto& x : th) x.join();
         for (int k = 0; k < nb && ok; ++k) {
             if (!good[k] || fwrite(z[k].data(), 1, z[k].size(), f) != z[k].size()) ok = false;
+        }
+    }
+    if (fclose(f) != 0) ok = false;
+    return ok ? 0 : fail("write error on %s", path);
+}
+
+int epgio_write_states(const char* path, const char* chrom, int64_t start0, int64_t step, const int8_t* states, int64_t R, int32_t N,
+                       int64_t ldx, int32_t threads, int32_t gzip_level) {
+    if (!path || !chrom || (R > 0 && !states) || N < 1 || ldx < N || step < 1) return fail("write_states: bad argument");
+    if (gzip_level < 1 || gzip_level > 9) gzip_level = 6;
+    FILE* f = fopen(path, "wb");
+    if (!f) return fail("cannot create %s", path);
+    const bool gz = ends_with_gz(path);
+    const int T = n_threads(threads);
+    const int64_t CH = 8192;                                    // rows per gzip member (~1.7 KB of text per row at N = 833)
+    const int64_t nchunks = (R + CH - 1) / CH;
+    const size_t clen = strlen(chrom);
+    if (R == 0 && gz) {
+        std::vector<unsigned char> z;
+        gzip_member(std::vector<char>(), gzip_level, z);
+        fwrite(z.data(), 1, z.size(), f);
+    }
+    bool ok = true;
+    for (int64_t c0 = 0; c0 < nchunks && ok; c0 += T) {
+        const int nb = (int)std::min<int64_t>(T, nchunks - c0);
+        std::vector<std::vector<unsigned char>> z(nb);
+        std::vector<std::vector<char>> plain(nb);
+        std::vector<int> good(nb, 0);
+        std::vector<std::thread> th;
+        for (int k = 0; k < nb; ++k)
+            th.emplace_back([&, k] {
+                const int64_t r0 = (c0 + k) * CH, r1 = std::min(R, r0 + CH);
+                std::vector<char>& txt = plain[k];
+                txt.resize((size_t)(r1 - r0) * (clen + 48 + 5 * (size_t)N));
+                char* o = txt.data();
+                for (int64_t r = r0; r < r1; ++r) {
+                    memcpy(o, chrom, clen);
+                    o += clen;
+                    o += sprintf(o, "\t%lld\t%lld", (long long)(start0 + r * step), (long long)(start0 + (r + 1) * step));
+                    const int8_t* row = states + r * ldx;
+                    for (int c = 0; c < N; ++c) {
+                        int v = (int)row[c] + 1;                // file states are 1-based
+                        *o++ = '\t';
+                        if (v < 0) { *o++ = '-'; v = -v; }
+                        if (v >= 100) { *o++ = (char)('0' + v / 100); v %= 100; *o++ = (char)('0' + v / 10); *o++ = (char)('0' + v % 10); }
+                        else if (v >= 10) { *o++ = (char)('0' + v / 10); *o++ = (char)('0' + v % 10); }
+                        else *o++ = (char)('0' + v);
+                    }
+                    *o++ = '\n';
+                }
+                txt.resize((size_t)(o - txt.data()));
+                good[k] = gz ? gzip_member(txt, gzip_level, z[k]) : 1;
+            });
+        for (auto& x : th) x.join();
+        for (int k = 0; k < nb && ok; ++k) {
+            if (!good[k]) { ok = false; break; }
+            const void* p = gz ? (const void*)z[k].data() : (const void*)plain[k].data();
+            const size_t n = gz ? z[k].size() : plain[k].size();
+            if (fwrite(p, 1, n, f) != n) ok = false;
         }
     }
     if (fclose(f) != 0) ok = false;

@@ -361,8 +361,11 @@ __global__ __launch_bounds__(256) void k_score_s2_bin(const u16* __restrict__ H,
         OT* srow = reinterpret_cast<OT*>(&s_stage[wave][lane * ROWB]);
         // LPQ is re-read through the scalar cache for every tile: as a loop invariant its 2*S*S dwords would be hoisted,
         // would not fit the 102 SGPRs and would be spilled to VGPR lanes (618 v_readlane per tile in the first build)
-        const double* lpq = LPQT;
-        asm volatile("" : "+s"(lpq));
+        // (constant address space: the loads stay scalar even though the pointer is opaque to the optimiser)
+        typedef const double __attribute__((address_space(4)))* cdp;
+        const double* lpq_ = LPQT;
+        asm volatile("" : "+s"(lpq_));
+        const cdp lpq = (cdp)lpq_;
 #pragma unroll
         for (int j = 0; j < S; ++j) {
             double G = 0.0;

@@ -40,7 +40,7 @@ def checkArguments(mode, saliency, inputDirPath, inputDirPath2, outputDirPath, n
         print("ERROR: Output directory cannot be the same as the input directory")
         sys.exit()
     if not outputDirPath.exists():
-        outputDirPath.mkdir(parents=True)
+        outputDirPath.mkdir(parents=True, exist_ok=True)       # every rank gets here; the first one creates it
     if not outputDirPath.is_dir():
         raise NotADirectoryError("Given path is not a directory: {}".format(str(outputDirPath)))
     if numProcesses < 0:

@@ -55,6 +55,13 @@ void epgio_close_table(epgio_table* t);
 int epgio_write_scores(const char* path, const char* loc, const int64_t* loc_off, const float* scores, int64_t R,
                        int32_t S, int32_t threads, int32_t gzip_level);
 
+/* The INPUT format, written: R lines "chrom\tstart\tend\t" + N tab-separated 1-based states (value = states[r*ldx + c] + 1),
+ * start = start0 + r*step, end = start + step; gzip (multi-member, compressed in parallel) when the path ends in "gz",
+ * plain text otherwise.  What bin/preprocess_data_ChromHMM.sh produces for the reference (README.md:127-134); here it
+ * feeds the end-to-end runs and tests with matrices at the reference's real width. */
+int epgio_write_states(const char* path, const char* chrom, int64_t start0, int64_t step, const int8_t* states, int64_t R,
+                       int32_t N, int64_t ldx, int32_t threads, int32_t gzip_level);
+
 /* pairwiseMetrics_*.txt.gz of the paired STEP 4 (roiAndVisualPairwise.py:520-573 writeMetrics): one line per bin,
  *   chromosome \t start \t end \t state name \t "%.5f" of |distance| (float32) \t "+" if distance >= 0 else "-"
  *   [ \t "%.5e" p-value \t "%.5e" adjusted p-value ]          (pvals and mh both NULL or both given)

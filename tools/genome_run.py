@@ -1,0 +1,124 @@
+#!/usr/bin/env python3
+"""Whole-genome-scale run of the command line (reference flow: run.py:190-279 processes every file of the input directory):
+24 synthetic "chromosome" .txt.gz files with the hg19 bin counts (200 bp bins, 15 478 375 in total) x 833 biosamples x 18
+states, written in the reference's input format by the native writer, then
+    python -m epilogos_amd.run -l -i <dir> -j <metadata> -o <out> -s 1 --cache-dir <cache>
+cold (text parse, fills the binary cache) and warm (memory-maps the cache), on one GPU.  Prints the phase table
+(EPILOGOS_TIMING), wall time and peak host RSS of each run, checks every output's line count and spot-checks scores against
+the engine.  usage: genome_run.py [--scale 1.0] [--dir /dev/shm/epg_genome] [--saliency 1] [--keep]"""
+import argparse
+import gzip
+import json
+import os
+import shutil
+import subprocess
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parents[1]
+sys.path.insert(0, str(ROOT))
+
+HG19 = [("chr1", 249250621), ("chr2", 243199373), ("chr3", 198022430), ("chr4", 191154276), ("chr5", 180915260),
+        ("chr6", 171115067), ("chr7", 159138663), ("chr8", 146364022), ("chr9", 141213431), ("chr10", 135534747),
+        ("chr11", 135006516), ("chr12", 133851895), ("chr13", 115169878), ("chr14", 107349540), ("chr15", 102531392),
+        ("chr16", 90354753), ("chr17", 81195210), ("chr18", 78077248), ("chr19", 59128983), ("chr20", 63025520),
+        ("chr21", 48129895), ("chr22", 51304566), ("chrX", 155270560), ("chrY", 59373566)]
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--scale", type=float, default=1.0, help="fraction of every chromosome's bins (quick trials)")
+ap.add_argument("--dir", default=None)
+ap.add_argument("--saliency", type=int, default=1)
+ap.add_argument("--biosamples", type=int, default=833)
+ap.add_argument("--keep", action="store_true")
+ap.add_argument("--skip-warm", action="store_true")
+a = ap.parse_args()
+N, S = a.biosamples, 18
+base = Path(a.dir or (Path("/dev/shm") if Path("/dev/shm").is_dir() else Path(os.environ.get("TMPDIR", "/tmp"))) / "epg_genome")
+shutil.rmtree(base, ignore_errors=True)
+ind, cache = base / "in", base / "cache"
+ind.mkdir(parents=True)
+meta = base / "metadata.tsv"
+meta.write_text("zero_index\tone_index\tshort_name\n" + "".join("%d\t%d\tS%d\n" % (i, i + 1, i + 1) for i in range(S)))
+
+# ---- inputs: states drawn on the GPU (bench.generate_shard: chr1 frequencies, fixed global chunk seeds), text by the native writer
+import torch  # noqa: E402
+import bench  # noqa: E402
+from epilogos_amd import _io, engine  # noqa: E402
+engine.require_gpu()
+t0 = time.time()
+rows, bin0, text_bytes = {}, 0, 0
+for name, bp in HG19:
+    R = max(int((bp // 200 + (1 if bp % 200 else 0)) * a.scale), 1)
+    X = torch.empty((R, N), dtype=torch.int8, device="cuda")
+    bench.generate_shard(torch, X, N, S, bin0)
+    x = X.cpu().numpy()
+    del X
+    path = ind / ("matrix_%s.txt.gz" % name)
+    _io.write_states(path, name, x, gzip_level=1)
+    rows[name] = R
+    bin0 += R
+    text_bytes += path.stat().st_size
+total = bin0
+print("inputs: %d files, %d bins x %d biosamples, %.2f GB of .txt.gz written in %.1f s" % (len(HG19), total, N, text_bytes / 1e9, time.time() - t0), flush=True)
+torch.cuda.empty_cache()
+
+WRAP = ("import resource, subprocess, sys, json, time; t = time.time(); r = subprocess.run(sys.argv[1:]); "
+        "print('@@' + json.dumps({'rc': r.returncode, 'wall_s': time.time() - t, "
+        "'peak_rss_gb': resource.getrusage(resource.RUSAGE_CHILDREN).ru_maxrss / 1048576.0})); sys.exit(r.returncode)")
+
+
+def run(label, out):
+    cmd = [sys.executable, "-c", WRAP, sys.executable, "-m", "epilogos_amd.run", "-l", "-i", str(ind), "-j", str(meta), "-o", str(out),
+           "-s", str(a.saliency), "--cache-dir", str(cache)]
+    r = subprocess.run(cmd, cwd=str(ROOT), capture_output=True, text=True, env=dict(os.environ, EPILOGOS_TIMING="1"))
+    info = [json.loads(l[2:]) for l in r.stdout.splitlines() if l.startswith("@@")]
+    print("== %s" % label)
+    print("".join(l + "\n" for l in r.stdout.splitlines() if "[timing]" in l), end="")
+    if r.returncode != 0 or not info:
+        print(r.stdout[-3000:], r.stderr[-5000:])
+        raise SystemExit("%s failed" % label)
+    i = info[0]
+    print("%s: %.1f s wall for %d bins = %.3f Mbins/s end to end (process start, parse, upload, kernels, %%.5f text + gzip, STEP 4); "
+          "peak host RSS %.1f GB" % (label, i["wall_s"], total, total / i["wall_s"] / 1e6, i["peak_rss_gb"]), flush=True)
+    return i
+
+
+out1, out2 = base / "out_cold", base / "out_warm"
+cold = run("cold (inflate + parse text, fills the cache)", out1)
+warm = None if a.skip_warm else run("warm (memory-mapped int8 cache)", out2)
+
+# ---- checks: every chromosome's output has its number of lines; chr21 equals the engine's scores of the cached matrix
+tag = "in_s%d" % a.saliency
+for name, _ in HG19:
+    p = out1 / ("scores_%s_matrix_%s.txt.gz" % (tag, name))
+    with gzip.open(p, "rb") as fh:
+        n = sum(chunk.count(b"\n") for chunk in iter(lambda: fh.read(1 << 24), b""))
+    assert n == rows[name], (name, n, rows[name])
+if warm is not None:
+    for name in ("chr21", "chrY"):
+        a_ = gzip.open(out1 / ("scores_%s_matrix_%s.txt.gz" % (tag, name)), "rb").read()
+        b_ = gzip.open(out2 / ("scores_%s_matrix_%s.txt.gz" % (tag, name)), "rb").read()
+        assert a_ == b_, "cold and warm runs differ on " + name
+if a.saliency == 1:
+    counts = torch.zeros(S, dtype=torch.int64, device="cuda")
+    H21 = None
+    for name, _ in HG19:
+        st = [p for p in cache.glob("matrix_%s_*.states.npy" % name)]
+        x = np.load(st[0], mmap_mode="r")
+        Xd = engine.states_to_device(np.ascontiguousarray(x))
+        H, _ = engine.bin_hist(Xd, N, S, counts=counts)
+        if name == "chr21":
+            H21 = H
+        del Xd
+    q = engine.normalise(counts)
+    o32, _ = engine.score_s1_from_binhist(H21, N, S, q)
+    with gzip.open(out1 / ("scores_%s_matrix_chr21.txt.gz" % tag), "rt") as fh:
+        got = np.loadtxt(fh, usecols=range(3, 3 + S), max_rows=4000, dtype=np.float64)
+    k = min(4000, rows["chr21"])
+    assert np.allclose(got[:k], o32.cpu().numpy()[:k], atol=1.01e-5), "CLI text differs from the engine's scores"
+    print("checks OK: %d output files with the right line counts; chr21 text == engine scores; exp_freq from all 24 files" % len(HG19))
+if not a.keep:
+    shutil.rmtree(base, ignore_errors=True)
