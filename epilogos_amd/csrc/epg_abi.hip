@@ -51,13 +51,13 @@ int null_hist_impl(const int8_t*, int32_t, int64_t, const int8_t*, int32_t, int6
 
 using namespace epg;
 
-namespace epg { extern int g_blocks_per_cu; extern int g_k1_variant; }
+namespace epg { extern int g_blocks_per_cu; }
 
 extern "C" {
 
 // tuning hook for A/B experiments (not part of the public header): persistent-grid size in blocks per CU
 int epg_debug_set_variant(int variant, int blocks_per_cu) {
-    if (variant >= 0) epg::g_k1_variant = variant;
+    (void)variant;
     if (blocks_per_cu > 0) epg::g_blocks_per_cu = blocks_per_cu;
     return EPG_OK;
 }

@@ -161,10 +161,14 @@ __device__ __forceinline__ void count_row(const char* rowp, int j, const RowGeom
 // once per super-tile so the outputs of 32 bins can be written as whole 128-byte lines (32 rows of H are 1152 bytes
 // = 9 lines; 36-byte row pieces written straight from the quads cost 0.35 ms of a 2.4 ms launch: partial-line
 // writes interleaved with the read stream).
+// Round 2 (profiles/r02d, r02e): with the H store the kernel keeps ~20 % fewer read requests in flight than without it
+// while no L2->fabric stall counter moves; the guess that a counting wave's vmcnt (loads and stores in one in-order counter)
+// puts the store latency on its load path was tested with a dedicated store wave per block (three counting waves hand
+// their super-tiles' H rows to the fourth through an LDS ring): same placement-dependent levels, same mean (2.51 against
+// 2.41 ms over four alternating bench runs each, 2.48 against 2.44 ms over eight placements) -- removed.
 // Measured alternatives that were NOT faster and were removed: (a) refilling group t of the next tile right after
 // counting it, with inline-asm loads and hand-counted vmcnt (2.46 vs 2.33 ms); (b) flat line-granular loads staged
 // through LDS so that no 128-byte line is requested twice (2.40 ms); (c) nt / sc1 / sc0 sc1 loads (3.1-3.4 ms).
-// NW = counting waves per block (4, or 3 when the block's last wave is a dedicated store wave)
 template <int S, int NG, int NW = 4, typename Epilogue, typename Finish>
 __device__ __forceinline__ void tile_loop(const char* __restrict__ X, long R, int N, long ldx, Epilogue&& epilogue, Finish&& finish) {
     const int lane = threadIdx.x & 63;

@@ -88,104 +88,6 @@ __global__ __launch_bounds__(256) void k_bin_hist(const char* __restrict__ X, lo
     }
 }
 
-// K1 with a dedicated STORE WAVE (even S, H wanted).  PMC (profiles/r02d): with the H store k_bin_hist keeps ~20 % fewer
-// read requests in flight than without it while no L2->fabric stall counter moves -- the kernel is not throttled by HBM,
-// it issues less.  On gfx950 vmcnt counts loads AND stores of a wave in issue order, so a counting wave that has stored a
-// super-tile's H rows cannot see its next tile's loads complete before those stores are acknowledged: the store latency
-// (which depends on where H and X sit physically) lands on the load path.  Here the block's waves 0..2 count and hand
-// finished super-tiles (32 rows of H = 1152 B at S = 18) to wave 3 through a small LDS ring; wave 3 does nothing but
-// global stores, and only its own vmcnt ever waits for them.
-constexpr int SW_SLOTS = 4;            // ring slots per counting wave
-template <int SC, int NG>
-__global__ __launch_bounds__(256) void k_bin_hist_sw(const char* __restrict__ X, long R, int N, long ldx, u16* __restrict__ H,
-                                                      u64* __restrict__ counts) {
-    constexpr int S = SC;
-    constexpr int ND = (S + 1) / 2;
-    constexpr int ROWB = 2 * S;
-    constexpr int NW = 3;
-    static_assert((S & 1) == 0, "even S only");
-    __shared__ u64 s_cnt[S + 1];
-    __shared__ __attribute__((aligned(16))) char s_ring[NW][SW_SLOTS][32 * ROWB];
-    __shared__ u32 s_flag[NW][SW_SLOTS];               // 0 = free, else rows in the slot
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int j = lane & 3, b = lane >> 2;
-    if (threadIdx.x <= S) s_cnt[threadIdx.x] = 0;
-    if (threadIdx.x < NW * SW_SLOTS) (&s_flag[0][0])[threadIdx.x] = 0;
-    __syncthreads();
-    const long nsuper = (R + 31) >> 5;
-    if (wave == NW) {
-        // ---- store wave: drain the three rings in arrival order; the tiles of counting wave w are known in advance
-        long st[NW];
-        int slot[NW];
-#pragma unroll
-        for (int w = 0; w < NW; ++w) { st[w] = (long)blockIdx.x * NW + w; slot[w] = 0; }
-        for (;;) {
-            bool any_left = false, did = false;
-#pragma unroll
-            for (int w = 0; w < NW; ++w) {
-                if (st[w] >= nsuper) continue;
-                any_left = true;
-                const u32 rows = __hip_atomic_load(&s_flag[w][slot[w]], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                if (!rows) continue;
-                store_staged(s_ring[w][slot[w]], reinterpret_cast<char*>(H) + st[w] * 32 * ROWB, (int)rows * ROWB, lane);
-                __hip_atomic_store(&s_flag[w][slot[w]], 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);   // LDS reads done
-                st[w] += (long)gridDim.x * NW;
-                slot[w] = slot[w] + 1 == SW_SLOTS ? 0 : slot[w] + 1;
-                did = true;
-            }
-            if (!any_left) break;
-            if (!did) __builtin_amdgcn_s_sleep(4);
-        }
-    } else {
-        u32 accp[ND];
-#pragma unroll
-        for (int m = 0; m < ND; ++m) accp[m] = 0;
-        const int flush_every = 65535 / N > 1 ? 65535 / N - 1 : 1;
-        int since = 0, slot = 0;
-        auto flush = [&]() {
-            if (j == 0) {
-#pragma unroll
-                for (int m = 0; m < ND; ++m) {
-                    const u32 lo = accp[m] & 0xffffu, hi = accp[m] >> 16;
-                    if (lo) atomicAdd(&s_cnt[2 * m], (u64)lo);
-                    if (hi) atomicAdd(&s_cnt[2 * m + 1], (u64)hi);
-                }
-            }
-#pragma unroll
-            for (int m = 0; m < ND; ++m) accp[m] = 0;
-            since = 0;
-        };
-        auto epilogue = [&](int half, long row, bool valid, u32 (&cnt)[S]) {
-            u32 d[ND];
-            pack_reduce<S>(cnt, d);
-            if (counts) {
-#pragma unroll
-                for (int m = 0; m < ND; ++m) accp[m] += valid ? d[m] : 0u;
-                if (++since >= flush_every) flush();
-            }
-            if (half == 0)                              // the slot must have been drained (SW_SLOTS super-tiles ago)
-                while (__hip_atomic_load(&s_flag[wave][slot], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) __builtin_amdgcn_s_sleep(1);
-            char* srow = &s_ring[wave][slot][(half * 16 + b) * ROWB];
-#pragma unroll
-            for (int k = 0; k < (ND + 3) / 4; ++k) {
-                const u32 v = sel4(d[4 * k], 4 * k + 1 < ND ? d[4 * k + 1] : 0u, 4 * k + 2 < ND ? d[4 * k + 2] : 0u,
-                                   4 * k + 3 < ND ? d[4 * k + 3] : 0u, j);
-                if (4 * k + j < ND) *reinterpret_cast<u32*>(srow + 4 * (4 * k + j)) = v;
-            }
-        };
-        auto finish = [&](long st, long row0, int rows) {
-            __hip_atomic_store(&s_flag[wave][slot], (u32)rows, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-            slot = slot + 1 == SW_SLOTS ? 0 : slot + 1;
-        };
-        tile_loop<S, NG, NW>(X, R, N, ldx, epilogue, finish);
-        if (counts) flush();
-    }
-    if (counts) {
-        __syncthreads();
-        if ((int)threadIdx.x < S && s_cnt[threadIdx.x]) atomicAdd(&counts[threadIdx.x], s_cnt[threadIdx.x]);
-    }
-}
-
 // Any S <= 127, any N, any alignment, never reads past a row's N bytes: one wave per bin, LDS atomics.
 // Used for the matrix's last row(s) when ldx < 16*ceil(N/16) (the fast kernel's last chunk would over-read).  Decodes
 // the low five bits of a byte like the fast kernel (see epg_count.h) so that both treat every byte value alike.
@@ -342,33 +244,12 @@ static int grid_for_tiles(long R) {
 }
 
 int g_blocks_per_cu = 4;  // persistent grid size (epg_debug_set_variant tunes it for A/B runs)
-int g_k1_variant = 0;     // 0 = counting waves store their own H rows, 1 = dedicated store wave (EPG_K1=sw, or the debug hook)
-
-static int grid_for_tiles_nw(long R, int nw) {
-    const long nsuper = (R + 31) >> 5;
-    long blocks = (nsuper + nw - 1) / nw;
-    const long cap = (long)num_cus() * g_blocks_per_cu;
-    if (blocks > cap) blocks = cap;
-    if (blocks < 1) blocks = 1;
-    return (int)blocks;
-}
-
-static bool k1_store_wave() {
-    static const int env = [] { const char* e = getenv("EPG_K1"); return e ? (e[0] == 's' ? 1 : 0) : -1; }();
-    return env >= 0 ? env == 1 : g_k1_variant == 1;
-}
 
 template <int S, int NG>
 static void launch_bin_hist(const char* X, long R, int N, long ldx, int Sout, u16* H, u64* counts, hipStream_t st) {
     // odd S stores uint16 by uint16 either way; with the row width as a run-time value that path measured 2.30 ms
     // against 2.64 ms for the compile-time one (15 M x 833, S = 15), so only even S takes the compile-time width
     constexpr bool FULL = (S & 1) == 0;
-    if constexpr (FULL && NG > 0) {
-        if (H && k1_store_wave()) {
-            hipLaunchKernelGGL((k_bin_hist_sw<S, NG>), dim3(grid_for_tiles_nw(R, 3)), dim3(256), 0, st, X, R, N, ldx, H, counts);
-            return;
-        }
-    }
     hipLaunchKernelGGL((k_bin_hist<S, NG, FULL>), dim3(grid_for_tiles(R)), dim3(256), 0, st, X, R, N, ldx, Sout, H, counts);
 }
 
