@@ -39,6 +39,8 @@ def load():
     lib.epgio_table_locations.argtypes = [p, C.POINTER(p)]
     lib.epgio_close_table.restype = None
     lib.epgio_close_table.argtypes = [p]
+    lib.epgio_parse_locations.restype = C.c_int
+    lib.epgio_parse_locations.argtypes = [p, p, i64, p, p, C.POINTER(i32), i32]
     lib.epgio_write_scores.restype = C.c_int
     lib.epgio_write_scores.argtypes = [C.c_char_p, p, p, p, i64, i32, i32, i32]
     lib.epgio_write_states.restype = C.c_int
@@ -84,10 +86,21 @@ class Locations:
         return pd.read_table(io.BytesIO(self.blob.tobytes()), header=None, sep="\t").to_numpy()
 
     def columns(self):
-        """(chromosome object array, start int64, end int64) of every row."""
+        """(chromosome object array, start int64, end int64) of every row.  Native parse when the coordinates are plain
+        integers and every row names the same chromosome (one file = one chromosome); pandas otherwise."""
         import pandas as pd
-        if len(self) == 0:
+        R = len(self)
+        if R == 0:
             return np.empty(0, dtype=object), np.zeros(0, dtype=np.int64), np.zeros(0, dtype=np.int64)
+        blob = np.ascontiguousarray(self.blob)
+        off = np.ascontiguousarray(self.offsets, dtype=np.int64)
+        start, end, same = np.empty(R, dtype=np.int64), np.empty(R, dtype=np.int64), C.c_int32(0)
+        rc = load().epgio_parse_locations(blob.ctypes.data, off.ctypes.data, R, start.ctypes.data, end.ctypes.data, C.byref(same), 0)
+        if rc == 0 and same.value:
+            first = blob[off[0]:off[1]].tobytes()
+            chrom = np.empty(R, dtype=object)
+            chrom[:] = first[:first.index(b"\t")].decode()
+            return chrom, start, end
         df = pd.read_table(io.BytesIO(self.blob.tobytes()), header=None, sep="\t")
         return df.iloc[:, 0].to_numpy(dtype=object), df.iloc[:, 1].to_numpy(dtype=np.int64), df.iloc[:, 2].to_numpy(dtype=np.int64)
 

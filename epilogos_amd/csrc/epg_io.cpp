@@ -336,6 +336,50 @@ bool gzip_member(const std::vector<char>& in, int level, std::vector<unsigned ch
 
 extern "C" {
 
+int epgio_parse_locations(const char* loc, const int64_t* loc_off, int64_t R, int64_t* start, int64_t* end, int32_t* same_chrom,
+                          int32_t threads) {
+    if (R < 0 || (R > 0 && (!loc || !loc_off || !start || !end))) return fail("parse_locations: bad argument");
+    const int T = (int)std::max<int64_t>(1, std::min<int64_t>(n_threads(threads), (R + 65535) / 65536));
+    std::vector<int> bad(T, 0), same(T, 1);
+    const char* c0 = loc + (R ? loc_off[0] : 0);
+    const char* c0e = R ? (const char*)memchr(c0, '\t', (size_t)(loc_off[1] - loc_off[0])) : c0;
+    const size_t c0n = c0e ? (size_t)(c0e - c0) : 0;
+    std::vector<std::thread> th;
+    for (int t = 0; t < T; ++t)
+        th.emplace_back([&, t] {
+            for (int64_t r = R * t / T; r < R * (t + 1) / T; ++r) {
+                const char* p = loc + loc_off[r];
+                const char* e = loc + loc_off[r + 1];
+                const char* tab = (const char*)memchr(p, '\t', (size_t)(e - p));
+                if (!tab) { bad[t] = 1; return; }
+                if ((size_t)(tab - p) != c0n || memcmp(p, c0, c0n) != 0) same[t] = 0;
+                int64_t v[2];
+                const char* q = tab + 1;
+                for (int k = 0; k < 2; ++k) {
+                    int64_t x = 0;
+                    bool any = false, neg = false;
+                    if (q < e && *q == '-') { neg = true; ++q; }
+                    while (q < e && *q >= '0' && *q <= '9') { x = x * 10 + (*q - '0'); ++q; any = true; }
+                    if (!any) { bad[t] = 1; return; }
+                    v[k] = neg ? -x : x;
+                    if (k == 0) { if (q >= e || *q != '\t') { bad[t] = 1; return; } ++q; }
+                }
+                if (q < e && *q == '\r') ++q;
+                if (q >= e || *q != '\n') { bad[t] = 1; return; }   // anything else (a float, a third tab): not plain integers
+                start[r] = v[0];
+                end[r] = v[1];
+            }
+        });
+    for (auto& x : th) x.join();
+    int all_same = 1;
+    for (int t = 0; t < T; ++t) {
+        if (bad[t]) return fail("parse_locations: a row is not 'name<TAB>integer<TAB>integer'");
+        all_same &= same[t];
+    }
+    if (same_chrom) *same_chrom = all_same;
+    return 0;
+}
+
 int64_t epgio_format_f5(const float* v, int64_t n, char sep, char* buf, int64_t cap) {
     if (cap < 48 * n) return fail("format_f5: buffer too small");
     char* o = buf;

@@ -38,7 +38,7 @@ def findSign(x):
     return "+" if x >= 0 else "-"
 
 
-def maxMean(chrom, start, end, score, roiWidth, maxRegions):
+def maxMean(chrom, start, end, score, roiWidth, maxRegions, _first_candidates=None):
     """Top `maxRegions` non-overlapping windows of `roiWidth` bins by (rolling max, rolling mean, centre score).
     Restates filter_regions.Filter.maxmean (:375-448) + helpers.maxMean (:253-274) on plain arrays.
     Returns (chromosome, window start, window end, score = rolling max, original centre index), best first."""
@@ -61,18 +61,31 @@ def maxMean(chrom, start, end, score, roiWidth, maxRegions):
     keep = np.nonzero(ok)[0]
     orig, w_start, w_end, sc, rmax, rmean = orig[keep], w_start[keep], w_end[keep], sc[keep], rmax[keep], rmean[keep]
     n = len(keep)
-    # descending by (max, mean, score); ties keep genomic order (pandas' multi-key sort is stable)
-    order = np.lexsort((-sc, -rmean, -rmax))
-    hits = np.zeros(n, dtype=bool)
-    chosen = []
-    for m in order:
-        if len(chosen) >= maxRegions:
+    # descending by (max, mean, score); ties keep genomic order (pandas' multi-key sort is stable).  The greedy pick only
+    # consumes a PREFIX of that order, so instead of sorting all n windows (a whole genome has 15 M) the windows whose
+    # rolling max reaches the m-th largest are sorted -- every one of them, ties at the threshold included, so their order
+    # is exactly the prefix of the full sort -- and the candidate set grows only if the pick runs through it.
+    m_try = min(n, _first_candidates if _first_candidates else max(4096, 64 * W * maxRegions))
+    while True:
+        if m_try >= n:
+            cand = np.arange(n)
+        else:
+            thresh = np.partition(rmax, n - m_try)[n - m_try]
+            cand = np.nonzero(rmax >= thresh)[0]          # ascending = genomic order, as a stable sort needs
+        order = cand[np.lexsort((-sc[cand], -rmean[cand], -rmax[cand]))]
+        hits = np.zeros(n, dtype=bool)
+        chosen = []
+        for m in order:
+            if len(chosen) >= maxRegions:
+                break
+            a = max(m - h, 0)
+            b = min(m + h + 1 if W % 2 else m + h, n)
+            if not hits[a:b].any():
+                hits[a:b] = True
+                chosen.append(m)
+        if len(chosen) >= maxRegions or len(cand) == n:
             break
-        a = max(m - h, 0)
-        b = min(m + h + 1 if W % 2 else m + h, n)
-        if not hits[a:b].any():
-            hits[a:b] = True
-            chosen.append(m)
+        m_try = min(n, 8 * m_try)
     chosen = np.array(sorted(chosen), dtype=np.int64)        # back to genomic order, then best first (stable)
     final = chosen[np.lexsort((-sc[chosen], -rmean[chosen], -rmax[chosen]))]    # helpers.py:272: by max, mean, centre score
     return (np.asarray(chrom)[orig[final]], w_start[final], w_end[final], rmax[final], orig[final])
@@ -121,7 +134,7 @@ def mainFromArrays(results, outputDir, stateInfo, fileTag, expFreqPath, roiWidth
     byChr = {v[0]: v for v in results.values()}
     order = orderChromosomes(list(byChr))
     scoreArr = np.concatenate([byChr[c][1] for c in order])
-    cols = [byChr[c][2].columns() for c in order]
+    cols = [byChr[c][2].columns() for c in order]              # native parse of the verbatim "chr\tstart\tend" text
     locationArr = tuple(np.concatenate([c[k] for c in cols]) for k in range(3))
     if not verbose: print("    Regions of interest txt\t", end="", flush=True)
     createTopScoresTxt(Path(outputDir) / "regionsOfInterest_{}.txt".format(fileTag), locationArr, scoreArr,

@@ -48,6 +48,11 @@ int epgio_table_copy_states(const epgio_table* t, int8_t* out, int64_t ldx);
  * concatenated; offsets[r]..offsets[r+1] delimit row r (newline included).  Valid until epgio_close_table. */
 const char* epgio_table_locations(const epgio_table* t, const int64_t** offsets);
 void epgio_close_table(epgio_table* t);
+/* Integer start / end of every row of such a location text ("name\tstart\tend\n" per row) and whether all rows carry the
+ * first row's name -- what STEP 4 needs of locationArr (roiSingle.py:95-142) without a text parse of 15 M rows in Python.
+ * Fails (-1) when a coordinate is not a plain integer; callers then fall back to a general parser. */
+int epgio_parse_locations(const char* loc, const int64_t* loc_off, int64_t R, int64_t* start, int64_t* end,
+                          int32_t* same_chrom, int32_t threads);
 
 /* Write R lines: location text of row r (loc + loc_off[r] .. loc_off[r+1], its trailing '\n' dropped) + '\t' + S
  * "%.5f" values + '\n'.
