@@ -1,0 +1,241 @@
+// S3 expected pass as a pure fp4 matrix-core contraction of a PRECOMPUTED one-hot operand (gfx950).
+//
+// C[a,b,i,j] = #{bins : x[a] == i and x[b] == j} = E^T E for the one-hot expansion E[bin, (sample, state)]
+// (reference expected.py:183-200).  epg_s3_mfma.hip builds the one-hot nibbles inside the contraction kernel, from state
+// bytes, and measured that on a gfx950 SIMD the VALU time of that build and the MFMA time ADD UP (tools/ubench/
+// mfma_valu.hip): 9 MFMAs of 64 bins cost ~400 cycles, the operand build ~350 more, and every operand is rebuilt by each of
+// the ~157 workgroups that need it.  Here every operand is built ONCE per chunk of bins into HBM, already in the register
+// layout of v_mfma_scale_f32_32x32x64_f8f6f4 (fp4 E2M1, 1.0 = 0b0010, unit block scales), and the contraction kernel is
+// left with loads and matrix instructions:
+//   k_s3_onehot_fp4   XT[sample][bin] -> E4[kstep][tile32][1 KiB]: tile = 32 consecutive (sample, state) rows x 64 bins,
+//                     stored [half][row][16 B] = lane-linear for both the LDS-DMA that stages it and the ds_read_b128 that
+//                     feeds it to the MFMA (7.5 KB per bin; a chunk of 256 K bins = 1.9 GB of workspace at N = 833).
+//   k_s3_syrk_fp4     workgroup = 8 waves = 2 x 4 blocks of 96 rows (192 x 384 of C), wave = one 96 x 96 block pair (3 x 3
+//                     MFMA tiles, 144 accumulator registers); per 128 bins the 18 + 18 operand tiles (36 KiB) are staged
+//                     ONCE per workgroup by global_load_lds_dwordx4 (no registers, no VALU) into a 3-deep LDS ring, two
+//                     stages ahead (counted vmcnt, raw s_barrier: one barrier per 18 MFMAs of a wave), and every wave reads
+//                     its six tiles per 64 bins with ds_read_b128.  Only block pairs bm <= bn are computed; the epilogue
+//                     writes the mirrored cells too.  Workgroups are ordered in 8 x 4 patches of the (bm-pair, bn-quad)
+//                     grid and dealt to the XCDs in contiguous runs, so the 32 workgroups that share an L2 share operand
+//                     panels.  Accumulation is float32 of exact integers (a chunk is < 2^24 bins); int32 atomics add the
+//                     chunk to the caller's counts.
+// Rows past N*S are zero tiles, bins past R hold "not a state": no edge cases inside the loop.
+#include "epg_common.h"
+
+namespace epg {
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v8i __attribute__((ext_vector_type(8)));
+typedef float v16f __attribute__((ext_vector_type(16)));
+
+constexpr int G_WM = 2, G_WN = 4;                       // waves of a workgroup along the A / B side
+constexpr int G_BLK = 96;                               // rows of a wave's block (3 tiles of 32)
+constexpr int G_BM = G_WM * G_BLK, G_BN = G_WN * G_BLK; // 192 x 384 rows of C per workgroup
+constexpr int G_TA = G_BM / 32, G_TB = G_BN / 32;       // 6 + 12 operand tiles per k-step
+constexpr int G_KS = 2;                                 // k-steps (of 64 bins) per stage
+constexpr int G_STAGES = 3;                             // LDS ring depth; loads run two stages ahead
+constexpr int G_LOADS = 5;                              // 1 KiB LDS-DMA loads per wave and stage: 8 x 5 = 40 slots, 36 used
+constexpr int G_STAGE_BYTES = 8 * G_LOADS * 1024;       // 40 KiB
+constexpr int G_PATCH_P = 8, G_PATCH_Q = 4;             // workgroup ordering: patches of 8 bm-pairs x 4 bn-quads
+constexpr long G_KC_MAX = 262144;                       // bins per chunk (multiple of 128; < 2^24)
+
+__host__ __device__ inline int g_rows_padded(int NS) { return (NS + G_BN - 1) / G_BN * G_BN; }
+
+// SWAR one-hot of 32 state bytes (two uint4) against the lane's state: fp4 nibbles, 0b0010 where equal (see
+// epg_s3_mfma.hip: both operands come from this routine, so which bin lands in which nibble does not matter)
+__device__ __forceinline__ u32 g_eq_pair_fp4(u32 w0, u32 w1, u32 pat) {
+    const u32 d0 = 0x80808080u - (w0 ^ pat);
+    const u32 d1 = 0x80808080u - (w1 ^ pat);
+    return ((d0 >> 6) & 0x02020202u) | ((d1 >> 2) & 0x20202020u);
+}
+
+__global__ __launch_bounds__(256) void k_s3_onehot_fp4(const char* __restrict__ XT, long Rp, int N, int S, int NS, int NT, long k0,
+                                                        long nksteps, uint4* __restrict__ E4) {
+    const int lane = threadIdx.x & 63;
+    const long id = (long)blockIdx.x * 4 + (threadIdx.x >> 6);          // (kstep, tile), tile fastest: 1 KiB per wave, in order
+    if (id >= nksteps * NT) return;
+    const int tile = (int)(id % NT);
+    const long kstep = id / NT;
+    const int r = tile * 32 + (lane & 31);
+    const int a = r < NS ? r / S : N - 1;
+    const u32 pat = (u32)(r < NS ? r - a * S : 30) * 0x01010101u;        // rows past N*S match nothing (states <= 29 or 31)
+    const char* src = XT + (long)a * Rp + k0 + 64 * kstep + 32 * (lane >> 5);
+    const uint4 r0 = *reinterpret_cast<const uint4*>(src), r1 = *reinterpret_cast<const uint4*>(src + 16);
+    E4[id * 64 + lane] = make_uint4(g_eq_pair_fp4(r0.x, r0.y, pat), g_eq_pair_fp4(r0.z, r0.w, pat), g_eq_pair_fp4(r1.x, r1.y, pat),
+                                    g_eq_pair_fp4(r1.z, r1.w, pat));
+}
+
+// Workgroup tasks (P = pair of A blocks, Q = quad of B blocks, P <= 2Q + 1 so that some bm <= bn), patch by patch.
+__global__ void k_s3_tasks(int NQ, int* __restrict__ tasks) {
+    if (threadIdx.x || blockIdx.x) return;
+    int n = 0;
+    for (int qq = 0; qq * G_PATCH_Q < NQ; ++qq)
+        for (int pp = 0; pp * G_PATCH_P <= 2 * (qq * G_PATCH_Q + G_PATCH_Q - 1) + 1; ++pp)
+            for (int Q = qq * G_PATCH_Q; Q < qq * G_PATCH_Q + G_PATCH_Q && Q < NQ; ++Q)
+                for (int P = pp * G_PATCH_P; P < pp * G_PATCH_P + G_PATCH_P && P <= 2 * Q + 1; ++P) tasks[n++] = P | (Q << 16);
+}
+
+__device__ __forceinline__ void g_lds_read(v4i& r, u32 addr, int imm) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(imm) : "memory");
+}
+
+template <int KS_IMM>
+__device__ __forceinline__ void g_step(u32 aA, u32 aB, bool active, v16f (&acc)[3][3]) {
+    v4i fa[3], fb[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fa[t]) : "v"(aA), "n"((KS_IMM * (G_TA + G_TB) + t) * 1024) : "memory");
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fb[t]) : "v"(aB), "n"((KS_IMM * (G_TA + G_TB) + t) * 1024) : "memory");
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[0]), "+v"(fa[1]), "+v"(fa[2]), "+v"(fb[0]), "+v"(fb[1]), "+v"(fb[2])::"memory");
+    if (active) {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) {
+                const v8i A = __builtin_shufflevector(fa[a], fa[a], 0, 1, 2, 3, -1, -1, -1, -1);   // fp4: four registers are read
+                const v8i B = __builtin_shufflevector(fb[b], fb[b], 0, 1, 2, 3, -1, -1, -1, -1);
+                acc[a][b] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A, B, acc[a][b], 4, 4, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+            }
+        __builtin_amdgcn_s_setprio(0);
+    }
+}
+
+__global__ __launch_bounds__(512, 2) void k_s3_syrk_fp4(const char* __restrict__ E4, int NT, long nstages, long stages_per_split,
+                                                         const int* __restrict__ tasks, int ntasks, int N, int S,
+                                                         int* __restrict__ counts) {
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = w >> 2, wn = w & 3;
+    // XCD b % 8 takes a contiguous run of the patch-ordered task list (bijective for any ntasks)
+    const int xcd = blockIdx.x & 7, q8 = ntasks >> 3, r8 = ntasks & 7;
+    const int tix = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (blockIdx.x >> 3);
+    const int task = tasks[tix];
+    const int P = task & 0xffff, Q = task >> 16;
+    const int bm = G_WM * P + wm, bn = G_WN * Q + wn;
+    const bool active = bm <= bn;                                           // wave-uniform
+    const long g0 = (long)blockIdx.y * stages_per_split;
+    const long G = nstages - g0 < stages_per_split ? nstages - g0 : stages_per_split;
+    if (G <= 0) return;
+
+    // this wave's five load slots of a stage: slot = w + 8 j -> (k-step, tile) -> source offset inside the stage's two k-steps
+    long soff[G_LOADS];
+    u32 doff[G_LOADS];
+#pragma unroll
+    for (int j = 0; j < G_LOADS; ++j) {
+        const int slot = w + 8 * j;
+        const int s = slot < G_KS * (G_TA + G_TB) ? slot : 0;              // slots 36..39: a harmless duplicate into scrap space
+        const int ks = s / (G_TA + G_TB), t = s - ks * (G_TA + G_TB);
+        const int gt = t < G_TA ? P * G_TA + t : Q * G_TB + (t - G_TA);
+        soff[j] = ((long)ks * NT + gt) * 1024 + lane * 16;
+        doff[j] = (u32)slot * 1024;
+    }
+    const char* src0 = E4 + g0 * G_KS * (long)NT * 1024;
+    const long stage_stride = (long)G_KS * NT * 1024;
+    auto issue = [&](long g) {
+        const char* src = src0 + g * stage_stride;
+        char* dst = smem + (g % G_STAGES) * G_STAGE_BYTES;
+#pragma unroll
+        for (int j = 0; j < G_LOADS; ++j)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + soff[j]),
+                                             (__attribute__((address_space(3))) void*)(dst + doff[j]), 16, 0, 0);
+    };
+
+    v16f acc[3][3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    const u32 lds0 = (u32)(uintptr_t)smem + (u32)lane * 16;
+    const u32 baseA = lds0 + (u32)(wm * 3) * 1024, baseB = lds0 + (u32)(G_TA + wn * 3) * 1024;
+    issue(0);
+    if (G > 1) issue(1);
+    for (long g = 0; g < G; ++g) {
+        // stage g has landed for this wave's loads; after the barrier for everybody's.  The barrier also tells that every
+        // wave is done reading stage g - 1, whose ring slot the loads of stage g + 2 overwrite.
+        if (g + 1 < G) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G_LOADS) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (g + 2 < G) issue(g + 2);
+        const u32 so = (u32)(g % G_STAGES) * G_STAGE_BYTES;
+        g_step<0>(baseA + so, baseB + so, active, acc);
+        g_step<1>(baseA + so, baseB + so, active, acc);
+    }
+    if (!active) return;
+
+    const int NS = N * S;
+    const long SS = (long)S * S;
+#pragma unroll
+    for (int ta = 0; ta < 3; ++ta)
+#pragma unroll
+        for (int tb = 0; tb < 3; ++tb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int v = (int)acc[ta][tb][r];
+                if (!v) continue;
+                const int m = (bm * 3 + ta) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const int n = (bn * 3 + tb) * 32 + (lane & 31);
+                if (m >= NS || n >= NS) continue;
+                const int a = m / S, i = m - a * S, b = n / S, j = n - b * S;
+                if (a == b) continue;
+                atomicAdd(&counts[((long)a * N + b) * SS + i * S + j], v);
+                if (bm != bn) atomicAdd(&counts[((long)b * N + a) * SS + j * S + i], v);
+            }
+}
+
+int transpose_states(const char* X, int64_t R, int32_t N, int64_t ldx, int32_t S, char* XT, int64_t Rp, int shift, hipStream_t st);
+
+static long g_chunk_bins(long Rp) { return Rp < G_KC_MAX ? Rp : G_KC_MAX; }
+
+// workspace: XT | task list | E4 chunk
+int64_t s3_gemm_ws_bytes(int64_t R, int N, int S) {
+    const long Rp = align_up(R, 512);
+    const int NSP = g_rows_padded(N * S), NT = NSP / 32, NQ = NSP / G_BN;
+    return align_up((int64_t)N * Rp + 64, 1024) + align_up((int64_t)NQ * (NQ + 1) * 4, 1024) + (int64_t)NT * 1024 * (g_chunk_bins(Rp) / 64);
+}
+
+int hist_s3_gemm(const char* X, int64_t R, int32_t N, int64_t ldx, int32_t S, int32_t* counts, void* ws, hipStream_t st) {
+    const long Rp = align_up(R, 512);                  // whole stages; padded bins hold 31, which matches no row
+    const int NS = N * S, NSP = g_rows_padded(NS), NT = NSP / 32, NQ = NSP / G_BN;
+    const int ntasks = NQ * (NQ + 1);
+    char* XT = reinterpret_cast<char*>(ws);
+    int* tasks = reinterpret_cast<int*>(XT + align_up((int64_t)N * Rp + 64, 1024));
+    char* E4 = reinterpret_cast<char*>(tasks) + align_up((int64_t)ntasks * 4, 1024);
+    int rc = transpose_states(X, R, N, ldx, S, XT, Rp, 0, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_s3_tasks, dim3(1), dim3(1), 0, st, NQ, tasks);
+    EPG_LAUNCH_CHECK("k_s3_tasks");
+    static bool attr_set = false;
+    if (!attr_set) {
+        EPG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_s3_syrk_fp4), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    G_STAGES * G_STAGE_BYTES));
+        attr_set = true;
+    }
+    const long KC = g_chunk_bins(Rp);
+    for (long k0 = 0; k0 < Rp; k0 += KC) {
+        const long kc = Rp - k0 < KC ? Rp - k0 : KC;   // multiple of 512
+        const long nksteps = kc / 64, nstages = nksteps / G_KS;
+        const long waves = nksteps * NT;
+        hipLaunchKernelGGL(k_s3_onehot_fp4, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, XT, Rp, N, S, NS, NT, k0, nksteps,
+                           reinterpret_cast<uint4*>(E4));
+        EPG_LAUNCH_CHECK("k_s3_onehot_fp4");
+        // few tasks (small N): split the chunk's stages over blockIdx.y so that every CU has work; int32 atomics combine
+        long splits = (2L * num_cus() + ntasks - 1) / ntasks;
+        if (splits > nstages) splits = nstages;
+        if (splits < 1) splits = 1;
+        if (splits > 65535) splits = 65535;
+        const long per = (nstages + splits - 1) / splits;
+        const long nsplit = (nstages + per - 1) / per;
+        hipLaunchKernelGGL(k_s3_syrk_fp4, dim3((unsigned)ntasks, (unsigned)nsplit), dim3(512), G_STAGES * G_STAGE_BYTES, st, E4, NT, nstages,
+                           per, tasks, ntasks, N, S, counts);
+        EPG_LAUNCH_CHECK("k_s3_syrk_fp4");
+    }
+    return EPG_OK;
+}
+
+}  // namespace epg
