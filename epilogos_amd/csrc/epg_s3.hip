@@ -284,7 +284,8 @@ int64_t s3_mfma_ws_bytes(int64_t R, int N);
 int transpose_states(const char* X, int64_t R, int32_t N, int64_t ldx, int32_t S, char* XT, int64_t Rp, int shift, hipStream_t st);
 int hist_s3_mfma(const char* X, int64_t R, int32_t N, int64_t ldx, int32_t S, int32_t* counts, void* ws, hipStream_t st);
 int64_t s3_gemm_ws_bytes(int64_t R, int N, int S);
-int hist_s3_gemm(const char* X, int64_t R, int32_t N, int64_t ldx, int32_t S, int32_t* counts, void* ws, hipStream_t st);
+int64_t s3_gemm_ws_min_bytes(int64_t R, int N, int S);
+int hist_s3_gemm(const char* X, int64_t R, int32_t N, int64_t ldx, int32_t S, int32_t* counts, void* ws, int64_t ws_bytes, hipStream_t st);
 
 static int s3_nceil(int N) { return (N + S3S_ACH - 1) / S3S_ACH * S3S_ACH; }
 int64_t s3_table_bytes(int N, int S) { return align_up((int64_t)s3_nceil(N) * N * S * S * 4, 256); }
@@ -308,8 +309,8 @@ int hist_s3_impl(const int8_t* X8, int64_t R, int32_t N, int64_t ldx, int32_t S,
     // default: the precomputed-operand contraction (epg_s3_gemm.hip) when the workspace holds a chunk of the operand;
     // EPG_S3_MFMA = f / e / b selects one of the build-in-kernel variants of epg_s3_mfma.hip (A/B measurements)
     static const char mfma_choice = [] { const char* e = getenv("EPG_S3_MFMA"); return e ? e[0] : 'g'; }();
-    if (!force_lds && S <= 30 && ws && mfma_choice == 'g' && ws_bytes >= s3_gemm_ws_bytes(R, N, S))
-        return hist_s3_gemm(reinterpret_cast<const char*>(X8), R, N, ldx, S, counts, ws, st);
+    if (!force_lds && S <= 30 && ws && mfma_choice == 'g' && ws_bytes >= s3_gemm_ws_min_bytes(R, N, S))
+        return hist_s3_gemm(reinterpret_cast<const char*>(X8), R, N, ldx, S, counts, ws, ws_bytes, st);
     if (!force_lds && S <= 30 && ws && ws_bytes >= s3_mfma_ws_bytes(R, N))
         return hist_s3_mfma(reinterpret_cast<const char*>(X8), R, N, ldx, S, counts, ws, st);
     const int TA = s3_ta(S);

@@ -22,6 +22,8 @@
 // Rows past N*S are zero tiles, bins past R hold "not a state": no edge cases inside the loop.
 #include "epg_common.h"
 
+#include <stdlib.h>
+
 namespace epg {
 
 typedef int v4i __attribute__((ext_vector_type(4)));
@@ -37,7 +39,8 @@ constexpr int G_STAGES = 3;                             // LDS ring depth; loads
 constexpr int G_LOADS = 5;                              // 1 KiB LDS-DMA loads per wave and stage: 8 x 5 = 40 slots, 36 used
 constexpr int G_STAGE_BYTES = 8 * G_LOADS * 1024;       // 40 KiB
 constexpr int G_PATCH_P = 8, G_PATCH_Q = 4;             // workgroup ordering: patches of 8 bm-pairs x 4 bn-quads
-constexpr long G_KC_MAX = 262144;                       // bins per chunk (multiple of 128; < 2^24)
+constexpr long G_KC_MAX = 1048576;                      // bins per chunk the workspace size is quoted for (multiple of 512; < 2^24)
+constexpr long G_KC_MIN = 16384;
 
 __host__ __device__ inline int g_rows_padded(int NS) { return (NS + G_BN - 1) / G_BN * G_BN; }
 
@@ -75,36 +78,79 @@ __global__ void k_s3_tasks(int NQ, int* __restrict__ tasks) {
                 for (int P = pp * G_PATCH_P; P < pp * G_PATCH_P + G_PATCH_P && P <= 2 * Q + 1; ++P) tasks[n++] = P | (Q << 16);
 }
 
-__device__ __forceinline__ void g_lds_read(v4i& r, u32 addr, int imm) {
-    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(imm) : "memory");
-}
+// the six operand tiles of one k-step: issued as a batch, consumed one batch of nine MFMAs later
+struct GOps {
+    v4i a[3], b[3];
+};
 
 template <int KS_IMM>
-__device__ __forceinline__ void g_step(u32 aA, u32 aB, bool active, v16f (&acc)[3][3]) {
-    v4i fa[3], fb[3];
+__device__ __forceinline__ void g_read(GOps& o, u32 aA, u32 aB) {
 #pragma unroll
     for (int t = 0; t < 3; ++t) {
-        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fa[t]) : "v"(aA), "n"((KS_IMM * (G_TA + G_TB) + t) * 1024) : "memory");
-        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fb[t]) : "v"(aB), "n"((KS_IMM * (G_TA + G_TB) + t) * 1024) : "memory");
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(o.a[t]) : "v"(aA), "n"((KS_IMM * (G_TA + G_TB) + t) * 1024) : "memory");
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(o.b[t]) : "v"(aB), "n"((KS_IMM * (G_TA + G_TB) + t) * 1024) : "memory");
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[0]), "+v"(fa[1]), "+v"(fa[2]), "+v"(fb[0]), "+v"(fb[1]), "+v"(fb[2])::"memory");
-    if (active) {
-        __builtin_amdgcn_s_setprio(1);
+}
+
+__device__ __forceinline__ void g_wait_lds(GOps& o) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(o.a[0]), "+v"(o.a[1]), "+v"(o.a[2]), "+v"(o.b[0]), "+v"(o.b[1]), "+v"(o.b[2])::"memory");
+}
+
+#define G_MFMA(I, J)                                                                                                             \
+    acc[I][J] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(__builtin_shufflevector(o.a[I], o.a[I], 0, 1, 2, 3, -1, -1, -1, -1), \
+                                                                __builtin_shufflevector(o.b[J], o.b[J], 0, 1, 2, 3, -1, -1, -1, -1), \
+                                                                acc[I][J], 4, 4, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f)
+
+// nine MFMAs of one k-step (fp4 operands: four registers are read)
+__device__ __forceinline__ void g_mfma(const GOps& o, bool active, v16f (&acc)[3][3]) {
+    if (!active) return;
+    __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-        for (int a = 0; a < 3; ++a)
+    for (int a = 0; a < 3; ++a)
 #pragma unroll
-            for (int b = 0; b < 3; ++b) {
-                const v8i A = __builtin_shufflevector(fa[a], fa[a], 0, 1, 2, 3, -1, -1, -1, -1);   // fp4: four registers are read
-                const v8i B = __builtin_shufflevector(fb[b], fb[b], 0, 1, 2, 3, -1, -1, -1, -1);
-                acc[a][b] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A, B, acc[a][b], 4, 4, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
-            }
-        __builtin_amdgcn_s_setprio(0);
+        for (int b = 0; b < 3; ++b) G_MFMA(a, b);
+    __builtin_amdgcn_s_setprio(0);
+}
+
+// The same with the wave's five LDS-DMA loads of a later stage spread between the MFMAs.  Issuing an LDS-DMA load costs the
+// wave ~60-180 cycles of issue time (MI355X_MICROARCH.md, price list); five in a row right after the barrier, in both waves
+// of a SIMD at once, left the matrix pipe idle for that long (1M bins: 55.6 ms; interleaved: see DESIGN.md).  sched_barrier
+// pins the order the optimiser would otherwise restore.
+template <typename Load>
+__device__ __forceinline__ void g_mfma_loads(const GOps& o, bool active, v16f (&acc)[3][3], Load&& load) {
+    if (!active) {
+#pragma unroll
+        for (int j = 0; j < G_LOADS; ++j) load(j);
+        return;
     }
+    __builtin_amdgcn_s_setprio(1);
+    G_MFMA(0, 0); G_MFMA(0, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    load(0);
+    __builtin_amdgcn_sched_barrier(0);
+    G_MFMA(0, 2); G_MFMA(1, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    load(1);
+    __builtin_amdgcn_sched_barrier(0);
+    G_MFMA(1, 1); G_MFMA(1, 2);
+    __builtin_amdgcn_sched_barrier(0);
+    load(2);
+    __builtin_amdgcn_sched_barrier(0);
+    G_MFMA(2, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    load(3);
+    __builtin_amdgcn_sched_barrier(0);
+    G_MFMA(2, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    load(4);
+    __builtin_amdgcn_sched_barrier(0);
+    G_MFMA(2, 2);
+    __builtin_amdgcn_s_setprio(0);
 }
 
 __global__ __launch_bounds__(512, 2) void k_s3_syrk_fp4(const char* __restrict__ E4, int NT, long nstages, long stages_per_split,
                                                          const int* __restrict__ tasks, int ntasks, int N, int S,
-                                                         int* __restrict__ counts) {
+                                                         int* __restrict__ counts, int dbg) {
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -117,7 +163,7 @@ __global__ __launch_bounds__(512, 2) void k_s3_syrk_fp4(const char* __restrict__
     const int bm = G_WM * P + wm, bn = G_WN * Q + wn;
     const bool active = bm <= bn;                                           // wave-uniform
     const long g0 = (long)blockIdx.y * stages_per_split;
-    const long G = nstages - g0 < stages_per_split ? nstages - g0 : stages_per_split;
+    const int G = (int)(nstages - g0 < stages_per_split ? nstages - g0 : stages_per_split);   // < 2^24 / 128
     if (G <= 0) return;
 
     // this wave's five load slots of a stage: slot = w + 8 j -> (k-step, tile) -> source offset inside the stage's two k-steps
@@ -128,19 +174,19 @@ __global__ __launch_bounds__(512, 2) void k_s3_syrk_fp4(const char* __restrict__
         const int slot = w + 8 * j;
         const int s = slot < G_KS * (G_TA + G_TB) ? slot : 0;              // slots 36..39: a harmless duplicate into scrap space
         const int ks = s / (G_TA + G_TB), t = s - ks * (G_TA + G_TB);
-        const int gt = t < G_TA ? P * G_TA + t : Q * G_TB + (t - G_TA);
+        const int gt = (dbg & 1) ? t : (t < G_TA ? P * G_TA + t : Q * G_TB + (t - G_TA));   // dbg 1: every workgroup the same panels
         soff[j] = ((long)ks * NT + gt) * 1024 + lane * 16;
         doff[j] = (u32)slot * 1024;
     }
     const char* src0 = E4 + g0 * G_KS * (long)NT * 1024;
     const long stage_stride = (long)G_KS * NT * 1024;
-    auto issue = [&](long g) {
-        const char* src = src0 + g * stage_stride;
-        char* dst = smem + (g % G_STAGES) * G_STAGE_BYTES;
+    auto issue1 = [&](int g, int slot, int j) {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src0 + g * stage_stride + soff[j]),
+                                         (__attribute__((address_space(3))) void*)(smem + slot * G_STAGE_BYTES + doff[j]), 16, 0, 0);
+    };
+    auto issue = [&](int g, int slot) {
 #pragma unroll
-        for (int j = 0; j < G_LOADS; ++j)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + soff[j]),
-                                             (__attribute__((address_space(3))) void*)(dst + doff[j]), 16, 0, 0);
+        for (int j = 0; j < G_LOADS; ++j) issue1(g, slot, j);
     };
 
     v16f acc[3][3];
@@ -153,53 +199,123 @@ __global__ __launch_bounds__(512, 2) void k_s3_syrk_fp4(const char* __restrict__
 
     const u32 lds0 = (u32)(uintptr_t)smem + (u32)lane * 16;
     const u32 baseA = lds0 + (u32)(wm * 3) * 1024, baseB = lds0 + (u32)(G_TA + wn * 3) * 1024;
-    issue(0);
-    if (G > 1) issue(1);
-    for (long g = 0; g < G; ++g) {
-        // stage g has landed for this wave's loads; after the barrier for everybody's.  The barrier also tells that every
-        // wave is done reading stage g - 1, whose ring slot the loads of stage g + 2 overwrite.
-        if (g + 1 < G) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G_LOADS) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        if (g + 2 < G) issue(g + 2);
-        const u32 so = (u32)(g % G_STAGES) * G_STAGE_BYTES;
-        g_step<0>(baseA + so, baseB + so, active, acc);
-        g_step<1>(baseA + so, baseB + so, active, acc);
+    // Software pipeline.  LDS-DMA runs two to three stages ahead (ring of three: a stage's slot is refilled only after the
+    // barrier that every wave passes once its last operands of that stage sit in registers).  The operand tiles of k-step
+    // k + 1 are requested BEFORE the nine MFMAs of k-step k are issued and waited for after them, so the 48 KiB a
+    // workgroup reads from LDS per k-step (~190 LDS cycles) and the read latency hide under matrix work instead of
+    // standing between the two waves of a SIMD after every barrier (first version: 2400 cycles per stage for 1584 of MFMA).
+    issue(0, 0);
+    issue(G > 1 ? 1 : 0, 1);                               // a chunk shorter than the pipeline refetches stage 0: never read
+    issue(G > 2 ? 2 : 0, 2);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * G_LOADS) : "memory");
+    __builtin_amdgcn_s_barrier();
+    GOps o0, o1;
+    g_read<0>(o0, baseA, baseB);
+    g_wait_lds(o0);
+    int slot = 0;                                          // ring slot of stage g (g mod 3 without the division)
+    for (int g = 0; g < G; ++g) {
+        const u32 so = (u32)slot * G_STAGE_BYTES;
+        const int slot1 = slot == G_STAGES - 1 ? 0 : slot + 1;
+        g_read<1>(o1, baseA + so, baseB + so);
+        g_mfma(o0, active, acc);
+        g_wait_lds(o1);
+        if (g + 1 < G) {
+            // stage g + 1: this wave's loads have landed (those of stage g + 2 -- real or, at the tail, dummies -- stay in
+            // flight); after the barrier everybody's.  Every wave that reaches the barrier holds its last operands of stage g
+            // in registers: the slot is free.
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G_LOADS) : "memory");
+            __builtin_amdgcn_s_barrier();
+            const u32 sn = (u32)slot1 * G_STAGE_BYTES;
+            g_read<0>(o0, baseA + sn, baseB + sn);
+        }
+        // stage g + 3 takes over the slot stage g has just left; its loads go out between this batch's MFMAs.  Past the last
+        // stage the same instructions fetch stage 0 into the ring's scrap slots, so that the loop has no load-dependent
+        // control flow (the optimiser gathers conditional loads in front of the MFMAs) and one vmcnt value fits every turn.
+        {
+            const bool real = g + 3 < G;
+            const char* lsrc = src0 + (real ? (long)(g + 3) * stage_stride : 0L);
+            char* ldst = smem + slot * G_STAGE_BYTES;
+            g_mfma_loads(o1, active, acc, [&](int j) {
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(lsrc + soff[j]),
+                                                 (__attribute__((address_space(3))) void*)(ldst + (real ? doff[j] : (u32)(36 + (j & 3)) * 1024)), 16, 0, 0);
+            });
+        }
+        if (g + 1 < G) g_wait_lds(o0);
+        slot = slot1;
     }
-    if (!active) return;
-
+    // Epilogue.  Direct cells C[a,b,i,j]: a lane holds column n = (b, j), consecutive lanes consecutive j -- the atomics of
+    // one instruction fall into a few 72-byte runs.  Mirrored cells C[b,a,j,i] want consecutive lanes on consecutive i, i.e.
+    // lanes along m: the tile goes through a padded 32 x 33 LDS scratch (the ring is free once every wave has passed the
+    // barrier below) and comes back transposed.  With lanes along n the mirrored atomics touched 32 lines per instruction
+    // and an epilogue cost ~1.8 ms per launch (3.5-3.9 ms per chunk with the two K splits).
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the tail's dummy loads
+    __builtin_amdgcn_s_barrier();
+    if (!active || (dbg & 2)) return;                     // dbg 2: no epilogue (measurements only)
     const int NS = N * S;
     const long SS = (long)S * S;
+    float* scr = reinterpret_cast<float*>(smem) + w * (32 * 33);
+    const int lm = lane & 31, lh = lane >> 5;
 #pragma unroll
     for (int ta = 0; ta < 3; ++ta)
 #pragma unroll
-        for (int tb = 0; tb < 3; ++tb)
+        for (int tb = 0; tb < 3; ++tb) {
+            const int m0 = (bm * 3 + ta) * 32, n0 = (bn * 3 + tb) * 32;
+            {
+                const int n = n0 + lm;
+                const int b = n / S, j = n - b * S;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int v = (int)acc[ta][tb][r];
-                if (!v) continue;
-                const int m = (bm * 3 + ta) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                const int n = (bn * 3 + tb) * 32 + (lane & 31);
-                if (m >= NS || n >= NS) continue;
-                const int a = m / S, i = m - a * S, b = n / S, j = n - b * S;
-                if (a == b) continue;
-                atomicAdd(&counts[((long)a * N + b) * SS + i * S + j], v);
-                if (bm != bn) atomicAdd(&counts[((long)b * N + a) * SS + j * S + i], v);
+                for (int r = 0; r < 16; ++r) {
+                    const int v = (int)acc[ta][tb][r];
+                    const int m = m0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    const int a = m / S, i = m - a * S;
+                    if (v && m < NS && n < NS && a != b) atomicAdd(&counts[((long)a * N + b) * SS + i * S + j], v);
+                }
             }
+            if (bm != bn) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) scr[((r & 3) + 8 * (r >> 2) + 4 * lh) * 33 + lm] = acc[ta][tb][r];
+                __builtin_amdgcn_wave_barrier();
+                const int m = m0 + lm;
+                const int a = m / S, i = m - a * S;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int nl = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    const int v = (int)scr[lm * 33 + nl];
+                    const int n = n0 + nl;
+                    const int b = n / S, j = n - b * S;
+                    if (v && m < NS && n < NS && a != b) atomicAdd(&counts[((long)b * N + a) * SS + j * S + i], v);
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
 }
 
 int transpose_states(const char* X, int64_t R, int32_t N, int64_t ldx, int32_t S, char* XT, int64_t Rp, int shift, hipStream_t st);
 
 static long g_chunk_bins(long Rp) { return Rp < G_KC_MAX ? Rp : G_KC_MAX; }
 
+static int64_t g_fixed_bytes(long Rp, int N, int NQ) {
+    return align_up((int64_t)N * Rp + 64, 1024) + align_up((int64_t)NQ * (NQ + 1) * 4, 1024);
+}
+
+// smallest workspace the kernel can run with (a 16 K-bin chunk of the operand) -- less than that and the caller's
+// buffer goes to the build-in-kernel variant instead
+int64_t s3_gemm_ws_min_bytes(int64_t R, int N, int S) {
+    const long Rp = align_up(R, 512);
+    const int NSP = g_rows_padded(N * S), NT = NSP / 32, NQ = NSP / G_BN;
+    const long kc = Rp < G_KC_MIN ? Rp : G_KC_MIN;
+    return g_fixed_bytes(Rp, N, NQ) + (int64_t)NT * 1024 * (kc / 64);
+}
+
 // workspace: XT | task list | E4 chunk
 int64_t s3_gemm_ws_bytes(int64_t R, int N, int S) {
     const long Rp = align_up(R, 512);
     const int NSP = g_rows_padded(N * S), NT = NSP / 32, NQ = NSP / G_BN;
-    return align_up((int64_t)N * Rp + 64, 1024) + align_up((int64_t)NQ * (NQ + 1) * 4, 1024) + (int64_t)NT * 1024 * (g_chunk_bins(Rp) / 64);
+    return g_fixed_bytes(Rp, N, NQ) + (int64_t)NT * 1024 * (g_chunk_bins(Rp) / 64);
 }
 
-int hist_s3_gemm(const char* X, int64_t R, int32_t N, int64_t ldx, int32_t S, int32_t* counts, void* ws, hipStream_t st) {
+int hist_s3_gemm(const char* X, int64_t R, int32_t N, int64_t ldx, int32_t S, int32_t* counts, void* ws, int64_t ws_bytes,
+                 hipStream_t st) {
     const long Rp = align_up(R, 512);                  // whole stages; padded bins hold 31, which matches no row
     const int NS = N * S, NSP = g_rows_padded(NS), NT = NSP / 32, NQ = NSP / G_BN;
     const int ntasks = NQ * (NQ + 1);
@@ -216,7 +332,15 @@ int hist_s3_gemm(const char* X, int64_t R, int32_t N, int64_t ldx, int32_t S, in
                                     G_STAGES * G_STAGE_BYTES));
         attr_set = true;
     }
-    const long KC = g_chunk_bins(Rp);
+    // chunk = as many bins of the operand as the caller's workspace holds (every chunk ends in one epilogue of ~2 atomics
+    // per cell of counts, so fewer, longer chunks are better); EPG_S3_KC overrides for measurements
+    long KC = (ws_bytes - g_fixed_bytes(Rp, N, NQ)) / ((int64_t)NT * 1024) * 64 / 512 * 512;
+    static const int dbg_env = [] { const char* e = getenv("EPG_S3_DBG"); return e ? atoi(e) : 0; }();
+    static const long kc_env = [] { const char* e = getenv("EPG_S3_KC"); return e ? atol(e) / 512 * 512 : 0L; }();
+    if (kc_env > 0 && kc_env < KC) KC = kc_env;
+    if (KC > Rp) KC = Rp;
+    if (KC > (1L << 24) - 512) KC = (1L << 24) - 512;   // float32 accumulators hold exact integers
+    if (KC < 512) return fail(EPG_ERR_WORKSPACE, "hist_s3: workspace too small for the precomputed-operand kernel");
     for (long k0 = 0; k0 < Rp; k0 += KC) {
         const long kc = Rp - k0 < KC ? Rp - k0 : KC;   // multiple of 512
         const long nksteps = kc / 64, nstages = nksteps / G_KS;
@@ -224,15 +348,25 @@ int hist_s3_gemm(const char* X, int64_t R, int32_t N, int64_t ldx, int32_t S, in
         hipLaunchKernelGGL(k_s3_onehot_fp4, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, XT, Rp, N, S, NS, NT, k0, nksteps,
                            reinterpret_cast<uint4*>(E4));
         EPG_LAUNCH_CHECK("k_s3_onehot_fp4");
-        // few tasks (small N): split the chunk's stages over blockIdx.y so that every CU has work; int32 atomics combine
-        long splits = (2L * num_cus() + ntasks - 1) / ntasks;
+        // Split the chunk's stages over blockIdx.y: few tasks (small N) need it to give every CU work, and with one
+        // workgroup per CU the last round of a launch is only partly full -- 1640 tasks on 256 CUs are 6.4 rounds, paid as
+        // 7; in two halves 12.8, paid as 13.  int32 atomics combine the splits.
+        const long cus = num_cus();
+        long splits = (2L * cus + ntasks - 1) / ntasks, best = 0;
+        double best_waste = 1e9;
+        for (long sp = splits; sp <= splits + 3; ++sp) {
+            const double rounds = (double)ntasks * sp / cus;
+            const double waste = (double)((ntasks * sp + cus - 1) / cus) / rounds;
+            if (waste < best_waste - 0.01) { best_waste = waste; best = sp; }
+        }
+        splits = best;
         if (splits > nstages) splits = nstages;
         if (splits < 1) splits = 1;
         if (splits > 65535) splits = 65535;
         const long per = (nstages + splits - 1) / splits;
         const long nsplit = (nstages + per - 1) / per;
         hipLaunchKernelGGL(k_s3_syrk_fp4, dim3((unsigned)ntasks, (unsigned)nsplit), dim3(512), G_STAGES * G_STAGE_BYTES, st, E4, NT, nstages,
-                           per, tasks, ntasks, N, S, counts);
+                           per, tasks, ntasks, N, S, counts, dbg_env);
         EPG_LAUNCH_CHECK("k_s3_syrk_fp4");
     }
     return EPG_OK;
