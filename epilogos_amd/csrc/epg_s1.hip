@@ -159,12 +159,23 @@ __global__ __launch_bounds__(256) void k_score_s1(const char* __restrict__ X, lo
 // S1 score from cached histograms: 2*S bytes read + S*sizeof(OT) written per bin.  A lane handles 4 consecutive
 // elements (8 bytes of H in, 16/32 bytes out); consecutive lanes take consecutive quads so every load and store
 // instruction covers whole contiguous lines; 4 quads in flight per lane.
-template <typename OT>
-__global__ __launch_bounds__(256) void k_score_s1_from_hist(const u16* __restrict__ H, long total, int S,
-                                                             const OT* __restrict__ T, OT* __restrict__ out) {
+// LDS_T: the table is first copied into LDS (nent entries) and gathered from there.  From memory a 64-lane gather of four-byte
+// entries walks up to 64 lines through the L1 (one line per clock), four gathers per 16 bytes of output: the kernel ran at
+// the texture-address rate, 3.9 TB/s of its 108 B/bin; an LDS gather costs a few cycles.
+template <typename OT, bool LDS_T>
+__global__ __launch_bounds__(LDS_T ? 1024 : 256) void k_score_s1_from_hist(const u16* __restrict__ H, long total, int S,
+                                                                             const OT* __restrict__ Tg, int nent, OT* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) char smem_t[];
+    const OT* T = Tg;
+    if (LDS_T) {
+        OT* Ts = reinterpret_cast<OT*>(smem_t);
+        for (int e = threadIdx.x; e < nent; e += blockDim.x) Ts[e] = Tg[e];
+        __syncthreads();
+        T = Ts;
+    }
     const long nquads = total >> 2;
-    const long stride = (long)gridDim.x * 256;
-    long qd = (long)blockIdx.x * 256 + threadIdx.x;
+    const long stride = (long)gridDim.x * blockDim.x;
+    long qd = (long)blockIdx.x * blockDim.x + threadIdx.x;
     for (; qd + 3 * stride < nquads; qd += 4 * stride) {
         uint2 h[4];
 #pragma unroll
@@ -359,17 +370,40 @@ static int check_score_from_hist_args(const uint16_t* H, const double* out64, co
     return EPG_OK;
 }
 
-static int launch_score_s1_from_hist(const uint16_t* H, int64_t R, int32_t S, const double* T64, const float* T32, double* out64,
-                                     float* out32, hipStream_t st) {
-    const long total = (long)R * S;
-    long nb = (total / 4 + 1023) / 1024;
-    if (nb > num_cus() * 8L) nb = num_cus() * 8L;      // 8 blocks/CU measured best (16: +5 %); nt stores: no gain
-    if (nb < 1) nb = 1;
-    const int blocks = (int)nb;
-    if (out32) hipLaunchKernelGGL((k_score_s1_from_hist<float>), dim3(blocks), dim3(256), 0, st, H, total, S, T32, out32);
-    if (out64) hipLaunchKernelGGL((k_score_s1_from_hist<double>), dim3(blocks), dim3(256), 0, st, H, total, S, T64, out64);
+template <typename OT>
+static int launch_score_s1_from_hist_t(const uint16_t* H, long total, int32_t S, const OT* T, int nent, OT* out, hipStream_t st) {
+    const size_t tbytes = (size_t)nent * sizeof(OT);
+    static const bool no_lds = [] { const char* e = getenv("EPG_S1_SCORE"); return e && e[0] == 'g'; }();   // A/B: gather from memory
+    if (tbytes <= 150 * 1024 && !no_lds) {             // the table in LDS: blocks of 16 waves, as many per CU as tables fit (<= 2)
+        const int per_cu = tbytes <= 75 * 1024 ? 2 : 1;
+        long nb = (total / 4 + 4095) / 4096;
+        if (nb > (long)num_cus() * per_cu) nb = (long)num_cus() * per_cu;
+        if (nb < 1) nb = 1;
+        auto kern = k_score_s1_from_hist<OT, true>;
+        static bool attr_set = false;                  // one flag per OT instantiation
+        if (!attr_set) {
+            EPG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(kern, dim3((int)nb), dim3(1024), tbytes, st, H, total, S, T, nent, out);
+    } else {
+        long nb = (total / 4 + 1023) / 1024;
+        if (nb > num_cus() * 8L) nb = num_cus() * 8L;  // 8 blocks/CU measured best (16: +5 %); nt stores: no gain
+        if (nb < 1) nb = 1;
+        hipLaunchKernelGGL((k_score_s1_from_hist<OT, false>), dim3((int)nb), dim3(256), 0, st, H, total, S, T, nent, out);
+    }
     EPG_LAUNCH_CHECK("k_score_s1_from_hist");
     return EPG_OK;
+}
+
+static int launch_score_s1_from_hist(const uint16_t* H, int64_t R, int32_t N, int32_t S, const double* T64, const float* T32,
+                                     double* out64, float* out32, hipStream_t st) {
+    const long total = (long)R * S;
+    const int nent = (N + 1) * S;
+    int rc = EPG_OK;
+    if (out32) rc = launch_score_s1_from_hist_t<float>(H, total, S, T32, nent, out32, st);
+    if (!rc && out64) rc = launch_score_s1_from_hist_t<double>(H, total, S, T64, nent, out64, st);
+    return rc;
 }
 
 int score_s1_from_hist_impl(const uint16_t* H, int64_t R, int32_t N, int32_t S, const float* q, double* out64,
@@ -383,7 +417,7 @@ int score_s1_from_hist_impl(const uint16_t* H, int64_t R, int32_t N, int32_t S, 
     double* T64; float* T32;
     rc = build_s1_table(q, N, S, ws, &T64, &T32, st);
     if (rc) return rc;
-    return launch_score_s1_from_hist(H, R, S, T64, T32, out64, out32, st);
+    return launch_score_s1_from_hist(H, R, N, S, T64, T32, out64, out32, st);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -443,7 +477,7 @@ int combine_score_s1_impl(int64_t* counts, int32_t rezero, const uint16_t* H, in
         if (rc) return rc;
     }
     if (R == 0) return EPG_OK;
-    return launch_score_s1_from_hist(H, R, S, T64, T32, out64, out32, st);
+    return launch_score_s1_from_hist(H, R, N, S, T64, T32, out64, out32, st);
 }
 
 int score_s1_impl(const int8_t* X8, int64_t R, int32_t N, int64_t ldx, int32_t S, const float* q, double* out64,
