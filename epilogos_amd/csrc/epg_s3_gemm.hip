@@ -116,35 +116,29 @@ __device__ __forceinline__ void g_mfma(const GOps& o, bool active, v16f (&acc)[3
 // wave ~60-180 cycles of issue time (MI355X_MICROARCH.md, price list); five in a row right after the barrier, in both waves
 // of a SIMD at once, left the matrix pipe idle for that long (1M bins: 55.6 ms; interleaved: see DESIGN.md).  sched_barrier
 // pins the order the optimiser would otherwise restore.
-template <typename Load>
+// The same with NJ of the wave's LDS-DMA loads (j = J0 ..) spread between the MFMAs.
+template <int J0, int NJ, typename Load>
 __device__ __forceinline__ void g_mfma_loads(const GOps& o, bool active, v16f (&acc)[3][3], Load&& load) {
+    static_assert(NJ == 2 || NJ == 3, "two or three loads per batch");
     if (!active) {
 #pragma unroll
-        for (int j = 0; j < G_LOADS; ++j) load(j);
+        for (int j = 0; j < NJ; ++j) load(J0 + j);
         return;
     }
     __builtin_amdgcn_s_setprio(1);
     G_MFMA(0, 0); G_MFMA(0, 1);
     __builtin_amdgcn_sched_barrier(0);
-    load(0);
+    load(J0);
     __builtin_amdgcn_sched_barrier(0);
-    G_MFMA(0, 2); G_MFMA(1, 0);
+    G_MFMA(0, 2); G_MFMA(1, 0); G_MFMA(1, 1);
     __builtin_amdgcn_sched_barrier(0);
-    load(1);
+    load(J0 + 1);
     __builtin_amdgcn_sched_barrier(0);
-    G_MFMA(1, 1); G_MFMA(1, 2);
+    G_MFMA(1, 2); G_MFMA(2, 0);
     __builtin_amdgcn_sched_barrier(0);
-    load(2);
+    if (NJ == 3) load(J0 + 2);
     __builtin_amdgcn_sched_barrier(0);
-    G_MFMA(2, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    load(3);
-    __builtin_amdgcn_sched_barrier(0);
-    G_MFMA(2, 1);
-    __builtin_amdgcn_sched_barrier(0);
-    load(4);
-    __builtin_amdgcn_sched_barrier(0);
-    G_MFMA(2, 2);
+    G_MFMA(2, 1); G_MFMA(2, 2);
     __builtin_amdgcn_s_setprio(0);
 }
 
@@ -206,21 +200,37 @@ __global__ __launch_bounds__(512, 2) void k_s3_syrk_fp4(const char* __restrict__
     // standing between the two waves of a SIMD after every barrier (first version: 2400 cycles per stage for 1584 of MFMA).
     issue(0, 0);
     issue(G > 1 ? 1 : 0, 1);                               // a chunk shorter than the pipeline refetches stage 0: never read
-    issue(G > 2 ? 2 : 0, 2);
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * G_LOADS) : "memory");
+#pragma unroll
+    for (int j = 2; j < G_LOADS; ++j) issue1(G > 2 ? 2 : 0, 2, j);     // stage 2's first two loads go out in the loop's first turn
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * G_LOADS - 2) : "memory");
     __builtin_amdgcn_s_barrier();
     GOps o0, o1;
     g_read<0>(o0, baseA, baseB);
     g_wait_lds(o0);
-    int slot = 0;                                          // ring slot of stage g (g mod 3 without the division)
+    // A wave's five DMA loads of a stage go out between MFMAs, two in one batch and three in the next, never in a row:
+    // issuing an LDS-DMA load holds a wave up for 60-180 cycles, and the two waves of a SIMD reach the same point together.
+    // Stage g + 2 is fetched into the slot of stage g - 1: loads j = 2, 3, 4 between the MFMAs of k-step 1 of stage g - 1
+    // (after that turn's barrier: the slot is free) and j = 0, 1 between those of k-step 0 of stage g.  Issue order per wave:
+    // ... s(g+1){2,3,4} s(g+1){0,1} s(g+2){2,3,4} s(g+2){0,1} | wait for stage g + 1 = vmcnt(5).  Past the last stage the
+    // same instructions fetch stage 0 into the ring's scrap slots, so the loop has no load-dependent control flow.
+    auto loads_for = [&](int gs, int into_slot) {
+        const bool real = gs < G;
+        const char* lsrc = src0 + (real ? (long)gs * stage_stride : 0L);
+        char* ldst = smem + into_slot * G_STAGE_BYTES;
+        return [=, &soff, &doff](int j) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(lsrc + soff[j]),
+                                             (__attribute__((address_space(3))) void*)(ldst + (real ? doff[j] : (u32)(36 + (j & 3)) * 1024)), 16, 0, 0);
+        };
+    };
+    int slot = 0, slot_prev = G_STAGES - 1;                // ring slots of stage g and g - 1 (no division in the loop)
     for (int g = 0; g < G; ++g) {
         const u32 so = (u32)slot * G_STAGE_BYTES;
         const int slot1 = slot == G_STAGES - 1 ? 0 : slot + 1;
         g_read<1>(o1, baseA + so, baseB + so);
-        g_mfma(o0, active, acc);
+        g_mfma_loads<0, 2>(o0, active, acc, loads_for(g + 2, slot_prev));
         g_wait_lds(o1);
         if (g + 1 < G) {
-            // stage g + 1: this wave's loads have landed (those of stage g + 2 -- real or, at the tail, dummies -- stay in
+            // stage g + 1: this wave's loads have landed (the five of stage g + 2 -- real or, at the tail, dummies -- stay in
             // flight); after the barrier everybody's.  Every wave that reaches the barrier holds its last operands of stage g
             // in registers: the slot is free.
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G_LOADS) : "memory");
@@ -228,28 +238,18 @@ __global__ __launch_bounds__(512, 2) void k_s3_syrk_fp4(const char* __restrict__
             const u32 sn = (u32)slot1 * G_STAGE_BYTES;
             g_read<0>(o0, baseA + sn, baseB + sn);
         }
-        // stage g + 3 takes over the slot stage g has just left; its loads go out between this batch's MFMAs.  Past the last
-        // stage the same instructions fetch stage 0 into the ring's scrap slots, so that the loop has no load-dependent
-        // control flow (the optimiser gathers conditional loads in front of the MFMAs) and one vmcnt value fits every turn.
-        {
-            const bool real = g + 3 < G;
-            const char* lsrc = src0 + (real ? (long)(g + 3) * stage_stride : 0L);
-            char* ldst = smem + slot * G_STAGE_BYTES;
-            g_mfma_loads(o1, active, acc, [&](int j) {
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(lsrc + soff[j]),
-                                                 (__attribute__((address_space(3))) void*)(ldst + (real ? doff[j] : (u32)(36 + (j & 3)) * 1024)), 16, 0, 0);
-            });
-        }
+        g_mfma_loads<2, 3>(o1, active, acc, loads_for(g + 3, slot));
         if (g + 1 < G) g_wait_lds(o0);
+        slot_prev = slot;
         slot = slot1;
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the tail's dummy loads
+    __builtin_amdgcn_s_barrier();
     // Epilogue.  Direct cells C[a,b,i,j]: a lane holds column n = (b, j), consecutive lanes consecutive j -- the atomics of
     // one instruction fall into a few 72-byte runs.  Mirrored cells C[b,a,j,i] want consecutive lanes on consecutive i, i.e.
     // lanes along m: the tile goes through a padded 32 x 33 LDS scratch (the ring is free once every wave has passed the
     // barrier below) and comes back transposed.  With lanes along n the mirrored atomics touched 32 lines per instruction
     // and an epilogue cost ~1.8 ms per launch (3.5-3.9 ms per chunk with the two K splits).
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the tail's dummy loads
-    __builtin_amdgcn_s_barrier();
     if (!active || (dbg & 2)) return;                     // dbg 2: no epilogue (measurements only)
     const int NS = N * S;
     const long SS = (long)S * S;

@@ -87,7 +87,10 @@ def maxMean(chrom, start, end, score, roiWidth, maxRegions, _first_candidates=No
             break
         m_try = min(n, 8 * m_try)
     chosen = np.array(sorted(chosen), dtype=np.int64)        # back to genomic order, then best first (stable)
-    final = chosen[np.lexsort((-sc[chosen], -rmean[chosen], -rmax[chosen]))]    # helpers.py:272: by max, mean, centre score
+    # helpers.py:272 sorts by [RollingMax, RollingMean, Score], but by then Filter.filter has overwritten Score with RollingMax
+    # (filter_regions.py:215-216, aggregation "max"): the third key repeats the first, windows that tie on max and mean stay
+    # in genomic order (pinned by tests/golden/roi.npz roi_tie_*; sorting by the centre score instead does NOT match)
+    final = chosen[np.lexsort((-rmean[chosen], -rmax[chosen]))]
     return (np.asarray(chrom)[orig[final]], w_start[final], w_end[final], rmax[final], orig[final])
 
 

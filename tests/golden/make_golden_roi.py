@@ -46,6 +46,20 @@ def main():
     np.save(d / "exp_freq_t.npy", g["s1_exp"])
     roi.main(d, state_info, "t", d / "exp_freq_t.npy", 50, False)
     out["roi_single_w50"] = np.frombuffer((d / "regionsOfInterest_t.txt").read_bytes(), dtype=np.uint8)
+    # ties: a handful of distinct scores, so that many windows share rolling max AND rolling mean and the reference's third
+    # sort key (the centre bin's score, helpers.py:272) and pandas' stable order decide
+    rng = np.random.default_rng(11)
+    tie = np.zeros((3000, S), dtype=np.float32)
+    tie[:, 4] = rng.integers(0, 4, size=3000)
+    tie[:, 9] = rng.integers(0, 2, size=3000) * 0.5
+    out["tie_scores"] = tie
+    for width in (7, 10):
+        d = Path(tempfile.mkdtemp(prefix="epg_roi_"))
+        loc = np.array([["chr2", 200 * i, 200 * i + 200] for i in range(tie.shape[0])], dtype=object)
+        np.savez_compressed(d / "temp_scores_t_chr2.npz", chrName=np.array(["chr2"]), scoreArr=tie, locationArr=loc)
+        np.save(d / "exp_freq_t.npy", g["s1_exp"])
+        roi.main(d, state_info, "t", d / "exp_freq_t.npy", width, False)
+        out["roi_tie_w%d" % width] = np.frombuffer((d / "regionsOfInterest_t.txt").read_bytes(), dtype=np.uint8)
     out["state_names"] = np.array(__import__("pandas").read_table(state_info, header=0, sep="\t")["short_name"].values, dtype="U32")
     np.savez_compressed(HERE / "roi.npz", **out)
     print({k: getattr(v, "shape", None) for k, v in out.items()})
