@@ -138,6 +138,173 @@ __global__ __launch_bounds__(256) void k_s2_hist_from_binhist(const u16* __restr
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// The same counts, every WAVE on its own (round 2).  PMC of the block-wide kernel above: SQ_WAIT_ANY 70 % of the wave
+// cycles, VALU 9 % -- three block barriers per 128 bins with little work between them.  Here a wave owns tiles of 64 bins:
+// it fetches a tile's 128*S bytes one tile ahead with whole-line loads, parks them in its own LDS slot, re-packs them as
+// bin PAIRS per state (word (i, k) = counts of state i in bins 2k and 2k+1, row stride 33 words) and contracts them with
+// v_dot2_u32_u16 in REGISTER TILES: a lane owns a 3 x 3 block of state pairs (groups gi <= gj of three states) and every
+// third pair-word k, so six LDS words feed nine dot products (the one-pair-per-thread form read two words per product).
+// Diagonal blocks also sum their three states' counts (the -sum h_i of the diagonal).  Only wave-level barriers.
+// Exact: a lane's partial sums are < 2^32 while counts are < 4096 (11 words x 2 products); a tile holding a larger count
+// takes a plain u64 path.  H2: optional second histogram array added bin by bin (paired mode, see above).
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int S2W_LD = 33;                   // pair-matrix row stride in words
+// S2W_MAXPASS = ceil(#block roles / 64): 1 for S <= 30 (55 roles), 2 for S = 31 (66)
+template <int S2W_MAXPASS>
+__global__ __launch_bounds__(256, S2W_MAXPASS == 1 ? 4 : 2) void k_s2_hist_wave(const u16* __restrict__ H, const u16* __restrict__ H2, long R, int S,
+                                                       u64* __restrict__ counts) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int ng = (S + 2) / 3, SP = 3 * ng;                 // state groups; rows of the pair matrix (padded rows stay zero)
+    const int nroles = ng * (ng + 1) / 2;
+    const int nslice = nroles <= 64 ? 64 / nroles : 1;       // lanes per role, each taking every nslice-th pair word
+    const int raw_bytes = 64 * S * 2;
+    const int wave_bytes = ((raw_bytes + 15) & ~15) + SP * S2W_LD * 4;
+    char* s_raw = smem + (size_t)wave * wave_bytes;
+    u32* s_p = reinterpret_cast<u32*>(s_raw + ((raw_bytes + 15) & ~15));
+    for (int e = lane; e < SP * S2W_LD; e += 64) s_p[e] = 0;
+    // block roles of this lane (one per pass)
+    int gi[S2W_MAXPASS], gj[S2W_MAXPASS], kq[S2W_MAXPASS];
+    u64 acc[S2W_MAXPASS][9], rs[S2W_MAXPASS][3];
+#pragma unroll
+    for (int p = 0; p < S2W_MAXPASS; ++p) {
+        const int role = nroles <= 64 ? (p == 0 && lane < nroles * nslice ? lane / nslice : -1) : lane + 64 * p;
+        gi[p] = -1; gj[p] = 0; kq[p] = nroles <= 64 ? lane % nslice : 0;
+        if (role >= 0 && role < nroles) {
+            int t = role, i = 0;
+            while (t >= ng - i) { t -= ng - i; ++i; }
+            gi[p] = i; gj[p] = i + t;
+        }
+#pragma unroll
+        for (int c = 0; c < 9; ++c) acc[p][c] = 0;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) rs[p][c] = 0;
+    }
+    const int nchunks = (raw_bytes + 15) >> 4;               // 16-byte pieces of a tile: at most three per lane (S <= 31: 248)
+    const long total_bytes = R * S * 2;
+    const long ntiles = (R + 63) >> 6;
+    const long stride = (long)gridDim.x * 4;
+    auto fetch = [&](long tile, int c) -> uint4 {
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (tile >= ntiles || c >= nchunks) return v;
+        const long off = tile * raw_bytes + 16L * c;
+        if (off + 16 <= total_bytes && 16 * c + 16 <= raw_bytes) {
+            v = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(H) + off);
+            if (H2) {
+                const uint4 w = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(H2) + off);
+                v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
+            }
+            return v;
+        }
+        u16 t[8] = {0, 0, 0, 0, 0, 0, 0, 0};                   // the piece at the end of the tile / of H
+        for (int k = 0; k < 8; ++k)
+            if (off + 2 * k < total_bytes && 16 * c + 2 * k < raw_bytes) {
+                t[k] = *reinterpret_cast<const u16*>(reinterpret_cast<const char*>(H) + off + 2 * k);
+                if (H2) t[k] = (u16)(t[k] + *reinterpret_cast<const u16*>(reinterpret_cast<const char*>(H2) + off + 2 * k));
+            }
+        return make_uint4(t[0] | (u32)t[1] << 16, t[2] | (u32)t[3] << 16, t[4] | (u32)t[5] << 16, t[6] | (u32)t[7] << 16);
+    };
+    long tile = (long)blockIdx.x * 4 + wave;
+    uint4 pre[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) pre[c] = fetch(tile, lane + 64 * c);
+    for (; tile < ntiles; tile += stride) {
+        __builtin_amdgcn_wave_barrier();
+        u32 m = 0;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            if (lane + 64 * c < nchunks) *reinterpret_cast<uint4*>(s_raw + 16 * (lane + 64 * c)) = pre[c];
+            m |= pre[c].x | pre[c].y | pre[c].z | pre[c].w;
+        }
+        const bool big = __any((m & 0xF000F000u) != 0);       // a count >= 4096 somewhere in the tile
+#pragma unroll
+        for (int c = 0; c < 4; ++c) pre[c] = fetch(tile + stride, lane + 64 * c);   // lands while this tile is contracted
+        __builtin_amdgcn_wave_barrier();
+        const u16* raw = reinterpret_cast<const u16*>(s_raw);
+        if (!big) {
+            for (int e = lane; e < S * 32; e += 64) {
+                const int i = e >> 5, k = e & 31;
+                s_p[i * S2W_LD + k] = (u32)raw[(2 * k) * S + i] | ((u32)raw[(2 * k + 1) * S + i] << 16);
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int p = 0; p < S2W_MAXPASS; ++p) {
+                if (gi[p] < 0) continue;
+                const u32* pi = s_p + 3 * gi[p] * S2W_LD;
+                const u32* pj = s_p + 3 * gj[p] * S2W_LD;
+                u32 part[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, ps[3] = {0, 0, 0};
+                const bool diag = gi[p] == gj[p];
+                for (int k = kq[p]; k < 32; k += nslice) {
+                    const u32 a0 = pi[k], a1 = pi[S2W_LD + k], a2 = pi[2 * S2W_LD + k];
+                    const u32 b0 = pj[k], b1 = pj[S2W_LD + k], b2 = pj[2 * S2W_LD + k];
+                    const u32 av[3] = {a0, a1, a2}, bv[3] = {b0, b1, b2};
+#pragma unroll
+                    for (int t = 0; t < 3; ++t)
+#pragma unroll
+                        for (int u = 0; u < 3; ++u)
+                            part[3 * t + u] = __builtin_amdgcn_udot2(__builtin_bit_cast(v2u16, av[t]), __builtin_bit_cast(v2u16, bv[u]), part[3 * t + u], false);
+                    if (diag) {
+#pragma unroll
+                        for (int t = 0; t < 3; ++t)
+                            ps[t] = __builtin_amdgcn_udot2(__builtin_bit_cast(v2u16, av[t]), __builtin_bit_cast(v2u16, 0x00010001u), ps[t], false);
+                    }
+                }
+#pragma unroll
+                for (int c = 0; c < 9; ++c) acc[p][c] += part[c];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) rs[p][c] += ps[c];
+            }
+        } else {                                               // counts >= 4096: 64-bit products straight from the raw tile
+            const long r0 = tile * 64;
+            const int rows = (int)(R - r0 < 64 ? R - r0 : 64);
+#pragma unroll
+            for (int p = 0; p < S2W_MAXPASS; ++p) {
+                if (gi[p] < 0) continue;
+                for (int r = kq[p]; r < rows; r += nslice) {
+#pragma unroll
+                    for (int t = 0; t < 3; ++t) {
+                        const int i = 3 * gi[p] + t;
+                        const u64 hi = i < S ? raw[r * S + i] : 0;
+#pragma unroll
+                        for (int u = 0; u < 3; ++u) {
+                            const int j = 3 * gj[p] + u;
+                            acc[p][3 * t + u] += hi * (u64)(j < S ? raw[r * S + j] : 0);
+                        }
+                        if (gi[p] == gj[p]) rs[p][t] += hi;
+                    }
+                }
+            }
+        }
+    }
+    // C[i,j] = sum h_i h_j (both orders);  C[i,i] = sum h_i^2 - sum h_i.  The block's lanes first meet in an LDS copy of C
+    // (the staging memory is free now), then one global atomic per cell and block: with every lane adding its nine sums
+    // straight to global memory 7.7 M atomics queued up on 324 addresses and the kernel took 3.9 ms.
+    __syncthreads();
+    u64* s_c = reinterpret_cast<u64*>(smem);
+    for (int e = threadIdx.x; e < S * S; e += 256) s_c[e] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < S2W_MAXPASS; ++p) {
+        if (gi[p] < 0) continue;
+        const bool diag = gi[p] == gj[p];
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+                const int i = 3 * gi[p] + t, j = 3 * gj[p] + u;
+                u64 v = acc[p][3 * t + u];
+                if (diag && t == u) v -= rs[p][t];             // two's complement
+                if (i >= S || j >= S || !v) continue;
+                atomicAdd(&s_c[i * S + j], v);
+                if (!diag) atomicAdd(&s_c[j * S + i], v);
+            }
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < S * S; e += 256)
+        if (s_c[e]) atomicAdd(&counts[e], s_c[e]);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // S2 score tables: LH[c] = log2(c) for c = 0..maxc (LH[0] = 0, never used);
 // LPQ[i,j] = log2(perms * q[i,j]) or +inf-marker where q == 0.
 // log2(p/q) with p = num/perms is evaluated as LH[a] + LH[b] - LPQ[i,j], num = a*b (DESIGN.md, S2 numerics).
@@ -532,11 +699,24 @@ int hist_s2_from_binhist_impl(const uint16_t* H, const uint16_t* H2, int64_t R, 
     if (!H || !counts) return fail(EPG_ERR_INVALID_ARG, "hist_s2: NULL argument");
     const long nb = (R + S2H_BATCH - 1) / S2H_BATCH;
     if ((reinterpret_cast<uintptr_t>(H) & 15) || (reinterpret_cast<uintptr_t>(H2) & 15)) return fail(EPG_ERR_INVALID_ARG, "hist_s2: H must be 16-byte aligned");
-    long blocks = nb < num_cus() * 8L ? nb : num_cus() * 8L;
-    const size_t shmem = (((size_t)S2H_BATCH * S * 2 + 15) & ~(size_t)15) + (size_t)S * S2H_LD * 4;
-    hipLaunchKernelGGL(k_s2_hist_from_binhist, dim3((int)blocks), dim3(256), shmem, st, H, H2, (long)R, S,
-                       reinterpret_cast<u64*>(counts));
-    EPG_LAUNCH_CHECK("k_s2_hist_from_binhist");
+    static const bool use_block = [] { const char* e = getenv("EPG_S2_HIST"); return e && e[0] == 'b'; }();   // A/B: round-1 kernel
+    if (use_block) {
+        long blocks = nb < num_cus() * 8L ? nb : num_cus() * 8L;
+        const size_t shmem = (((size_t)S2H_BATCH * S * 2 + 15) & ~(size_t)15) + (size_t)S * S2H_LD * 4;
+        hipLaunchKernelGGL(k_s2_hist_from_binhist, dim3((int)blocks), dim3(256), shmem, st, H, H2, (long)R, S,
+                           reinterpret_cast<u64*>(counts));
+        EPG_LAUNCH_CHECK("k_s2_hist_from_binhist");
+        return EPG_OK;
+    }
+    const long ntiles = (R + 63) / 64;
+    long blocks = (ntiles + 3) / 4;
+    if (blocks > num_cus() * 8L) blocks = num_cus() * 8L;
+    const int SP = 3 * ((S + 2) / 3);
+    size_t shmem = 4 * ((((size_t)64 * S * 2 + 15) & ~(size_t)15) + (size_t)SP * S2W_LD * 4);
+    if (shmem < (size_t)S * S * 8) shmem = (size_t)S * S * 8;
+    if (S <= 30) hipLaunchKernelGGL(k_s2_hist_wave<1>, dim3((int)blocks), dim3(256), shmem, st, H, H2, (long)R, S, reinterpret_cast<u64*>(counts));
+    else hipLaunchKernelGGL(k_s2_hist_wave<2>, dim3((int)blocks), dim3(256), shmem, st, H, H2, (long)R, S, reinterpret_cast<u64*>(counts));
+    EPG_LAUNCH_CHECK("k_s2_hist_wave");
     return EPG_OK;
 }
 

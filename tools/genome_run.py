@@ -34,6 +34,7 @@ ap.add_argument("--saliency", type=int, default=1)
 ap.add_argument("--biosamples", type=int, default=833)
 ap.add_argument("--keep", action="store_true")
 ap.add_argument("--skip-warm", action="store_true")
+ap.add_argument("--also", default="", help="comma list of further saliencies to run from the warm cache, e.g. 2,3")
 a = ap.parse_args()
 N, S = a.biosamples, 18
 base = Path(a.dir or (Path("/dev/shm") if Path("/dev/shm").is_dir() else Path(os.environ.get("TMPDIR", "/tmp"))) / "epg_genome")
@@ -70,9 +71,9 @@ WRAP = ("import resource, subprocess, sys, json, time; t = time.time(); r = subp
         "'peak_rss_gb': resource.getrusage(resource.RUSAGE_CHILDREN).ru_maxrss / 1048576.0})); sys.exit(r.returncode)")
 
 
-def run(label, out):
+def run(label, out, saliency=None):
     cmd = [sys.executable, "-c", WRAP, sys.executable, "-m", "epilogos_amd.run", "-l", "-i", str(ind), "-j", str(meta), "-o", str(out),
-           "-s", str(a.saliency), "--cache-dir", str(cache)]
+           "-s", str(saliency or a.saliency), "--cache-dir", str(cache)]
     r = subprocess.run(cmd, cwd=str(ROOT), capture_output=True, text=True, env=dict(os.environ, EPILOGOS_TIMING="1"))
     info = [json.loads(l[2:]) for l in r.stdout.splitlines() if l.startswith("@@")]
     print("== %s" % label)
@@ -89,6 +90,14 @@ def run(label, out):
 out1, out2 = base / "out_cold", base / "out_warm"
 cold = run("cold (inflate + parse text, fills the cache)", out1)
 warm = None if a.skip_warm else run("warm (memory-mapped int8 cache)", out2)
+
+for sal in [int(v) for v in a.also.split(",") if v]:
+    o = base / ("out_s%d" % sal)
+    run("saliency %d from the warm cache" % sal, o, saliency=sal)
+    for name, _ in HG19:
+        with gzip.open(o / ("scores_in_s%d_matrix_%s.txt.gz" % (sal, name)), "rb") as fh:
+            n = sum(chunk.count(b"\n") for chunk in iter(lambda: fh.read(1 << 24), b""))
+        assert n == rows[name], (sal, name, n, rows[name])
 
 # ---- checks: every chromosome's output has its number of lines; chr21 equals the engine's scores of the cached matrix
 tag = "in_s%d" % a.saliency
