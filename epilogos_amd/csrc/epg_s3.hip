@@ -197,20 +197,14 @@ __device__ __forceinline__ void s3_phase(const char* __restrict__ XTs, long Rp, 
 
 template <int STG>
 __global__ __launch_bounds__(S3S_THREADS, STG <= 6 ? 3 : 2) void k_s3_score(const char* __restrict__ XT4, long Rp, long R, int N, int Nceil, int S,
-                                                              const float* __restrict__ T, double* __restrict__ out64, int PB, int PS,
-                                                              int nbp, long nslices) {
+                                                              const float* __restrict__ T, double* __restrict__ out64) {
     __shared__ float tab[2][S3S_ACH][32][S3S_LD];  // [phase][a][31 - x_b][x_a], zero outside S x S
     char* tabc = reinterpret_cast<char*>(&tab[0][0][0][0]);
-    // Blocks in dispatch order fill patches of PB biosamples x PS bin slices (b fastest inside a patch): the ~768 blocks the
-    // chip runs at a time then share PS table columns T[:, b] (1.08 MB each) 1 : PS and PB state-matrix slices (3.4 MB each)
-    // 1 : PB, and both sets fit the 256 MB Infinity Cache.  With b running over ALL biosamples of one slice (round 1) every
-    // block streamed its own table column from HBM: PMC 360 GB of fabric reads per 1 M bins, 46 % of the wave time waiting.
-    const long patch = blockIdx.x / (PB * PS);
-    const int within = (int)(blockIdx.x - patch * (PB * PS));
-    const int b = (int)(patch % nbp) * PB + within % PB;
-    const long slice = (patch / nbp) * PS + within / PB;
-    if (b >= N || slice >= nslices) return;
-    const long slice0 = slice * S3S_SLICE;
+    // b fastest: the N blocks of a slice share its XT rows in L2.  (Round 2 tried patches of PB biosamples x PS slices so that
+    // the resident blocks also share table columns -- PMC shows 360 GB of fabric reads per 1 M bins --: 96 x 8 and 64 x 12
+    // run the same 100 ms, 16 x 48 and 8 x 96 are slower; the kernel is bound by the LDS gathers and their VALU, not by memory.)
+    const int b = blockIdx.x % N;
+    const long slice0 = (long)(blockIdx.x / N) * S3S_SLICE;
     const long r0 = slice0 + (long)threadIdx.x * S3S_BPT;
     const char* XTs = XT4 + slice0;               // wave-uniform base of this slice
     const u32 toff = (u32)((r0 < Rp ? r0 : Rp - 16) - slice0);   // threads past the end gather from valid memory, write nothing
@@ -359,18 +353,10 @@ int score_s3_impl(const int8_t* X8, int64_t R, int32_t N, int64_t ldx, int32_t S
     if (nslices * N > 0x7fffffffL) return fail(EPG_ERR_UNSUPPORTED, "score_s3: R*N too large for one call");
     // staging elements per thread: ceil(ACH * S * S / THREADS)
     const int stg = (S3S_ACH * S * S + S3S_THREADS - 1) / S3S_THREADS;
-    // patch shape: EPG_S3_PATCH=PBxPS overrides the default 32 x 24 (= the 768 blocks 256 CUs hold at three blocks each)
-    static const int patch_env = [] { const char* e = getenv("EPG_S3_PATCH"); int pb = 0, ps = 0; return e && sscanf(e, "%dx%d", &pb, &ps) == 2 && pb > 0 && ps > 0 ? pb * 65536 + ps : 0; }();
-    int PB = patch_env ? patch_env >> 16 : 32, PS = patch_env ? patch_env & 0xffff : 24;
-    if (PB > N) PB = N;
-    if (PS > nslices) PS = (int)nslices;
-    const int nbp = (N + PB - 1) / PB;
-    const long nsp = (nslices + PS - 1) / PS;
-    if ((long)nbp * nsp * PB * PS > 0x7fffffffL) return fail(EPG_ERR_UNSUPPORTED, "score_s3: R*N too large for one call");
-    const dim3 grid((unsigned)((long)nbp * nsp * PB * PS)), block(S3S_THREADS);
-    if (stg <= 6) hipLaunchKernelGGL(k_s3_score<6>, grid, block, 0, st, XT, Rp, (long)R, N, Nceil, S, T, acc, PB, PS, nbp, nslices);
-    else if (stg <= 10) hipLaunchKernelGGL(k_s3_score<10>, grid, block, 0, st, XT, Rp, (long)R, N, Nceil, S, T, acc, PB, PS, nbp, nslices);
-    else hipLaunchKernelGGL(k_s3_score<16>, grid, block, 0, st, XT, Rp, (long)R, N, Nceil, S, T, acc, PB, PS, nbp, nslices);
+    const dim3 grid((unsigned)(nslices * N)), block(S3S_THREADS);
+    if (stg <= 6) hipLaunchKernelGGL(k_s3_score<6>, grid, block, 0, st, XT, Rp, (long)R, N, Nceil, S, T, acc);
+    else if (stg <= 10) hipLaunchKernelGGL(k_s3_score<10>, grid, block, 0, st, XT, Rp, (long)R, N, Nceil, S, T, acc);
+    else hipLaunchKernelGGL(k_s3_score<16>, grid, block, 0, st, XT, Rp, (long)R, N, Nceil, S, T, acc);
     EPG_LAUNCH_CHECK("k_s3_score");
     {
         long blocks = ((long)R * S + 255) / 256;
