@@ -46,6 +46,8 @@ PROTOTYPES = {
     "epg_pair_metrics": (C.c_int, [_p, _i64, _i32, _i32, _p, _p, _p]),
     "epg_quiescent": (C.c_int, [_p, _i32, _i64, _p, _i32, _i64, _i64, _i32, _p, _p]),
     "epg_null_hist": (C.c_int, [_p, _i32, _i64, _p, _i32, _i64, _i64, _i32, _i32, _i32, _u64, _i64, _p, _p, _p]),
+    "epg_quiescent_from_binhist": (C.c_int, [_p, _p, _i64, _i32, _i32, _i32, _i32, _p, _p]),
+    "epg_null_hist_from_binhist": (C.c_int, [_p, _p, _i64, _i32, _i32, _i32, _i32, _u64, _i64, _p, _p, _p]),
 }
 
 _lib = None

@@ -277,7 +277,8 @@ class _HipPairedSession(_HipSession):
         XA, XB, HA, HB, row0 = self.parts[pid]
         self.parts[pid] = None
         ga, gb = (NA, NB) if self.groupSize == -1 else (self.groupSize, self.groupSize)
-        HnA, HnB = eng.null_hist(XA, NA, XB, NB, S, ga, gb, self.seed, row0)
+        # the null groups' histograms straight from the real groups' (multivariate hypergeometric, no pass over X)
+        HnA, HnB = eng.null_hist_from_binhist(HA, HB, NA + NB, S, ga, gb, self.seed, row0)
         if self.sal == 1:
             sA, _ = eng.score_s1_from_binhist(HA, NA, S, q)
             sB, _ = eng.score_s1_from_binhist(HB, NB, S, q)
@@ -291,7 +292,7 @@ class _HipPairedSession(_HipSession):
         delta, _ = eng.pair_finish(sA, sB, want_dist=False)
         _, null = eng.pair_finish(nA, nB)
         rdist, mdiff = eng.pair_metrics(delta, roundtrip=True)     # what STEP 4 would recompute from the text
-        quies = eng.quiescent(XA, NA, XB, NB, self.qstate)
+        quies = eng.quiescent_from_binhist(HA, NA, HB, NB, S, self.qstate)
         return {"delta": delta.cpu().numpy(), "null": null.cpu().numpy(), "quies": quies.cpu().numpy().astype(bool),
                 "rdist": rdist.cpu().numpy(), "mdiff": mdiff.cpu().numpy()}
 

@@ -47,6 +47,11 @@ int score_s3_impl(const int8_t*, int64_t, int32_t, int64_t, int32_t, const float
 int null_hist_impl(const int8_t*, int32_t, int64_t, const int8_t*, int32_t, int64_t, int64_t, int32_t, int32_t, int32_t,
                    uint64_t, int64_t, uint16_t*, uint16_t*, hipStream_t);
 
+int null_hist_from_binhist_impl(const uint16_t*, const uint16_t*, int64_t, int32_t, int32_t, int32_t, int32_t, uint64_t, int64_t, uint16_t*,
+                                uint16_t*, hipStream_t);
+
+int quiescent_from_binhist_impl(const uint16_t*, const uint16_t*, int64_t, int32_t, int32_t, int32_t, int32_t, uint8_t*, hipStream_t);
+
 }  // namespace epg
 
 using namespace epg;
@@ -170,6 +175,16 @@ int epg_quiescent(const int8_t* XA, int32_t NA, int64_t ldxa, const int8_t* XB, 
 int epg_null_hist(const int8_t* XA, int32_t NA, int64_t ldxa, const int8_t* XB, int32_t NB, int64_t ldxb, int64_t R, int32_t S,
                   int32_t ga, int32_t gb, uint64_t seed, int64_t row0, uint16_t* HA, uint16_t* HB, void* stream) {
     return null_hist_impl(XA, NA, ldxa, XB, NB, ldxb, R, S, ga, gb, seed, row0, HA, HB, (hipStream_t)stream);
+}
+
+int epg_null_hist_from_binhist(const uint16_t* HA, const uint16_t* HB, int64_t R, int32_t S, int32_t n_cols, int32_t ga, int32_t gb,
+                               uint64_t seed, int64_t row0, uint16_t* OA, uint16_t* OB, void* stream) {
+    return null_hist_from_binhist_impl(HA, HB, R, S, n_cols, ga, gb, seed, row0, OA, OB, (hipStream_t)stream);
+}
+
+int epg_quiescent_from_binhist(const uint16_t* HA, const uint16_t* HB, int64_t R, int32_t S, int32_t NA, int32_t NB, int32_t qstate,
+                               uint8_t* mask, void* stream) {
+    return quiescent_from_binhist_impl(HA, HB, R, S, NA, NB, qstate, mask, (hipStream_t)stream);
 }
 
 }  // extern "C"

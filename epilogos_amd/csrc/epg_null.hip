@@ -119,7 +119,127 @@ __global__ __launch_bounds__(256) void k_null_hist(const char* __restrict__ XA, 
     }
 }
 
-// quiescent from cached histograms of the two real groups (scores.py:294-303)
+// ---------------------------------------------------------------------------------------------------------------
+// The same law from the two REAL groups' per-bin histograms (round 2).  Only the per-state counts of the shuffled groups are
+// needed, and they depend on the row only through its combined histogram h = hA + hB: the counts of the first ga and the next
+// gb columns of a uniform permutation of a row with h[s] columns of state s are MULTIVARIATE HYPERGEOMETRIC.  Sampled exactly,
+// category by category, by the same selection sampling as above (a column joins A with probability need_A / remaining, B with
+// need_B / remaining), except that the LAST category needs no draws at all: whatever is still needed comes from it.  The
+// row's most frequent state goes last, so a row costs n - max_s h[s] uniform numbers instead of n (71 % of real cells are
+// one state; i.i.d. synthetic rows at the chr1 frequencies: 209 of 721), and the kernel reads 72 bytes per bin instead of 721:
+// no state matrix, no LDS hand-over of rows.  Columns that hold no state (n - sum h) are one more category that is drawn
+// but not reported.  Philox4x32-10, counter = (global row, block of four draws, tag): a pure function of (seed, global row,
+// the row's histograms) -- not of the launch geometry or of the GPU count.  A lane owns a row; rows are handed over through
+// LDS both ways so that loads and stores cover whole lines.
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void nh_stage_in(char* lds, const char* src, int nbytes, int lane) {
+    const int nchunks = nbytes >> 4;
+    for (int c = lane; c < nchunks; c += 64) *reinterpret_cast<uint4*>(lds + 16 * c) = *reinterpret_cast<const uint4*>(src + 16 * c);
+    for (int o = (nchunks << 4) + 2 * lane; o + 2 <= nbytes; o += 128) *reinterpret_cast<u16*>(lds + o) = *reinterpret_cast<const u16*>(src + o);
+}
+
+__global__ __launch_bounds__(256) void k_null_hist_h(const u16* __restrict__ HA, const u16* __restrict__ HB, long R, int S, int n_cols,
+                                                      int ga, int gb, u64 seed, long row0, u16* __restrict__ OA, u16* __restrict__ OB) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int rowb = 2 * S;
+    char* sa = smem + (size_t)wave * 2 * 64 * rowb;               // the wave's 64 rows of hA, later of the A group's counts
+    char* sb = sa + 64 * rowb;
+    const long ntiles = (R + 63) >> 6;
+    for (long tile = (long)blockIdx.x * 4 + wave; tile < ntiles; tile += (long)gridDim.x * 4) {
+        const long r0 = tile * 64;
+        const int rows = (int)(R - r0 < 64 ? R - r0 : 64);
+        nh_stage_in(sa, reinterpret_cast<const char*>(HA + r0 * S), rows * rowb, lane);
+        nh_stage_in(sb, reinterpret_cast<const char*>(HB + r0 * S), rows * rowb, lane);
+        __builtin_amdgcn_wave_barrier();
+        if (lane < rows) {
+            u16* pa = reinterpret_cast<u16*>(sa + lane * rowb);
+            u16* pb = reinterpret_cast<u16*>(sb + lane * rowb);
+            // the most frequent state (first of equals) and the number of columns that hold a state
+            u32 tot = 0, best = 0;
+            int modal = 0;
+            for (int s = 0; s < S; ++s) {
+                const u32 h = (u32)pa[s] + pb[s];
+                tot += h;
+                if (h > best) { best = h; modal = s; }
+            }
+            u32 needA = (u32)ga, needB = (u32)gb, rem = (u32)n_cols;
+            const u64 grow = (u64)(row0 + r0 + lane);
+            u32 rnd[4], have = 0, calls = 0;
+            // categories: the states except the modal one, then the columns without a state; the modal state takes the rest
+            for (int s = 0; s <= S; ++s) {
+                if (s == modal) continue;
+                const u32 cnt = s < S ? (u32)pa[s] + pb[s] : (u32)n_cols - tot;
+                u32 inA = 0, inB = 0;
+                for (u32 d = 0; d < cnt && (needA | needB); ++d) {
+                    if (!have) {
+                        rnd[0] = (u32)grow; rnd[1] = (u32)(grow >> 32); rnd[2] = calls++; rnd[3] = 0x6e756c6cu;
+                        philox4x32_10(rnd, (u32)seed, (u32)(seed >> 32));
+                        have = 4;
+                    }
+                    const u32 u = have == 4 ? rnd[0] : (have == 3 ? rnd[1] : (have == 2 ? rnd[2] : rnd[3]));
+                    --have;
+                    const u32 pick = (u32)(((u64)u * rem) >> 32);              // uniform in [0, rem)
+                    const bool a = pick < needA, b = !a && pick < needA + needB;
+                    inA += a; inB += b;
+                    needA -= a; needB -= b;
+                    --rem;
+                }
+                if (s < S) { pa[s] = (u16)inA; pb[s] = (u16)inB; }
+            }
+            pa[modal] = (u16)needA;                                             // what is still missing comes from the last category
+            pb[modal] = (u16)needB;
+        }
+        __builtin_amdgcn_wave_barrier();
+        store_staged(sa, reinterpret_cast<char*>(OA + r0 * S), rows * rowb, lane);
+        store_staged(sb, reinterpret_cast<char*>(OB + r0 * S), rows * rowb, lane);
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+int null_hist_from_binhist_impl(const uint16_t* HA, const uint16_t* HB, int64_t R, int32_t S, int32_t n_cols, int32_t ga, int32_t gb,
+                                uint64_t seed, int64_t row0, uint16_t* OA, uint16_t* OB, hipStream_t st) {
+    if (R < 0 || S < 1 || S > 31 || n_cols < 1 || n_cols > 65535) return fail(EPG_ERR_INVALID_ARG, "null_hist_from_binhist: bad shape");
+    if (ga < 0 || gb < 0 || (long)ga + gb > n_cols)
+        return fail(EPG_ERR_INVALID_ARG, "null_hist_from_binhist: group sizes %d + %d exceed the %d columns", ga, gb, n_cols);
+    if (R == 0) return EPG_OK;
+    if (!HA || !HB || !OA || !OB) return fail(EPG_ERR_INVALID_ARG, "null_hist_from_binhist: NULL argument");
+    if ((reinterpret_cast<uintptr_t>(HA) | reinterpret_cast<uintptr_t>(HB) | reinterpret_cast<uintptr_t>(OA) | reinterpret_cast<uintptr_t>(OB)) & 15)
+        return fail(EPG_ERR_INVALID_ARG, "null_hist_from_binhist: histogram arrays must be 16-byte aligned");
+    long blocks = ((R + 63) / 64 + 3) / 4;
+    if (blocks > num_cus() * 8L) blocks = num_cus() * 8L;
+    const size_t shmem = (size_t)4 * 2 * 64 * 2 * S;
+    hipLaunchKernelGGL(k_null_hist_h, dim3((unsigned)blocks), dim3(256), shmem, st, HA, HB, (long)R, S, n_cols, ga, gb, (u64)seed,
+                       (long)row0, OA, OB);
+    EPG_LAUNCH_CHECK("k_null_hist_h");
+    return EPG_OK;
+}
+
+// quiescent from cached histograms of the two real groups (scores.py:294-303): every column of A and of B holds the
+// quiescent state <=> its count equals the group's width
+__global__ __launch_bounds__(256) void k_quiescent_h(const u16* __restrict__ HA, const u16* __restrict__ HB, long R, int S, int NA, int NB,
+                                                      int qstate, uint8_t* __restrict__ mask) {
+    const long row = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= R) return;
+    mask[row] = (uint8_t)(HA[row * S + qstate] == (u16)NA && HB[row * S + qstate] == (u16)NB);
+}
+
+int quiescent_from_binhist_impl(const uint16_t* HA, const uint16_t* HB, int64_t R, int32_t S, int32_t NA, int32_t NB, int32_t qstate,
+                                uint8_t* mask, hipStream_t st) {
+    if (R < 0 || S < 1 || NA < 1 || NB < 1 || NA > 65535 || NB > 65535 || qstate >= S)
+        return fail(EPG_ERR_INVALID_ARG, "quiescent_from_binhist: bad shape");
+    if (R == 0) return EPG_OK;
+    if (!HA || !HB || !mask) return fail(EPG_ERR_INVALID_ARG, "quiescent_from_binhist: NULL argument");
+    if (qstate < 0) {  // filtering off (run.py:113: -q 0 -> -1): nothing is quiescent
+        EPG_HIP(hipMemsetAsync(mask, 0, (size_t)R, st));
+        return EPG_OK;
+    }
+    hipLaunchKernelGGL(k_quiescent_h, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, st, HA, HB, (long)R, S, NA, NB, qstate, mask);
+    EPG_LAUNCH_CHECK("k_quiescent_h");
+    return EPG_OK;
+}
+
+
 int null_hist_impl(const int8_t* XA, int32_t NA, int64_t ldxa, const int8_t* XB, int32_t NB, int64_t ldxb, int64_t R, int32_t S,
                    int32_t ga, int32_t gb, uint64_t seed, int64_t row0, uint16_t* HA, uint16_t* HB, hipStream_t st) {
     if (R < 0 || NA < 1 || NB < 1 || ldxa < NA || ldxb < NB || S < 1 || S > 31)

@@ -290,6 +290,24 @@ def upload_states(pinned, R, ldx, copy_stream, device="cuda"):
     return X, ev
 
 
+def quiescent_from_binhist(HA, NA, HB, NB, S, qstate):
+    """Quiescence mask from the two groups' histograms (scores.py:294-303)."""
+    R = HA.shape[0]
+    mask = torch.empty(R, dtype=torch.uint8, device=HA.device)
+    _abi.call("epg_quiescent_from_binhist", _ptr(HA), _ptr(HB), R, S, NA, NB, qstate, _ptr(mask), _stream())
+    return mask
+
+
+def null_hist_from_binhist(HA, HB, n_cols, S, ga, gb, seed, row0=0):
+    """Histograms of the two shuffled null groups from the REAL groups' histograms (multivariate hypergeometric, exact)."""
+    if HA.shape != HB.shape:
+        raise ValueError("paired histograms must have the same shape")
+    OA, OB = torch.empty_like(HA), torch.empty_like(HB)
+    _abi.call("epg_null_hist_from_binhist", _ptr(HA), _ptr(HB), HA.shape[0], S, n_cols, ga, gb, seed, row0, _ptr(OA), _ptr(OB),
+              _stream())
+    return OA, OB
+
+
 def hist_to_numpy(H):
     """int16-stored uint16 histogram tensor -> numpy uint16."""
     return H.cpu().numpy().view(np.uint16)

@@ -131,12 +131,25 @@ int epg_pair_metrics(const float* delta, int64_t R, int32_t S, int32_t roundtrip
 /* mask[b] = all(XA[b,:]==qstate) && all(XB[b,:]==qstate)                          -- scores.py:294-303 */
 int epg_quiescent(const int8_t* XA, int32_t NA, int64_t ldxa, const int8_t* XB, int32_t NB, int64_t ldxb,
                   int64_t R, int32_t qstate, uint8_t* mask, void* stream);
+/* The same mask from the two groups' per-bin histograms: all NA columns of A and all NB columns of B hold qstate
+ * <=> HA[b, qstate] == NA and HB[b, qstate] == NB. */
+int epg_quiescent_from_binhist(const uint16_t* HA, const uint16_t* HB, int64_t R, int32_t S, int32_t NA, int32_t NB,
+                               int32_t qstate, uint8_t* mask, void* stream);
 /* Per-row uniform shuffle of the concatenation [A|B] (helpers.py:183-184: argsort of i.i.d. uniforms), written
  * as per-bin histograms of the two null halves: HA from the first `ga` shuffled columns, HB from the next `gb`
  * (helpers.py:190-194).  Philox4x32 keyed by (seed, row): reproducible, independent of the launch geometry. */
 int epg_null_hist(const int8_t* XA, int32_t NA, int64_t ldxa, const int8_t* XB, int32_t NB, int64_t ldxb,
                   int64_t R, int32_t S, int32_t ga, int32_t gb, uint64_t seed, int64_t row0,
                   uint16_t* HA, uint16_t* HB, void* stream);
+
+/* The same law from the two real groups' per-bin histograms HA, HB (uint16 [R, S], as epg_bin_hist leaves them): the
+ * per-state counts of the first `ga` and the next `gb` columns of a uniform permutation of a row depend on the row only
+ * through h = HA + HB and are multivariate hypergeometric; drawn exactly by selection sampling per state, the row's most
+ * frequent state taking the remainder without a draw.  n_cols = NA + NB (columns without a state, n_cols - sum h, take
+ * part in the shuffle and are not reported).  Same seeding contract as epg_null_hist, a DIFFERENT random stream: the two
+ * entry points agree in distribution, not draw by draw.  OA / OB may not alias HA / HB. */
+int epg_null_hist_from_binhist(const uint16_t* HA, const uint16_t* HB, int64_t R, int32_t S, int32_t n_cols, int32_t ga,
+                               int32_t gb, uint64_t seed, int64_t row0, uint16_t* OA, uint16_t* OB, void* stream);
 
 #ifdef __cplusplus
 }

@@ -139,6 +139,27 @@ def test_combine_score_s1_and_pair_hist_direct(abi):
     assert np.array_equal(c2.cpu().numpy().reshape(S, S), onp.expected_s2(np.concatenate([xa, xb], axis=1), S))
     with pytest.raises(abi.EpilogosHipError):
         abi.call("epg_hist_s2_from_binhist_pair", _p(HA), None, R, S, _p(c2), st)
+    # --- quiescence from the histograms == from the matrices
+    xq, yq = xa.copy(), xb.copy()
+    xq[10:20] = 17; yq[10:25] = 17
+    XQ, YQ = engine.states_to_device(xq), engine.states_to_device(yq)
+    HQ, _ = engine.bin_hist(XQ, NA, S, want_counts=False)
+    HY, _ = engine.bin_hist(YQ, NB, S, want_counts=False)
+    mq = torch.empty(R, dtype=torch.uint8, device="cuda")
+    abi.call("epg_quiescent_from_binhist", _p(HQ), _p(HY), R, S, NA, NB, 17, _p(mq), st)
+    assert torch.equal(mq, engine.quiescent(XQ, NA, YQ, NB, 17)) and int(mq.sum()) >= 10
+    assert np.array_equal(mq.cpu().numpy().astype(bool), onp.quiescent_mask(xq, yq, 17))
+    abi.call("epg_quiescent_from_binhist", _p(HQ), _p(HY), R, S, NA, NB, -1, _p(mq), st)
+    assert int(mq.sum()) == 0
+    # --- null groups from the real groups' histograms
+    OA, OB = torch.empty_like(HA), torch.empty_like(HB)
+    abi.call("epg_null_hist_from_binhist", _p(HA), _p(HB), R, S, NA + NB, NA, NB, 77, 0, _p(OA), _p(OB), st)
+    tot = engine.hist_to_numpy(HA).astype(np.int64) + engine.hist_to_numpy(HB).astype(np.int64)
+    got = engine.hist_to_numpy(OA).astype(np.int64) + engine.hist_to_numpy(OB).astype(np.int64)
+    assert np.array_equal(got, tot) and (engine.hist_to_numpy(OA).astype(np.int64).sum(axis=1) == NA).all()
+    with pytest.raises(abi.EpilogosHipError) as e:
+        abi.call("epg_null_hist_from_binhist", _p(HA), _p(HB), R, S, NA + NB, NA, NB + 1, 77, 0, _p(OA), _p(OB), st)
+    assert e.value.code == -1
 
 
 def test_combine_score_s1_long_table(abi):

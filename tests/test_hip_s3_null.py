@@ -228,3 +228,77 @@ def test_paired_pipeline_hip(tmp_path, golden_pair):
         assert nd.shape == gd.shape and nd.dtype == np.float32
         # unseeded in the reference: same scale and sign balance, not the same draws
         assert 0.5 < (np.abs(nd).mean() + 1e-12) / (np.abs(gd).mean() + 1e-12) < 2.0
+
+
+def test_null_hist_from_binhist_properties(eng):
+    """The histogram-based sampler (epg_null_hist_from_binhist): a permutation's bookkeeping, reproducibility, independence
+    of the row range a call covers, the group-size option, and columns that hold no state."""
+    R, NA, NB = 4000, 379, 342
+    xa = synth_states(R, NA, seed=21)
+    xb = synth_states(R, NB, seed=22)
+    xa[5, 3] = -1                                   # a column without a state takes part in the shuffle, is not reported
+    xb[7, 341] = 25
+    XA, XB = eng.states_to_device(xa), eng.states_to_device(xb)
+    HA, _ = eng.bin_hist(XA, NA, S, want_counts=False)
+    HB, _ = eng.bin_hist(XB, NB, S, want_counts=False)
+    tot = (eng.hist_to_numpy(HA).astype(np.int64) + eng.hist_to_numpy(HB).astype(np.int64))
+    OA, OB = eng.null_hist_from_binhist(HA, HB, NA + NB, S, NA, NB, seed=123)
+    oa, ob = eng.hist_to_numpy(OA).astype(np.int64), eng.hist_to_numpy(OB).astype(np.int64)
+    assert np.array_equal(oa + ob, tot)            # every column with a state lands in exactly one group
+    ok = np.ones(R, dtype=bool); ok[[5, 7]] = False
+    assert (oa[ok].sum(axis=1) == NA).all() and (ob[ok].sum(axis=1) == NB).all()
+    assert oa[5].sum() + ob[5].sum() == NA + NB - 1 and oa[7].sum() + ob[7].sum() == NA + NB - 1
+    OA2, OB2 = eng.null_hist_from_binhist(HA, HB, NA + NB, S, NA, NB, seed=123)
+    assert torch.equal(OA, OA2) and torch.equal(OB, OB2)
+    OA3, _ = eng.null_hist_from_binhist(HA, HB, NA + NB, S, NA, NB, seed=124)
+    assert not torch.equal(OA, OA3)
+    OAs, OBs = eng.null_hist_from_binhist(HA[1024:1600].contiguous(), HB[1024:1600].contiguous(), NA + NB, S, NA, NB, seed=123, row0=1024)
+    assert torch.equal(OAs, OA[1024:1600]) and torch.equal(OBs, OB[1024:1600])
+    frac = oa[:, 17].sum() / tot[:, 17].sum()      # the dominant state is never drawn, only completed: still NA / (NA + NB)
+    assert abs(frac - NA / (NA + NB)) < 0.002
+    OAg, OBg = eng.null_hist_from_binhist(HA, HB, NA + NB, S, 100, 100, seed=7)
+    oag, obg = eng.hist_to_numpy(OAg).astype(np.int64), eng.hist_to_numpy(OBg).astype(np.int64)
+    assert (oag[ok].sum(axis=1) == 100).all() and (obg[ok].sum(axis=1) == 100).all() and (oag + obg <= tot).all()
+    # odd state counts / tiny shapes
+    for S_, R_, na, nb in ((15, 70, 9, 4), (5, 1, 3, 3), (31, 129, 40, 41)):
+        ya, yb = synth_states(R_, na, S=S_, seed=S_, uniform=True), synth_states(R_, nb, S=S_, seed=S_ + 1, uniform=True)
+        Ha, _ = eng.bin_hist(eng.states_to_device(ya), na, S_, want_counts=False)
+        Hb, _ = eng.bin_hist(eng.states_to_device(yb), nb, S_, want_counts=False)
+        Oa, Ob = eng.null_hist_from_binhist(Ha, Hb, na + nb, S_, na, nb, seed=3)
+        t = eng.hist_to_numpy(Ha).astype(np.int64) + eng.hist_to_numpy(Hb).astype(np.int64)
+        assert np.array_equal(eng.hist_to_numpy(Oa).astype(np.int64) + eng.hist_to_numpy(Ob).astype(np.int64), t)
+        assert (eng.hist_to_numpy(Oa).astype(np.int64).sum(axis=1) == na).all()
+
+
+def test_null_hist_from_binhist_is_a_uniform_shuffle(eng):
+    """Same row repeated: the histogram-based sampler gives the counts of a uniform shuffle -- hypergeometric mean and variance
+    per state (the dominant state, which is never drawn, included), the joint law of two states, and the same empirical pmf as
+    numpy's argsort-of-uniforms shuffle (the reference's method, helpers.py:183-184) and as the column-based kernel."""
+    R, NA, NB = 60000, 12, 9
+    M = NA + NB
+    base = np.array([0] * 8 + [5] * 6 + [17] * 7, dtype=np.int8)
+    xa = np.tile(base[:NA], (R, 1))
+    xb = np.tile(base[NA:], (R, 1))
+    XA, XB = eng.states_to_device(xa), eng.states_to_device(xb)
+    HA, _ = eng.bin_hist(XA, NA, S, want_counts=False)
+    HB, _ = eng.bin_hist(XB, NB, S, want_counts=False)
+    OA, _ = eng.null_hist_from_binhist(HA, HB, M, S, NA, NB, seed=99)
+    oa = eng.hist_to_numpy(OA).astype(np.float64)
+    CA, _ = eng.null_hist(XA, NA, XB, NB, S, NA, NB, seed=5)
+    ca = eng.hist_to_numpy(CA).astype(np.int64)
+    rng = np.random.default_rng(0)
+    comb = np.tile(base, (R, 1))
+    sh = onp.shuffle_rows(comb, rng.random(comb.shape))[:, :NA]
+    for s, K in ((0, 8), (5, 6), (17, 7)):
+        mean = NA * K / M
+        var = NA * (K / M) * (1 - K / M) * (M - NA) / (M - 1)
+        assert abs(oa[:, s].mean() - mean) < 5 * np.sqrt(var / R)
+        assert abs(oa[:, s].var() - var) < 0.05 * var
+        pm_new = np.bincount(oa[:, s].astype(int), minlength=NA + 1) / R
+        pm_ref = np.bincount((sh == s).sum(axis=1), minlength=NA + 1) / R
+        pm_col = np.bincount(ca[:, s], minlength=NA + 1) / R
+        assert np.abs(pm_new - pm_ref).max() < 0.01 and np.abs(pm_new - pm_col).max() < 0.01
+    # joint law: cov(X_0, X_5) = -n (K0/M)(K5/M)(M - n)/(M - 1)
+    cov = np.cov(oa[:, 0], oa[:, 5])[0, 1]
+    want = -NA * (8 / M) * (6 / M) * (M - NA) / (M - 1)
+    assert abs(cov - want) < 0.05 * abs(want)

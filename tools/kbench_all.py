@@ -80,3 +80,14 @@ if "pair" in a.what:
     bench.generate_shard(torch, XB, NB, S, 0)
     t, _ = timed(lambda: engine.quiescent(XA, NA, XB, NB, S - 1))
     print("quiescent          : %8.3f ms for %d bins x (%d+%d) -> %.2f Gbins/s (%.0f GB/s)" % (t, R, NA, NB, R / t / 1e6, R * (NA + NB) / t / 1e6))
+if "null" in a.what:
+    R, NA, NB = a.bins, 379, 342
+    XA, XB = engine.alloc_states(R, NA), engine.alloc_states(R, NB)
+    bench.generate_shard(torch, XA, NA, S, 0)
+    bench.generate_shard(torch, XB, NB, S, 0)
+    HA, _ = engine.bin_hist(XA, NA, S, want_counts=False)
+    HB, _ = engine.bin_hist(XB, NB, S, want_counts=False)
+    t, _ = timed(lambda: engine.null_hist_from_binhist(HA, HB, NA + NB, S, NA, NB, seed=1))
+    print("null groups from H : %8.3f ms for %d bins x (%d+%d) -> %.2f Gbins/s" % (t, R, NA, NB, R / t / 1e6))
+    t, _ = timed(lambda: engine.null_hist(XA, NA, XB, NB, S, NA, NB, seed=1), reps=1)
+    print("null groups from X : %8.3f ms for %d bins x (%d+%d) -> %.2f Gbins/s" % (t, R, NA, NB, R / t / 1e6))
