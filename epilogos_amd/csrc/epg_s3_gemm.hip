@@ -30,15 +30,26 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v8i __attribute__((ext_vector_type(8)));
 typedef float v16f __attribute__((ext_vector_type(16)));
 
-constexpr int G_WM = 2, G_WN = 4;                       // waves of a workgroup along the A / B side
+// Workgroup shape: 2 x 4 waves (192 x 384 cells of C, 18 operand tiles per k-step, one workgroup per CU).  Building with
+// -DEPG_S3_WN=2 gives 2 x 2 waves (192 x 192, 12 tiles per k-step, 76 KB of LDS, TWO workgroups per CU -- confirmed with the
+// occupancy API -- so that one workgroup's waves could own the matrix pipe while the other waits at its barrier): measured
+// 70 ms per 1 M bins against 42, a third more operand traffic per MFMA outweighs the overlap.
+#ifndef EPG_S3_WN
+#define EPG_S3_WN 4
+#endif
+constexpr int G_WM = 2, G_WN = EPG_S3_WN;               // waves of a workgroup along the A / B side
+constexpr int G_NW = G_WM * G_WN;
 constexpr int G_BLK = 96;                               // rows of a wave's block (3 tiles of 32)
-constexpr int G_BM = G_WM * G_BLK, G_BN = G_WN * G_BLK; // 192 x 384 rows of C per workgroup
-constexpr int G_TA = G_BM / 32, G_TB = G_BN / 32;       // 6 + 12 operand tiles per k-step
+constexpr int G_BM = G_WM * G_BLK, G_BN = G_WN * G_BLK; // rows of C per workgroup
+constexpr int G_TA = G_BM / 32, G_TB = G_BN / 32;       // operand tiles per k-step
 constexpr int G_KS = 2;                                 // k-steps (of 64 bins) per stage
-constexpr int G_STAGES = 3;                             // LDS ring depth; loads run two stages ahead
-constexpr int G_LOADS = 5;                              // 1 KiB LDS-DMA loads per wave and stage: 8 x 5 = 40 slots, 36 used
-constexpr int G_STAGE_BYTES = 8 * G_LOADS * 1024;       // 40 KiB
-constexpr int G_PATCH_P = 8, G_PATCH_Q = 4;             // workgroup ordering: patches of 8 bm-pairs x 4 bn-quads
+constexpr int G_STAGES = 3;                             // LDS ring depth; loads run two to three stages ahead
+constexpr int G_LOADS = (G_KS * (G_TA + G_TB) + G_NW - 1) / G_NW;   // 1 KiB LDS-DMA loads per wave and stage (6; 5 of 40 slots for 2 x 4)
+constexpr int G_LA = G_LOADS - 3;                       // of which between the MFMAs of a stage's first / second k-step: G_LA / 3
+constexpr int G_STAGE_BYTES = G_NW * G_LOADS * 1024;
+constexpr int G_LDS_BYTES = G_STAGES * G_STAGE_BYTES + G_NW * 1024;   // ring + one scrap KiB per wave for the tail's dummy loads
+constexpr int G_PATCH_P = 8, G_PATCH_Q = G_WN == 2 ? 8 : 4;           // workgroup ordering: patches of the (P, Q) task grid
+static_assert(G_LA == 2 || G_LA == 3, "five or six loads per wave and stage");
 constexpr long G_KC_MAX = 1048576;                      // bins per chunk the workspace size is quoted for (multiple of 512; < 2^24)
 constexpr long G_KC_MIN = 16384;
 
@@ -68,14 +79,23 @@ __global__ __launch_bounds__(256) void k_s3_onehot_fp4(const char* __restrict__ 
                                     g_eq_pair_fp4(r1.z, r1.w, pat));
 }
 
-// Workgroup tasks (P = pair of A blocks, Q = quad of B blocks, P <= 2Q + 1 so that some bm <= bn), patch by patch.
+// Workgroup tasks (P = G_WM-tuple of A blocks, Q = G_WN-tuple of B blocks; needed when some bm <= bn, i.e. P <= g_pmax(Q)),
+// patch by patch.
+__host__ __device__ inline int g_pmax(int Q) { return (G_WN * Q + G_WN - 1) / G_WM; }
+
+static int g_ntasks(int NQ) {
+    int n = 0;
+    for (int Q = 0; Q < NQ; ++Q) n += g_pmax(Q) + 1;
+    return n;
+}
+
 __global__ void k_s3_tasks(int NQ, int* __restrict__ tasks) {
     if (threadIdx.x || blockIdx.x) return;
     int n = 0;
     for (int qq = 0; qq * G_PATCH_Q < NQ; ++qq)
-        for (int pp = 0; pp * G_PATCH_P <= 2 * (qq * G_PATCH_Q + G_PATCH_Q - 1) + 1; ++pp)
+        for (int pp = 0; pp * G_PATCH_P <= g_pmax(qq * G_PATCH_Q + G_PATCH_Q - 1); ++pp)
             for (int Q = qq * G_PATCH_Q; Q < qq * G_PATCH_Q + G_PATCH_Q && Q < NQ; ++Q)
-                for (int P = pp * G_PATCH_P; P < pp * G_PATCH_P + G_PATCH_P && P <= 2 * Q + 1; ++P) tasks[n++] = P | (Q << 16);
+                for (int P = pp * G_PATCH_P; P < pp * G_PATCH_P + G_PATCH_P && P <= g_pmax(Q); ++P) tasks[n++] = P | (Q << 16);
 }
 
 // the six operand tiles of one k-step: issued as a batch, consumed one batch of nine MFMAs later
@@ -142,13 +162,13 @@ __device__ __forceinline__ void g_mfma_loads(const GOps& o, bool active, v16f (&
     __builtin_amdgcn_s_setprio(0);
 }
 
-__global__ __launch_bounds__(512, 2) void k_s3_syrk_fp4(const char* __restrict__ E4, int NT, long nstages, long stages_per_split,
+__global__ __launch_bounds__(64 * G_NW, 2) void k_s3_syrk_fp4(const char* __restrict__ E4, int NT, long nstages, long stages_per_split,
                                                          const int* __restrict__ tasks, int ntasks, int N, int S,
                                                          int* __restrict__ counts, int dbg) {
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int wm = w >> 2, wn = w & 3;
+    const int wm = w / G_WN, wn = w % G_WN;
     // XCD b % 8 takes a contiguous run of the patch-ordered task list (bijective for any ntasks)
     const int xcd = blockIdx.x & 7, q8 = ntasks >> 3, r8 = ntasks & 7;
     const int tix = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (blockIdx.x >> 3);
@@ -165,8 +185,8 @@ __global__ __launch_bounds__(512, 2) void k_s3_syrk_fp4(const char* __restrict__
     u32 doff[G_LOADS];
 #pragma unroll
     for (int j = 0; j < G_LOADS; ++j) {
-        const int slot = w + 8 * j;
-        const int s = slot < G_KS * (G_TA + G_TB) ? slot : 0;              // slots 36..39: a harmless duplicate into scrap space
+        const int slot = w + G_NW * j;
+        const int s = slot < G_KS * (G_TA + G_TB) ? slot : 0;              // surplus slots (2 x 4 waves: 36..39): a harmless duplicate
         const int ks = s / (G_TA + G_TB), t = s - ks * (G_TA + G_TB);
         const int gt = (dbg & 1) ? t : (t < G_TA ? P * G_TA + t : Q * G_TB + (t - G_TA));   // dbg 1: every workgroup the same panels
         soff[j] = ((long)ks * NT + gt) * 1024 + lane * 16;
@@ -201,8 +221,8 @@ __global__ __launch_bounds__(512, 2) void k_s3_syrk_fp4(const char* __restrict__
     issue(0, 0);
     issue(G > 1 ? 1 : 0, 1);                               // a chunk shorter than the pipeline refetches stage 0: never read
 #pragma unroll
-    for (int j = 2; j < G_LOADS; ++j) issue1(G > 2 ? 2 : 0, 2, j);     // stage 2's first two loads go out in the loop's first turn
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * G_LOADS - 2) : "memory");
+    for (int j = G_LA; j < G_LOADS; ++j) issue1(G > 2 ? 2 : 0, 2, j);  // stage 2's first G_LA loads go out in the loop's first turn
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G_LOADS + 3) : "memory");
     __builtin_amdgcn_s_barrier();
     GOps o0, o1;
     g_read<0>(o0, baseA, baseB);
@@ -219,7 +239,7 @@ __global__ __launch_bounds__(512, 2) void k_s3_syrk_fp4(const char* __restrict__
         char* ldst = smem + into_slot * G_STAGE_BYTES;
         return [=, &soff, &doff](int j) {
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(lsrc + soff[j]),
-                                             (__attribute__((address_space(3))) void*)(ldst + (real ? doff[j] : (u32)(36 + (j & 3)) * 1024)), 16, 0, 0);
+                                             (__attribute__((address_space(3))) void*)(real ? ldst + doff[j] : smem + G_STAGES * G_STAGE_BYTES + w * 1024), 16, 0, 0);
         };
     };
     int slot = 0, slot_prev = G_STAGES - 1;                // ring slots of stage g and g - 1 (no division in the loop)
@@ -227,7 +247,7 @@ __global__ __launch_bounds__(512, 2) void k_s3_syrk_fp4(const char* __restrict__
         const u32 so = (u32)slot * G_STAGE_BYTES;
         const int slot1 = slot == G_STAGES - 1 ? 0 : slot + 1;
         g_read<1>(o1, baseA + so, baseB + so);
-        g_mfma_loads<0, 2>(o0, active, acc, loads_for(g + 2, slot_prev));
+        g_mfma_loads<0, G_LA>(o0, active, acc, loads_for(g + 2, slot_prev));
         g_wait_lds(o1);
         if (g + 1 < G) {
             // stage g + 1: this wave's loads have landed (the five of stage g + 2 -- real or, at the tail, dummies -- stay in
@@ -238,7 +258,7 @@ __global__ __launch_bounds__(512, 2) void k_s3_syrk_fp4(const char* __restrict__
             const u32 sn = (u32)slot1 * G_STAGE_BYTES;
             g_read<0>(o0, baseA + sn, baseB + sn);
         }
-        g_mfma_loads<2, 3>(o1, active, acc, loads_for(g + 3, slot));
+        g_mfma_loads<G_LA, 3>(o1, active, acc, loads_for(g + 3, slot));
         if (g + 1 < G) g_wait_lds(o0);
         slot_prev = slot;
         slot = slot1;
@@ -295,7 +315,7 @@ int transpose_states(const char* X, int64_t R, int32_t N, int64_t ldx, int32_t S
 static long g_chunk_bins(long Rp) { return Rp < G_KC_MAX ? Rp : G_KC_MAX; }
 
 static int64_t g_fixed_bytes(long Rp, int N, int NQ) {
-    return align_up((int64_t)N * Rp + 64, 1024) + align_up((int64_t)NQ * (NQ + 1) * 4, 1024);
+    return align_up((int64_t)N * Rp + 64, 1024) + align_up((int64_t)g_ntasks(NQ) * 4, 1024);
 }
 
 // smallest workspace the kernel can run with (a 16 K-bin chunk of the operand) -- less than that and the caller's
@@ -316,9 +336,10 @@ int64_t s3_gemm_ws_bytes(int64_t R, int N, int S) {
 
 int hist_s3_gemm(const char* X, int64_t R, int32_t N, int64_t ldx, int32_t S, int32_t* counts, void* ws, int64_t ws_bytes,
                  hipStream_t st) {
+    static const int dbg_env = [] { const char* e = getenv("EPG_S3_DBG"); return e ? atoi(e) : 0; }();
     const long Rp = align_up(R, 512);                  // whole stages; padded bins hold 31, which matches no row
     const int NS = N * S, NSP = g_rows_padded(NS), NT = NSP / 32, NQ = NSP / G_BN;
-    const int ntasks = NQ * (NQ + 1);
+    const int ntasks = g_ntasks(NQ);
     char* XT = reinterpret_cast<char*>(ws);
     int* tasks = reinterpret_cast<int*>(XT + align_up((int64_t)N * Rp + 64, 1024));
     char* E4 = reinterpret_cast<char*>(tasks) + align_up((int64_t)ntasks * 4, 1024);
@@ -327,15 +348,19 @@ int hist_s3_gemm(const char* X, int64_t R, int32_t N, int64_t ldx, int32_t S, in
     hipLaunchKernelGGL(k_s3_tasks, dim3(1), dim3(1), 0, st, NQ, tasks);
     EPG_LAUNCH_CHECK("k_s3_tasks");
     static bool attr_set = false;
+    if (dbg_env & 4) {
+        int nblk = -1;
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&nblk, reinterpret_cast<const void*>(k_s3_syrk_fp4), 64 * G_NW, G_LDS_BYTES);
+        fprintf(stderr, "k_s3_syrk_fp4: %d workgroups of %d threads per CU with %d bytes of LDS\n", nblk, 64 * G_NW, G_LDS_BYTES);
+    }
     if (!attr_set) {
         EPG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_s3_syrk_fp4), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    G_STAGES * G_STAGE_BYTES));
+                                    G_LDS_BYTES));
         attr_set = true;
     }
     // chunk = as many bins of the operand as the caller's workspace holds (every chunk ends in one epilogue of ~2 atomics
     // per cell of counts, so fewer, longer chunks are better); EPG_S3_KC overrides for measurements
     long KC = (ws_bytes - g_fixed_bytes(Rp, N, NQ)) / ((int64_t)NT * 1024) * 64 / 512 * 512;
-    static const int dbg_env = [] { const char* e = getenv("EPG_S3_DBG"); return e ? atoi(e) : 0; }();
     static const long kc_env = [] { const char* e = getenv("EPG_S3_KC"); return e ? atol(e) / 512 * 512 : 0L; }();
     if (kc_env > 0 && kc_env < KC) KC = kc_env;
     if (KC > Rp) KC = Rp;
@@ -351,7 +376,7 @@ int hist_s3_gemm(const char* X, int64_t R, int32_t N, int64_t ldx, int32_t S, in
         // Split the chunk's stages over blockIdx.y: few tasks (small N) need it to give every CU work, and with one
         // workgroup per CU the last round of a launch is only partly full -- 1640 tasks on 256 CUs are 6.4 rounds, paid as
         // 7; in two halves 12.8, paid as 13.  int32 atomics combine the splits.
-        const long cus = num_cus();
+        const long cus = (long)num_cus() * (G_NW == 4 ? 2 : 1);   // workgroups the chip holds at a time
         long splits = (2L * cus + ntasks - 1) / ntasks, best = 0;
         double best_waste = 1e9;
         for (long sp = splits; sp <= splits + 3; ++sp) {
@@ -365,7 +390,7 @@ int hist_s3_gemm(const char* X, int64_t R, int32_t N, int64_t ldx, int32_t S, in
         if (splits > 65535) splits = 65535;
         const long per = (nstages + splits - 1) / splits;
         const long nsplit = (nstages + per - 1) / per;
-        hipLaunchKernelGGL(k_s3_syrk_fp4, dim3((unsigned)ntasks, (unsigned)nsplit), dim3(512), G_STAGES * G_STAGE_BYTES, st, E4, NT, nstages,
+        hipLaunchKernelGGL(k_s3_syrk_fp4, dim3((unsigned)ntasks, (unsigned)nsplit), dim3(64 * G_NW), G_LDS_BYTES, st, E4, NT, nstages,
                            per, tasks, ntasks, N, S, counts, dbg_env);
         EPG_LAUNCH_CHECK("k_s3_syrk_fp4");
     }

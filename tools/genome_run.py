@@ -35,12 +35,16 @@ ap.add_argument("--biosamples", type=int, default=833)
 ap.add_argument("--keep", action="store_true")
 ap.add_argument("--skip-warm", action="store_true")
 ap.add_argument("--also", default="", help="comma list of further saliencies to run from the warm cache, e.g. 2,3")
+ap.add_argument("--paired", action="store_true", help="also write the 379 + 342 column split as two groups and run -m paired (S1)")
 a = ap.parse_args()
 N, S = a.biosamples, 18
 base = Path(a.dir or (Path("/dev/shm") if Path("/dev/shm").is_dir() else Path(os.environ.get("TMPDIR", "/tmp"))) / "epg_genome")
 shutil.rmtree(base, ignore_errors=True)
 ind, cache = base / "in", base / "cache"
 ind.mkdir(parents=True)
+gA, gB = base / "male", base / "female"
+if a.paired:
+    gA.mkdir(); gB.mkdir()
 meta = base / "metadata.tsv"
 meta.write_text("zero_index\tone_index\tshort_name\n" + "".join("%d\t%d\tS%d\n" % (i, i + 1, i + 1) for i in range(S)))
 
@@ -59,6 +63,9 @@ for name, bp in HG19:
     del X
     path = ind / ("matrix_%s.txt.gz" % name)
     _io.write_states(path, name, x, gzip_level=1)
+    if a.paired:                                     # BASELINE config 5 shape: 379 + 342 biosamples
+        _io.write_states(gA / path.name, name, np.ascontiguousarray(x[:, :379]), gzip_level=1)
+        _io.write_states(gB / path.name, name, np.ascontiguousarray(x[:, 379:721]), gzip_level=1)
     rows[name] = R
     bin0 += R
     text_bytes += path.stat().st_size
@@ -71,8 +78,9 @@ WRAP = ("import resource, subprocess, sys, json, time; t = time.time(); r = subp
         "'peak_rss_gb': resource.getrusage(resource.RUSAGE_CHILDREN).ru_maxrss / 1048576.0})); sys.exit(r.returncode)")
 
 
-def run(label, out, saliency=None):
-    cmd = [sys.executable, "-c", WRAP, sys.executable, "-m", "epilogos_amd.run", "-l", "-i", str(ind), "-j", str(meta), "-o", str(out),
+def run(label, out, saliency=None, paired=False):
+    src = ["-m", "paired", "-a", str(gA), "-b", str(gB), "--null-seed", "7"] if paired else ["-i", str(ind)]
+    cmd = [sys.executable, "-c", WRAP, sys.executable, "-m", "epilogos_amd.run", "-l", *src, "-j", str(meta), "-o", str(out),
            "-s", str(saliency or a.saliency), "--cache-dir", str(cache)]
     r = subprocess.run(cmd, cwd=str(ROOT), capture_output=True, text=True, env=dict(os.environ, EPILOGOS_TIMING="1"))
     info = [json.loads(l[2:]) for l in r.stdout.splitlines() if l.startswith("@@")]
@@ -99,6 +107,22 @@ for sal in [int(v) for v in a.also.split(",") if v]:
             n = sum(chunk.count(b"\n") for chunk in iter(lambda: fh.read(1 << 24), b""))
         assert n == rows[name], (sal, name, n, rows[name])
 
+if a.paired:
+    o = base / "out_paired"
+    run("paired S1, 379 + 342 biosamples, cold", o, saliency=1, paired=True)
+    run("paired S1, 379 + 342 biosamples, warm cache", base / "out_paired2", saliency=1, paired=True)
+    for name, _ in HG19:
+        with gzip.open(o / ("pairwiseDelta_male_female_s1_matrix_%s.txt.gz" % name), "rb") as fh:
+            n = sum(chunk.count(b"\n") for chunk in iter(lambda: fh.read(1 << 24), b""))
+        assert n == rows[name], ("paired", name, n, rows[name])
+    with gzip.open(o / "pairwiseMetrics_male_female_s1.txt.gz", "rb") as fh:
+        n = sum(chunk.count(b"\n") for chunk in iter(lambda: fh.read(1 << 24), b""))
+    assert n == total, ("pairwiseMetrics", n, total)
+    a_ = gzip.open(o / "pairwiseDelta_male_female_s1_matrix_chr21.txt.gz", "rb").read()
+    b_ = gzip.open(base / "out_paired2" / "pairwiseDelta_male_female_s1_matrix_chr21.txt.gz", "rb").read()
+    assert a_ == b_, "paired cold and warm runs differ"
+    print("paired checks OK: 24 pairwiseDelta files and pairwiseMetrics with the right line counts", flush=True)
+
 # ---- checks: every chromosome's output has its number of lines; chr21 equals the engine's scores of the cached matrix
 tag = "in_s%d" % a.saliency
 for name, _ in HG19:
@@ -115,8 +139,8 @@ if a.saliency == 1:
     counts = torch.zeros(S, dtype=torch.int64, device="cuda")
     H21 = None
     for name, _ in HG19:
-        st = [p for p in cache.glob("matrix_%s_*.states.npy" % name)]
-        x = np.load(st[0], mmap_mode="r")
+        st = [np.load(p, mmap_mode="r") for p in cache.glob("matrix_%s_*.states.npy" % name)]
+        x = [m for m in st if m.shape[1] == N][0]                  # the paired runs cache their 379- and 342-column files too
         Xd = engine.states_to_device(np.ascontiguousarray(x))
         H, _ = engine.bin_hist(Xd, N, S, counts=counts)
         if name == "chr21":
