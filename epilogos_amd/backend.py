@@ -146,7 +146,8 @@ class _HipSession:
     def __init__(self, be, S, saliency):
         self.be, self.S, self.sal = be, S, saliency
         self.torch, self.eng, self.device = be.torch, be.engine, be.device
-        self.pool = be.engine.PinnedPool(int(__import__("os").environ.get("EPILOGOS_PINNED_BUFFERS", "4")))
+        # staging buffers in flight; paired mode holds a part's A and B at once, so never fewer than two
+        self.pool = be.engine.PinnedPool(max(2, int(__import__("os").environ.get("EPILOGOS_PINNED_BUFFERS", "4"))))
         self.copy_stream = self.torch.cuda.Stream(device=self.device)
         self.held = {}                                   # ticket -> pinned buffer handed to the parser
         self.acc = None
