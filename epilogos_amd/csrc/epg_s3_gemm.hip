@@ -175,7 +175,7 @@ __global__ __launch_bounds__(64 * G_NW, 2) void k_s3_syrk_fp4(const char* __rest
     const int task = tasks[tix];
     const int P = task & 0xffff, Q = task >> 16;
     const int bm = G_WM * P + wm, bn = G_WN * Q + wn;
-    const bool active = bm <= bn;                                           // wave-uniform
+    const bool active = bm <= bn && !(dbg & 8);                             // wave-uniform (dbg 8: data path only, no MFMAs)
     const long g0 = (long)blockIdx.y * stages_per_split;
     const int G = (int)(nstages - g0 < stages_per_split ? nstages - g0 : stages_per_split);   // < 2^24 / 128
     if (G <= 0) return;
@@ -234,7 +234,7 @@ __global__ __launch_bounds__(64 * G_NW, 2) void k_s3_syrk_fp4(const char* __rest
     // ... s(g+1){2,3,4} s(g+1){0,1} s(g+2){2,3,4} s(g+2){0,1} | wait for stage g + 1 = vmcnt(5).  Past the last stage the
     // same instructions fetch stage 0 into the ring's scrap slots, so the loop has no load-dependent control flow.
     auto loads_for = [&](int gs, int into_slot) {
-        const bool real = gs < G;
+        const bool real = gs < G && !(dbg & 16);           // dbg 16: no operand traffic in the loop (dummy loads of stage 0)
         const char* lsrc = src0 + (real ? (long)gs * stage_stride : 0L);
         char* ldst = smem + into_slot * G_STAGE_BYTES;
         return [=, &soff, &doff](int j) {
