@@ -247,7 +247,10 @@ def _stream_parts(jobs, sess, numStates):
     """jobs: [(path, lo, hi or None)].  Parses ahead in threads (inflate is serial per file, files run in parallel; the
     native parser releases the GIL) and yields (ticket, states [rows, width], N, Locations) in job order.  Destinations
     come from the session (pinned staging, handed out in ticket order, which also bounds the host memory in flight)."""
-    workers = max(1, min(int(os.environ.get("EPILOGOS_PARSE_WORKERS", "8")), len(jobs)))
+    # files in flight: inflate is one serial stream per file, so more files than cores keeps the cores busy while some workers
+    # wait for their staging buffer (whole genome, 16 cores: 8 workers 22.6 s, 16 workers 17.3 s, 24 workers 14.7 s of parse)
+    default_workers = max(8, min(32, 3 * (len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else 8) // 2))
+    workers = max(1, min(int(os.environ.get("EPILOGOS_PARSE_WORKERS", default_workers)), len(jobs)))
 
     def read(ticket):
         path, lo, hi = jobs[ticket]
