@@ -289,13 +289,18 @@ int hist_s3_mfma(const char* X, int64_t R, int32_t N, int64_t ldx, int32_t S, in
 int64_t s3_gemm_ws_bytes(int64_t R, int N, int S);
 int64_t s3_gemm_ws_min_bytes(int64_t R, int N, int S);
 int hist_s3_gemm(const char* X, int64_t R, int32_t N, int64_t ldx, int32_t S, int32_t* counts, void* ws, int64_t ws_bytes, hipStream_t st);
+bool s3_lanes_ok(int N, int S);
+int64_t s3_lanes_ws_bytes(int64_t R, int N, int S);
+int score_s3_lanes(const int8_t* X8, int64_t R, int32_t N, int64_t ldx, int32_t S, const float* q, double* out64, float* out32, void* ws,
+                   int64_t ws_bytes, hipStream_t st);
 
 static int s3_nceil(int N) { return (N + S3S_ACH - 1) / S3S_ACH * S3S_ACH; }
 int64_t s3_table_bytes(int N, int S) { return align_up((int64_t)s3_nceil(N) * N * S * S * 4, 256); }
 int64_t s3_ws_bytes(int64_t R, int N, int S) {
     // score: table + transposed state matrix + float64 accumulator; expected: transposed state matrix (+ a chunk of the
     // precomputed fp4 one-hot operand for the default kernel)
-    const int64_t score = s3_table_bytes(N, S) + s3_mfma_ws_bytes(R, N) + align_up(R * S * 8, 256);
+    int64_t score = s3_table_bytes(N, S) + s3_mfma_ws_bytes(R, N) + align_up(R * S * 8, 256);
+    if (s3_lanes_ok(N, S) && s3_lanes_ws_bytes(R, N, S) > score) score = s3_lanes_ws_bytes(R, N, S);
     const int64_t expected = s3_gemm_ws_bytes(R, N, S);
     return score > expected ? score : expected;
 }
@@ -335,6 +340,12 @@ int score_s3_impl(const int8_t* X8, int64_t R, int32_t N, int64_t ldx, int32_t S
     if (S > 31) return fail(EPG_ERR_UNSUPPORTED, "score_s3: S=%d > 31 not supported by this build", S);
     if (R == 0) return EPG_OK;
     if (!X8 || !q || !ws) return fail(EPG_ERR_INVALID_ARG, "score_s3: NULL argument");
+    // default: the biosample-lane kernel (epg_s3_lanes.hip, S <= 21) when the workspace holds its table;
+    // EPG_S3_SCORE=bins selects k_s3_score below (A/B measurements; the path for S > 21)
+    const char* env = getenv("EPG_S3_SCORE");      // read per call: the tests run both kernels in one process
+    const bool force_bins = env && env[0] == 'b';
+    if (!force_bins && s3_lanes_ok(N, S) && ws_bytes >= s3_lanes_ws_bytes(R, N, S) - (out64 ? align_up(R * S * 8, 256) : 0))
+        return score_s3_lanes(X8, R, N, ldx, S, q, out64, out32, ws, ws_bytes, st);
     const int64_t tb = s3_table_bytes(N, S), xtb = s3_mfma_ws_bytes(R, N);
     const int64_t need = tb + xtb + (out64 ? 0 : align_up(R * S * 8, 256));
     if (ws_bytes < need) return fail(EPG_ERR_WORKSPACE, "score_s3: workspace %lld < %lld bytes", (long long)ws_bytes, (long long)need);

@@ -35,7 +35,7 @@ constexpr int MF_T = 3;               // tiles per block side
 constexpr int MF_ROWS = 32 * MF_T;    // (sample, state) rows per block
 
 __global__ __launch_bounds__(256) void k_transpose_states(const char* __restrict__ X, long R, int N, long ldx, int S,
-                                                           char* __restrict__ XT, long Rp, int shift) {
+                                                           char* __restrict__ XT, long Rp, int shift, int bad) {
     __shared__ unsigned char tile[64][65];
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const long b0 = (long)blockIdx.x * 64;
@@ -44,10 +44,10 @@ __global__ __launch_bounds__(256) void k_transpose_states(const char* __restrict
     for (int i = 0; i < 16; ++i) {
         const long bin = b0 + ty + 4 * i;
         const int smp = s0 + tx;
-        unsigned char v = 31;                         // "not a state": bins past R, states outside [0, S)
+        unsigned char v = (unsigned char)bad;         // "not a state": bins past R, states outside [0, S)
         if (bin < R && smp < N) {
             v = (unsigned char)X[bin * ldx + smp];
-            if (v >= S) v = 31;
+            if (v >= S) v = (unsigned char)bad;
         }
         tile[ty + 4 * i][tx] = (unsigned char)(v << shift);
     }
@@ -460,11 +460,16 @@ int64_t s3_mfma_ws_bytes(int64_t R, int N) { return align_up((int64_t)N * align_
 
 // XT[sample][bin], bins padded to Rp (a multiple of 32), everything that is not a state in [0, S) stored as 31;
 // bytes are stored shifted left by `shift` (the S3 score kernel wants 4 * state, a ready-made LDS byte offset)
-int transpose_states(const char* X, int64_t R, int32_t N, int64_t ldx, int32_t S, char* XT, int64_t Rp, int shift, hipStream_t st) {
+// `bad` is the code stored for "not a state" (31 for the kernels of this file and k_s3_score; S for k_s3_score_bl, whose
+// table rows have exactly one zero column after the S states)
+int transpose_states_bad(const char* X, int64_t R, int32_t N, int64_t ldx, int32_t S, char* XT, int64_t Rp, int shift, int bad, hipStream_t st) {
     hipLaunchKernelGGL(k_transpose_states, dim3((unsigned)((Rp + 63) / 64), (unsigned)((N + 63) / 64)), dim3(256), 0, st, X, (long)R, N,
-                       (long)ldx, S, XT, (long)Rp, shift);
+                       (long)ldx, S, XT, (long)Rp, shift, bad);
     EPG_LAUNCH_CHECK("k_transpose_states");
     return EPG_OK;
+}
+int transpose_states(const char* X, int64_t R, int32_t N, int64_t ldx, int32_t S, char* XT, int64_t Rp, int shift, hipStream_t st) {
+    return transpose_states_bad(X, R, N, ldx, S, XT, Rp, shift, 31, st);
 }
 
 int hist_s3_mfma(const char* X, int64_t R, int32_t N, int64_t ldx, int32_t S, int32_t* counts, void* ws, hipStream_t st) {

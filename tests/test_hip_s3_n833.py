@@ -108,3 +108,24 @@ def test_s3_scores_n833(eng, case, oracle_counts):
     want = np.zeros(S)
     np.add.at(want, xr[b_idx[keep]], T[a_idx[keep], b_idx[keep], xr[a_idx[keep]], xr[b_idx[keep]]])
     np.testing.assert_allclose(o64.cpu().numpy()[r], want, rtol=2e-6, atol=1e-9)
+
+
+def test_s3_score_two_kernels_agree(eng, case, oracle_counts, monkeypatch):
+    """The biosample-lane kernel (default, 32-bit fixed-point table, epg_s3_lanes.hip) against the bin-lane kernel (float32
+    table, float64 folds, EPG_S3_SCORE=bins) on the same 4400 bins -- three workgroup slices of 1440 with a ragged tail,
+    27 chunks of 32 biosamples with a ragged last one (833 = 26 * 32 + 1), bins holding bytes that are not states."""
+    q = torch.from_numpy(onp.normalise(oracle_counts).reshape(-1)).cuda()
+    lo = 70001 - 2000
+    X = case["X"][lo:lo + 4400]
+    monkeypatch.delenv("EPG_S3_SCORE", raising=False)
+    a32, a64 = eng.score_s3(X, N, S, q, want32=True, want64=True)
+    a32b, _ = eng.score_s3(X, N, S, q, want32=True, want64=False)
+    assert torch.equal(a32, a32b)                                   # integer accumulation: run-to-run identical
+    monkeypatch.setenv("EPG_S3_SCORE", "bins")
+    b32, b64 = eng.score_s3(X, N, S, q, want32=True, want64=True)
+    monkeypatch.delenv("EPG_S3_SCORE")
+    np.testing.assert_allclose(a64.cpu().numpy(), b64.cpu().numpy(), rtol=1e-6, atol=1e-9)
+    assert not torch.equal(a64, b64)                                # two different kernels did run
+    # a partition of the bins gives the same bits (the cells are integers until the last step)
+    p32, _ = eng.score_s3(X[:1500], N, S, q, want32=True, want64=False)
+    assert torch.equal(p32, a32[:1500])
