@@ -87,10 +87,12 @@ def test_s3_score_tile_not_multiple_of_four(eng, N):
     _s3_score_check(eng, x, onp.normalise(c))
 
 
-@pytest.mark.parametrize("S_,N,R", [(5, 40, 300), (13, 23, 1000), (15, 64, 700), (25, 30, 257), (30, 21, 420), (31, 9, 300)])
+@pytest.mark.parametrize("S_,N,R", [(5, 40, 300), (13, 23, 1000), (15, 64, 700), (25, 30, 257), (30, 21, 420), (31, 9, 300),
+                                     (15, 200, 1500), (20, 70, 1500), (19, 33, 2900), (21, 40, 300)])
 def test_s3_other_state_counts(eng, S_, N, R):
-    """State models other than 18: S < 14 takes the per-lane-load MFMA kernel, S = 31 the LDS-atomic one; the score
-    kernel is instantiated for 6, 10 and 16 staging elements per thread."""
+    """State models other than 18: S < 14 takes the per-lane-load MFMA kernel, S = 31 the LDS-atomic one; k_s3_score (S > 20)
+    is instantiated for 6, 10 and 16 staging elements per thread, k_s3_score_bl (S <= 20) for 16, 32, 43 and 53 table loads per
+    chunk (S = 5 / 13 / 15, 18 / 19, 20), with one to seven chunks of 32 biosamples and one to three bin slices of 1440."""
     x = synth_states(R, N, S=S_, seed=S_, uniform=True)
     keep = x[R // 2, N // 2]
     x[R // 2, N // 2] = -1                         # not a state: skipped in every pair it takes part in
