@@ -164,8 +164,12 @@ __global__ __launch_bounds__(256) void k_score_s1(const char* __restrict__ X, lo
 // the texture-address rate, 3.9 TB/s of its 108 B/bin; an LDS gather costs a few cycles.
 template <typename OT, bool LDS_T>
 __global__ __launch_bounds__(LDS_T ? 1024 : 256) void k_score_s1_from_hist(const u16* __restrict__ H, long total, int S,
-                                                                             const OT* __restrict__ Tg, int nent, OT* __restrict__ out) {
+                                                                             const OT* __restrict__ Tg, int nent, OT* __restrict__ out,
+                                                                             u64* __restrict__ zero_counts) {
     extern __shared__ __attribute__((aligned(16))) char smem_t[];
+    // the job's state counts are spent once the table exists (this launch is ordered after k_s1_combine): zero them for the
+    // next job's accumulation here instead of in a launch of its own
+    if (zero_counts && blockIdx.x == 0 && (int)threadIdx.x < S) zero_counts[threadIdx.x] = 0;
     const OT* T = Tg;
     if (LDS_T) {
         OT* Ts = reinterpret_cast<OT*>(smem_t);
@@ -371,7 +375,7 @@ static int check_score_from_hist_args(const uint16_t* H, const double* out64, co
 }
 
 template <typename OT>
-static int launch_score_s1_from_hist_t(const uint16_t* H, long total, int32_t S, const OT* T, int nent, OT* out, hipStream_t st) {
+static int launch_score_s1_from_hist_t(const uint16_t* H, long total, int32_t S, const OT* T, int nent, OT* out, u64* zero_counts, hipStream_t st) {
     const size_t tbytes = (size_t)nent * sizeof(OT);
     static const bool no_lds = [] { const char* e = getenv("EPG_S1_SCORE"); return e && e[0] == 'g'; }();   // A/B: gather from memory
     if (tbytes <= 150 * 1024 && !no_lds) {             // the table in LDS: blocks of 16 waves, as many per CU as tables fit (<= 2)
@@ -385,24 +389,24 @@ static int launch_score_s1_from_hist_t(const uint16_t* H, long total, int32_t S,
             EPG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
             attr_set = true;
         }
-        hipLaunchKernelGGL(kern, dim3((int)nb), dim3(1024), tbytes, st, H, total, S, T, nent, out);
+        hipLaunchKernelGGL(kern, dim3((int)nb), dim3(1024), tbytes, st, H, total, S, T, nent, out, zero_counts);
     } else {
         long nb = (total / 4 + 1023) / 1024;
         if (nb > num_cus() * 8L) nb = num_cus() * 8L;  // 8 blocks/CU measured best (16: +5 %); nt stores: no gain
         if (nb < 1) nb = 1;
-        hipLaunchKernelGGL((k_score_s1_from_hist<OT, false>), dim3((int)nb), dim3(256), 0, st, H, total, S, T, nent, out);
+        hipLaunchKernelGGL((k_score_s1_from_hist<OT, false>), dim3((int)nb), dim3(256), 0, st, H, total, S, T, nent, out, zero_counts);
     }
     EPG_LAUNCH_CHECK("k_score_s1_from_hist");
     return EPG_OK;
 }
 
 static int launch_score_s1_from_hist(const uint16_t* H, int64_t R, int32_t N, int32_t S, const double* T64, const float* T32,
-                                     double* out64, float* out32, hipStream_t st) {
+                                     double* out64, float* out32, hipStream_t st, u64* zero_counts = nullptr) {
     const long total = (long)R * S;
     const int nent = (N + 1) * S;
     int rc = EPG_OK;
-    if (out32) rc = launch_score_s1_from_hist_t<float>(H, total, S, T32, nent, out32, st);
-    if (!rc && out64) rc = launch_score_s1_from_hist_t<double>(H, total, S, T64, nent, out64, st);
+    if (out32) rc = launch_score_s1_from_hist_t<float>(H, total, S, T32, nent, out32, zero_counts, st);
+    if (!rc && out64) rc = launch_score_s1_from_hist_t<double>(H, total, S, T64, nent, out64, out32 ? nullptr : zero_counts, st);
     return rc;
 }
 
@@ -421,13 +425,15 @@ int score_s1_from_hist_impl(const uint16_t* H, int64_t R, int32_t N, int32_t S, 
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// STEP 2 and the S1 table of STEP 3 in ONE single-block launch (a whole S1 job on a 1.9 M-bin shard is ~0.35 ms of kernel
-// time: a memset, two normalise kernels and the table kernel, each with its ~1.7 us boundary and its host call, were a
-// measurable part of it): q = float32(double(C) / double(sum C)) (expectedCombination.py:42), T[c, s] = kl(c / N, q[s])
-// (scores.py:343,550), and optionally counts = 0 for the next job's accumulation.
+// STEP 2 and the S1 table of STEP 3 in ONE launch (a whole S1 job on a 1.9 M-bin shard is ~0.35 ms of kernel time: a memset,
+// two normalise kernels and the table kernel, each with its ~1.7 us boundary and its host call, were a measurable part of
+// it): q = float32(double(C) / double(sum C)) (expectedCombination.py:42), T[c, s] = kl(c / N, q[s]) (scores.py:343,550).
+// Every block works q out for itself from the S counts and then fills 256 entries of the table: as ONE block of 1024 threads
+// (each with 15 float64 log2 in a row) this launch took 16.5 us, a tenth of which is left.  The counts are zeroed for the next
+// job by the score kernel that follows (no block of this one knows when the others have read them).
 // ---------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void k_s1_combine(u64* __restrict__ counts, int rezero, int N, int S, float* __restrict__ q,
-                                                      double* __restrict__ T64, float* __restrict__ T32) {
+__global__ __launch_bounds__(256) void k_s1_combine(const u64* __restrict__ counts, int N, int S, float* __restrict__ q,
+                                                     double* __restrict__ T64, float* __restrict__ T32) {
     __shared__ long long s_c[32];
     __shared__ double s_q[32];
     const int t = threadIdx.x;
@@ -437,13 +443,12 @@ __global__ __launch_bounds__(1024) void k_s1_combine(u64* __restrict__ counts, i
         long long tot = 0;
         for (int s = 0; s < S; ++s) tot += s_c[s];
         const float qf = (float)((double)s_c[t] / (double)tot);
-        q[t] = qf;
+        if (blockIdx.x == 0) q[t] = qf;
         s_q[t] = (double)qf;
-        if (rezero) counts[t] = 0;
     }
     __syncthreads();
-    const int n = (N + 1) * S;
-    for (int e = t; e < n; e += 1024) {
+    const int e = blockIdx.x * 256 + t;
+    if (e < (N + 1) * S) {
         const int c = e / S, s = e - c * S;
         const double v = kl_term((double)c / (double)N, s_q[s]);
         T64[e] = v;
@@ -464,20 +469,14 @@ int combine_score_s1_impl(int64_t* counts, int32_t rezero, const uint16_t* H, in
     if (rc) return rc;
     double* T64 = reinterpret_cast<double*>(ws);
     float* T32 = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + align_up((int64_t)(N + 1) * S * 8, 256));
-    if ((long)(N + 1) * S <= (1L << 18)) {
-        hipLaunchKernelGGL(k_s1_combine, dim3(1), dim3(1024), 0, st, reinterpret_cast<u64*>(counts), rezero, N, S, q, T64, T32);
-        EPG_LAUNCH_CHECK("k_s1_combine");
-    } else {                                               // a table too long for one block: the separate kernels
-        if (ws_bytes < s1_table_bytes(N, S) + 256) return fail(EPG_ERR_WORKSPACE, "combine_score_s1: workspace too small");
-        void* tot = reinterpret_cast<char*>(ws) + s1_table_bytes(N, S);
-        rc = normalise_impl<long long>(reinterpret_cast<const long long*>(counts), S, q, tot, 256, st);
-        if (rc) return rc;
+    const long nent = (long)(N + 1) * S;
+    hipLaunchKernelGGL(k_s1_combine, dim3((unsigned)((nent + 255) / 256)), dim3(256), 0, st, reinterpret_cast<const u64*>(counts), N, S, q, T64, T32);
+    EPG_LAUNCH_CHECK("k_s1_combine");
+    if (R == 0 || (!out32 && !out64)) {
         if (rezero) EPG_HIP(hipMemsetAsync(counts, 0, (size_t)S * 8, st));
-        rc = build_s1_table(q, N, S, ws, &T64, &T32, st);
-        if (rc) return rc;
+        return EPG_OK;
     }
-    if (R == 0) return EPG_OK;
-    return launch_score_s1_from_hist(H, R, N, S, T64, T32, out64, out32, st);
+    return launch_score_s1_from_hist(H, R, N, S, T64, T32, out64, out32, st, rezero ? reinterpret_cast<u64*>(counts) : nullptr);
 }
 
 int score_s1_impl(const int8_t* X8, int64_t R, int32_t N, int64_t ldx, int32_t S, const float* q, double* out64,
