@@ -31,7 +31,7 @@
 //    share them in L2 (PMC: 81 % hits, 27 GB from memory per 1 M bins).
 //  * epilogue: the 32 lanes of a half wave hold one bin's sums for 32 biosamples; they are added up per (bin, state) in LDS
 //    first (see there).
-//  Measured at N = 833, S = 18, 1 M bins: 79 ms (k_s3_score 98).  Per a and workgroup the LDS pipe is busy 0.81 us with
+//  Measured at N = 833, S = 18, 1 M bins: 84 ms (k_s3_score 98).  Per a and workgroup the LDS pipe is busy 0.81 us with
 //  gathers and 0.16 us with the 43 KiB the loader streams in, 0.97 of the measured 1.03 us: the kernel is LDS bound, and what
 //  is left above that is table loads that miss L2 (+ 3 ms) and the epilogue.
 #include "epg_common.h"
