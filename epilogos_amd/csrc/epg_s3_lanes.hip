@@ -12,7 +12,8 @@
 //  * a lane is a BIOSAMPLE b (32 consecutive b per half wave), a half wave is one bin at a time.  x_a is then the same for
 //    the 32 lanes of a gather and only x_b differs, and with the table chunk of (a, 32 b) laid out [x_b][b][x_a] with an ODD
 //    number SI >= S + 1 of dwords per (x_b, b) the bank of lane l is (SI * l + x_a) mod 32: a bijection of l, whatever the
-//    states are.  Every gather is conflict free by construction (PMC: SQ_LDS_BANK_CONFLICT = 0).
+//    states are.  Every gather is conflict free by construction (PMC: SQ_LDS_BANK_CONFLICT is 2 % of
+//    SQ_LDS_IDX_ACTIVE, the epilogue's same-address adds; 45 % in k_s3_score).
 //  * the table is stored as 32-bit FIXED POINT in units of max|T| * N / 2^31: the N terms of one (bin, b) add up in a plain
 //    int32 without overflow, integer adds are exact and commute (bit-identical scores for any launch geometry, like the
 //    64-bit cells they are added to), and the only error is the rounding of a table entry, <= unit / 2 ~ 7e-12 absolute at
@@ -28,7 +29,7 @@
 //    sixteenth wave of the workgroup; the other fifteen gather): vmcnt counts in order, so when the gather waves issued
 //    the table loads themselves every wait for state bytes was also a wait for the table (106 ms per 1 M bins).  One raw
 //    barrier per a.  Workgroups are ordered with the bin slice fastest, so the ~256 resident ones walk the same chunks and
-//    share them in L2 (PMC: 81 % hits, 27 GB from memory per 1 M bins).
+//    share them in L2 (PMC: 91 % hits, 27 GB from memory per 1 M bins).
 //  * epilogue: the 32 lanes of a half wave hold one bin's sums for 32 biosamples; they are added up per (bin, state) in LDS
 //    first (see there).
 //  Measured at N = 833, S = 18, 1 M bins: 84 ms (k_s3_score 98).  Per a and workgroup the LDS pipe is busy 0.81 us with
