@@ -32,9 +32,9 @@
 //    share them in L2 (PMC: 91 % hits, 27 GB from memory per 1 M bins).
 //  * epilogue: the 32 lanes of a half wave hold one bin's sums for 32 biosamples; they are added up per (bin, state) in LDS
 //    first (see there).
-//  Measured at N = 833, S = 18, 1 M bins: 84 ms (k_s3_score 98).  Per a and workgroup the LDS pipe is busy 0.81 us with
-//  gathers and 0.16 us with the 43 KiB the loader streams in, 0.97 of the measured 1.03 us: the kernel is LDS bound, and what
-//  is left above that is table loads that miss L2 (+ 3 ms) and the epilogue.
+//  Measured at N = 833, S = 18, 1 M bins: 76.3 ms (k_s3_score 98.4).  Per a and workgroup the LDS pipe is busy 0.81 us with
+//  gathers and 0.16 us with the 43 KiB the loader streams in, a barrier costs ~0.1 us, and a phase takes 1.19 us: the
+//  kernel is LDS bound (EPG_S3_DBG: gathers alone 58 ms, the table stream alone 38 ms, barriers and epilogue alone 9 ms).
 #include "epg_common.h"
 
 #include <stdlib.h>
@@ -160,19 +160,24 @@ __device__ __forceinline__ void bl_issue(u32 (&t)[8], const u32 (&xbo)[BL_BW / 2
 }
 
 // one a of a gather wave: 48 gathers per half wave from LDS buffer PH, software-pipelined by hand over two sets of eight
-// registers, and the state bytes of the next a into the registers of this one as soon as their gathers are issued
+// registers, and the state bytes of the next a into the registers of this one as soon as their gathers are issued.
+// The pipeline runs THROUGH the barrier: the last four gathers of a phase (t1[4..7]) are still in flight when the wave
+// arrives, and are accumulated after the first block of the next phase has been issued -- with the LDS queue drained and
+// refilled at every barrier a phase cost ~150 cycles more.  (Those four reads were queued before the barrier; what the
+// loader sends into their buffer afterwards is a round trip to L2 behind them.)
 template <int PH>
 __device__ __forceinline__ void bl_phase(const char* __restrict__ xs_next, u32 xoff, const u32 (&xbo)[BL_BW / 2], u32x4 (&xa)[BL_BW / 16],
-                                         int (&acc)[BL_BW], int dbg) {
+                                         int (&acc)[BL_BW], u32 (&t1)[8], int dbg) {
     constexpr int BUF = PH * BL_BUF1;
     static_assert(BL_BW == 48, "six blocks of eight bins, three dwordx4 of states");
-    u32 t0[8], t1[8];
+    u32 t0[8];
     if (dbg & 4) {                                                  // measurement: no gathers, no state loads
         __builtin_amdgcn_s_barrier();
         return;
     }
     bl_wait_vm<2>(xa[0]);
     bl_issue<BUF, 0>(t0, xbo, xa);
+    bl_consume4<8, 1>(acc + 40, t1);                                // the previous phase's last four (zeros before the first)
     bl_consume4<4, 0>(acc, t0);
     bl_issue<BUF, 1>(t1, xbo, xa);
     bl_load_x<0>(xa[0], xs_next, xoff);                             // the same 16 bins of the next a
@@ -194,14 +199,17 @@ __device__ __forceinline__ void bl_phase(const char* __restrict__ xs_next, u32 x
     bl_load_x<32>(xa[2], xs_next, xoff);
     bl_consume4<8, 1>(acc + 32, t0);
     bl_consume4<4, 0>(acc + 40, t1);
-    bl_consume4<0, 1>(acc + 40, t1);
     __builtin_amdgcn_s_barrier();
 }
 
 // The loader's side of a phase: one chunk -> an LDS buffer, NP loads of 1 KiB whatever the chunk size (pieces past the end
 // repeat the last one).  A chunk has ONE phase to land: there are two buffers, because the span of three is out of reach of
-// the 16-bit ds_read immediate.  (Tried: the loader also touching one dword of every line of the chunk two phases ahead,
-// so that the request finds it in L2 -- 87.3 against 84.0 ms per call, dropped.)
+// the 16-bit ds_read immediate.  That is enough when its lines are in L2 and not when they come from memory (9 % of the
+// requests did, and the kernel ran at the pace of the slowest of a chunk's 43 loads: 1.31 us per a with 0.81 us of gathers).
+// So ONE workgroup per XCD and chunk -- the one whose rank among the workgroups of its XCD equals the chunk index mod 32 --
+// touches one dword of every 128-byte line of the chunk `ahead` phases before it is due: the 32 workgroups that share an L2
+// walk the chunks together, so all of them then find it there.  (Every workgroup touching every chunk two phases ahead
+// doubled the L2 traffic and was slower than no touch at all.)
 template <int NP>
 __device__ __forceinline__ void bl_request(const char* __restrict__ tq_a, u32 loff, int npieces, char* dst) {
 #pragma unroll
@@ -211,30 +219,56 @@ __device__ __forceinline__ void bl_request(const char* __restrict__ tq_a, u32 lo
                                          (__attribute__((address_space(3))) void*)(dst + p * 1024), 16, 0, 0);
     }
 }
+template <int NPF>
+__device__ __forceinline__ void bl_touch(u32 (&sink)[NPF], const char* __restrict__ tq_a, u32 toff, u32 tmax) {
+#pragma unroll
+    for (int r = 0; r < NPF; ++r) {
+        u32 o = toff + (u32)r * 8192u;
+        o = o < tmax ? o : tmax;
+        // "+v": the register stays this variable's from the first touch to the final wait -- as a plain output the compiler
+        // may hand the register of the PREVIOUS touch, whose load is still in flight, to something else
+        asm volatile("global_load_dword %0, %1, %2" : "+v"(sink[r]) : "v"(o), "s"(tq_a));
+    }
+}
 
 template <int NP>
 __global__ __launch_bounds__(BL_THREADS) void k_s3_score_bl(const char* __restrict__ XT4, long Rp, long R, int N, int S, int SI, int chb,
-                                                            const char* __restrict__ TQ, int nslices, u64* __restrict__ cells, int dbg) {
+                                                            const char* __restrict__ TQ, int nslices, u64* __restrict__ cells, int ahead,
+                                                            int dbg) {
     extern __shared__ __attribute__((aligned(1024))) char tab[];
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int c = blockIdx.x / nslices;
     const long slice0 = (long)(blockIdx.x - c * nslices) * BL_SLICE;
+    // the gathers address LDS by absolute offsets (immediates 0 and BL_BUF1): the dynamic segment must start at 0
+    if ((u32)(size_t)(__attribute__((address_space(3))) char*)tab != 0u) __builtin_trap();
 
     if (wv == BL_GW) {
         // ---- loader wave
+        constexpr int NPF = (NP + 7) / 8;
         const char* tq = TQ + (long)c * N * chb;
         const long tstride = (dbg & 1) ? 0 : chb;                        // measurement: every phase loads the chunk of a = 0
-        const u32 loff = (u32)lane * 16u;
+        const u32 loff = (u32)lane * 16u, toff = (u32)lane * 128u, tmax = (u32)chb - 128u;
         const int npieces = chb >> 10;
+        const int rank = (int)(blockIdx.x >> 3) & 31;                    // workgroups are dealt to the 8 XCDs round robin
+        u32 sink[NPF];
+#pragma unroll
+        for (int r = 0; r < NPF; ++r) sink[r] = 0;
         bl_request<NP>(tq, loff, npieces, tab);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         for (int a = 0; a < N; ++a) {
             const int a1 = a + 1 < N ? a + 1 : N - 1;                    // past the end: a valid chunk nobody reads
             if (!(dbg & 2)) bl_request<NP>(tq + a1 * tstride, loff, npieces, tab + ((a + 1) & 1) * BL_BUF1);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // chunk a + 1 has landed
+            if (ahead > 0 && ((a + ahead) & 31) == rank && a + ahead < N) {
+                bl_touch<NPF>(sink, tq + (a + ahead) * tstride, toff, tmax);   // younger than the request: it does not wait for them
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPF) : "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // chunk a + 1 has landed
+            }
             __builtin_amdgcn_s_barrier();
         }
+#pragma unroll
+        for (int r = 0; r < NPF; ++r) asm volatile("s_waitcnt vmcnt(0)" : "+v"(sink[r])::"memory");
     } else {
         // ---- gather waves
         const int l = lane & 31, h = lane >> 5;
@@ -270,16 +304,20 @@ __global__ __launch_bounds__(BL_THREADS) void k_s3_score_bl(const char* __restri
         bl_load_x<32>(xa[2], xs, xoff);
         __builtin_amdgcn_s_barrier();
 
+        u32 t1[8];                                                      // the gathers in flight across a barrier
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t1[k] = 0;
         for (int a = 0; a < N; a += 2) {
             {
                 const int an = a + 1 < N ? a + 1 : a;                   // past the end: valid addresses, results unused
-                bl_phase<0>(xs + (long)an * Rp, xoff, xbo, xa, acc, dbg);
+                bl_phase<0>(xs + (long)an * Rp, xoff, xbo, xa, acc, t1, dbg);
             }
             if (a + 1 < N) {
                 const int an = a + 2 < N ? a + 2 : a + 1;
-                bl_phase<1>(xs + (long)an * Rp, xoff, xbo, xa, acc, dbg);
+                bl_phase<1>(xs + (long)an * Rp, xoff, xbo, xa, acc, t1, dbg);
             }
         }
+        if (!(dbg & 4)) bl_consume4<0, 1>(acc + 40, t1);
         // the state loads of the clamped "next a" are still landing in xa: keep those registers until they have
         asm volatile("s_waitcnt vmcnt(0)" : "+v"(xa[0]), "+v"(xa[1]), "+v"(xa[2])::"memory");
 
@@ -370,12 +408,13 @@ int score_s3_lanes(const int8_t* X8, int64_t R, int32_t N, int64_t ldx, int32_t 
     if (shmem < red) shmem = red;
     // EPG_S3_DBG (measurements only, results are wrong): 1 = every phase loads the same chunk, 2 = no table loads, 4 = no gathers
     static const int dbg = [] { const char* e = getenv("EPG_S3_DBG"); return e ? atoi(e) : 0; }();
+    static const int ahead = [] { const char* e = getenv("EPG_S3_AHEAD"); return e ? atoi(e) : 6; }();   // phases between touch and use
     const int npieces = chb >> 10;                                        // 1 .. 53 for S <= 20; 32 at S = 15, 43 at S = 18
 #define BL_LAUNCH(NP)                                                                                                            \
     do {                                                                                                                         \
         EPG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_s3_score_bl<NP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem)); \
         hipLaunchKernelGGL(k_s3_score_bl<NP>, dim3((unsigned)(nslices * nchunk)), dim3(BL_THREADS), shmem, st, XT, Rp, (long)R, N, S, SI, chb, \
-                           reinterpret_cast<const char*>(TQ), (int)nslices, reinterpret_cast<u64*>(acc), dbg);                    \
+                           reinterpret_cast<const char*>(TQ), (int)nslices, reinterpret_cast<u64*>(acc), ahead, dbg);             \
     } while (0)
     if (npieces <= 16) BL_LAUNCH(16);
     else if (npieces <= 32) BL_LAUNCH(32);
