@@ -34,7 +34,7 @@
 //    first (see there).
 //  Measured at N = 833, S = 18, 1 M bins: 76.3 ms (k_s3_score 98.4).  Per a and workgroup the LDS pipe is busy 0.81 us with
 //  gathers and 0.16 us with the 43 KiB the loader streams in, a barrier costs ~0.1 us, and a phase takes 1.19 us: the
-//  kernel is LDS bound (EPG_S3_DBG: gathers alone 58 ms, the table stream alone 38 ms, barriers and epilogue alone 9 ms).
+//  kernel is LDS bound (EPG_S3_SCORE_DBG: gathers alone 58 ms, the table stream alone 38 ms, barriers and epilogue alone 9 ms).
 #include "epg_common.h"
 
 #include <stdlib.h>
@@ -406,8 +406,8 @@ int score_s3_lanes(const int8_t* X8, int64_t R, int32_t N, int64_t ldx, int32_t 
     size_t shmem = (size_t)BL_BUF1 + chb;
     const size_t red = (size_t)BL_GW * 2 * BL_EB * S * 8;
     if (shmem < red) shmem = red;
-    // EPG_S3_DBG (measurements only, results are wrong): 1 = every phase loads the same chunk, 2 = no table loads, 4 = no gathers
-    static const int dbg = [] { const char* e = getenv("EPG_S3_DBG"); return e ? atoi(e) : 0; }();
+    // EPG_S3_SCORE_DBG (measurements only, results are wrong): 1 = every phase loads the same chunk, 2 = no table loads, 4 = no gathers
+    static const int dbg = [] { const char* e = getenv("EPG_S3_SCORE_DBG"); return e ? atoi(e) : 0; }();
     static const int ahead = [] { const char* e = getenv("EPG_S3_AHEAD"); return e ? atoi(e) : 6; }();   // phases between touch and use
     const int npieces = chb >> 10;                                        // 1 .. 53 for S <= 20; 32 at S = 15, 43 at S = 18
 #define BL_LAUNCH(NP)                                                                                                            \

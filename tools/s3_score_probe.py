@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Times the S3 score call alone (kernel + table build + transpose) at N = 833, S = 18 for a list of EPG_S3_DBG values --
+"""Times the S3 score call alone (kernel + table build + transpose) at N = 833, S = 18 for a list of EPG_S3_SCORE_DBG values --
 each in a child process, because the library reads the variable once.  usage: s3_score_probe.py [--bins 1048576] [--dbg 0,1,2,4,6]"""
 import argparse
 import os
@@ -15,9 +15,9 @@ ap.add_argument("--child", action="store_true")
 a = ap.parse_args()
 if not a.child:
     for d in a.dbg.split(","):
-        env = dict(os.environ, EPG_S3_DBG=d)
+        env = dict(os.environ, EPG_S3_SCORE_DBG=d)
         r = subprocess.run([sys.executable, __file__, "--child", "--bins", str(a.bins)], env=env, capture_output=True, text=True)
-        print("EPG_S3_DBG=%s: %s" % (d, (r.stdout.strip().splitlines() or [r.stderr[-400:]])[-1]), flush=True)
+        print("EPG_S3_SCORE_DBG=%s: %s" % (d, (r.stdout.strip().splitlines() or [r.stderr[-400:]])[-1]), flush=True)
     sys.exit(0)
 sys.path.insert(0, str(ROOT))
 import torch  # noqa: E402
