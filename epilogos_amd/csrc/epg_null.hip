@@ -155,40 +155,81 @@ __global__ __launch_bounds__(256) void k_null_hist_h(const u16* __restrict__ HA,
         if (lane < rows) {
             u16* pa = reinterpret_cast<u16*>(sa + lane * rowb);
             u16* pb = reinterpret_cast<u16*>(sb + lane * rowb);
-            // the most frequent state (first of equals) and the number of columns that hold a state
+            // combined counts into pa (pb becomes the zeroed output row), the most frequent state (first of equals) and the
+            // number of columns that hold a state
             u32 tot = 0, best = 0;
             int modal = 0;
             for (int s = 0; s < S; ++s) {
                 const u32 h = (u32)pa[s] + pb[s];
+                pa[s] = (u16)h;
+                pb[s] = 0;
                 tot += h;
                 if (h > best) { best = h; modal = s; }
             }
-            u32 needA = (u32)ga, needB = (u32)gb, rem = (u32)n_cols;
+            // ONE flat loop over the columns that are drawn -- every state but the modal one, then the columns without a state
+            // -- so that the 64 rows of a wave run n - max h steps each (209 +- 12 on chr1-like rows) instead of the sum over
+            // the categories of the wave's largest count.  A draw takes ONE BYTE of Philox output: with u in [byte, byte + 1) / 256
+            // the column joins A if (byte + 1) rem <= 256 needA, B if byte rem >= 256 needA and (byte + 1) rem <= 256 (needA +
+            // needB), neither if byte rem >= 256 (needA + needB); in the remaining ~2 of 256 cases 32 more bits from a second
+            // stream decide -- the outcome is that of a 40-bit uniform number, 16 draws per Philox call instead of 4.
+            u32 A256 = (u32)ga << 8, AB256 = (u32)(ga + gb) << 8, rem = (u32)n_cols;
+            const u32 ndraw = (u32)n_cols - best;
             const u64 grow = (u64)(row0 + r0 + lane);
-            u32 rnd[4], have = 0, calls = 0;
-            // categories: the states except the modal one, then the columns without a state; the modal state takes the rest
-            for (int s = 0; s <= S; ++s) {
-                if (s == modal) continue;
-                const u32 cnt = s < S ? (u32)pa[s] + pb[s] : (u32)n_cols - tot;
-                u32 inA = 0, inB = 0;
-                for (u32 d = 0; d < cnt && (needA | needB); ++d) {
-                    if (!have) {
-                        rnd[0] = (u32)grow; rnd[1] = (u32)(grow >> 32); rnd[2] = calls++; rnd[3] = 0x6e756c6cu;
-                        philox4x32_10(rnd, (u32)seed, (u32)(seed >> 32));
-                        have = 4;
-                    }
-                    const u32 u = have == 4 ? rnd[0] : (have == 3 ? rnd[1] : (have == 2 ? rnd[2] : rnd[3]));
-                    --have;
-                    const u32 pick = (u32)(((u64)u * rem) >> 32);              // uniform in [0, rem)
-                    const bool a = pick < needA, b = !a && pick < needA + needB;
-                    inA += a; inB += b;
-                    needA -= a; needB -= b;
-                    --rem;
+            u32 r0w = 0, r1w = 0, r2w = 0, r3w = 0, cur = 0, nb = 0, calls = 0;          // main stream: 16 bytes per call
+            u32 a0w = 0, a1w = 0, a2w = 0, a3w = 0, ahave = 0, acalls = 0;               // second stream for the rare ties
+            int s = -1;
+            u32 left = 0, inA = 0, inB = 0;
+            for (u32 d = 0; d < ndraw; ++d) {
+                if (AB256 == 0) break;                                                    // both groups are full: the rest joins neither
+                while (left == 0) {                                                       // next non-empty category
+                    if (s >= 0 && s < S) { pa[s] = (u16)inA; pb[s] = (u16)inB; }
+                    ++s;
+                    if (s == modal) ++s;
+                    left = s < S ? (u32)pa[s] : (u32)n_cols - tot;
+                    inA = 0; inB = 0;
                 }
-                if (s < S) { pa[s] = (u16)inA; pb[s] = (u16)inB; }
+                if ((nb & 3u) == 0) {
+                    if (nb == 0) {
+                        u32 c[4] = {(u32)grow, (u32)(grow >> 32), calls++, 0x6e756c6cu};
+                        philox4x32_10(c, (u32)seed, (u32)(seed >> 32));
+                        r0w = c[0]; r1w = c[1]; r2w = c[2]; r3w = c[3];
+                        nb = 16;
+                    }
+                    cur = r0w; r0w = r1w; r1w = r2w; r2w = r3w;
+                }
+                const u32 byte = cur & 0xffu;
+                cur >>= 8;
+                --nb;
+                const u32 t = byte * rem, hi = t + rem;
+                bool a = hi <= A256;
+                bool b = t >= A256 && hi <= AB256;
+                if (!(a || b || t >= AB256)) {                                            // the byte's interval straddles a boundary
+                    if (ahave == 0) {
+                        u32 c[4] = {(u32)grow, (u32)(grow >> 32), acalls++, 0x74696573u};
+                        philox4x32_10(c, (u32)seed, (u32)(seed >> 32));
+                        a0w = c[0]; a1w = c[1]; a2w = c[2]; a3w = c[3];
+                        ahave = 4;
+                    }
+                    const u64 u40 = ((u64)byte << 32) | a0w;
+                    a0w = a1w; a1w = a2w; a2w = a3w;
+                    --ahave;
+                    const u32 pick = (u32)((u40 * rem) >> 40);                            // uniform in [0, rem)
+                    a = pick < (A256 >> 8);
+                    b = !a && pick < (AB256 >> 8);
+                }
+                inA += a; inB += b;
+                A256 -= a ? 256u : 0u;
+                AB256 -= (a || b) ? 256u : 0u;
+                --rem;
+                --left;
             }
-            pa[modal] = (u16)needA;                                             // what is still missing comes from the last category
-            pb[modal] = (u16)needB;
+            // the category the loop stopped in, the ones it never reached (nothing joins A or B any more), and the modal
+            // state, which takes what is still missing
+            if (s >= 0 && s < S) { pa[s] = (u16)inA; pb[s] = (u16)inB; }
+            for (int z = s + 1; z < S; ++z)
+                if (z != modal) pa[z] = 0;
+            pa[modal] = (u16)(A256 >> 8);
+            pb[modal] = (u16)((AB256 - A256) >> 8);
         }
         __builtin_amdgcn_wave_barrier();
         store_staged(sa, reinterpret_cast<char*>(OA + r0 * S), rows * rowb, lane);
