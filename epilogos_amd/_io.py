@@ -1,6 +1,7 @@
 """ctypes binding of include/epilogos_io.h (native TSV parser + score writer, host side)."""
 import ctypes as C
 import io
+import os
 
 import numpy as np
 
@@ -49,6 +50,8 @@ def load():
     lib.epgio_write_metrics.argtypes = [C.c_char_p, p, p, p, p, p, p, p, p, p, p, p, i64, i32, i32]
     lib.epgio_format_f5.restype = i64
     lib.epgio_format_f5.argtypes = [p, i64, C.c_char, p, i64]
+    lib.epgio_gzip_fast.restype = i64
+    lib.epgio_gzip_fast.argtypes = [p, i64, p, i64]
     _lib = lib
     return lib
 
@@ -152,7 +155,16 @@ def read_table(path, rows=None, threads=0, ldx=None, alloc=None, with_range=Fals
     return states, Locations(blob, off)
 
 
-def write_scores(path, locations, scores, threads=0, gzip_level=6):
+def default_gzip_level():
+    """0 = the library's own fast compressor (csrc/epg_deflate.h); EPILOGOS_GZIP_LEVEL=1..9 selects zlib."""
+    try:
+        v = int(os.environ.get("EPILOGOS_GZIP_LEVEL", "0"))
+    except ValueError:
+        v = 0
+    return v if 0 <= v <= 9 else 0
+
+
+def write_scores(path, locations, scores, threads=0, gzip_level=None):
     scores = np.ascontiguousarray(scores, dtype=np.float32)
     R, S = scores.shape
     if len(locations) != R:
@@ -160,7 +172,7 @@ def write_scores(path, locations, scores, threads=0, gzip_level=6):
     blob = np.ascontiguousarray(locations.blob)
     off = np.ascontiguousarray(locations.offsets, dtype=np.int64)
     rc = load().epgio_write_scores(str(path).encode(), blob.ctypes.data, off.ctypes.data, scores.ctypes.data, R, S,
-                                   threads, gzip_level)
+                                   threads, default_gzip_level() if gzip_level is None else gzip_level)
     if rc != 0:
         raise EpilogosIOError(_err())
 
@@ -186,7 +198,7 @@ def _string_table(strings):
 
 
 def write_metrics(path, chrom_names, chrom_idx, start, end, state_names, maxdiff, dist, pvals=None, mh=None, threads=0,
-                  gzip_level=6):
+                  gzip_level=None):
     """pairwiseMetrics text (see epilogos_io.h): chrom_names[chrom_idx[r]], start, end, state_names[maxdiff[r] - 1],
     |dist| %.5f, sign [, p %.5e, adjusted p %.5e]."""
     R = len(dist)
@@ -203,9 +215,19 @@ def write_metrics(path, chrom_names, chrom_idx, start, end, state_names, maxdiff
     rc = load().epgio_write_metrics(str(path).encode(), cb.ctypes.data, co.ctypes.data, ci.ctypes.data, st_.ctypes.data, en.ctypes.data,
                                     nb.ctypes.data, no.ctypes.data, md.ctypes.data, di.ctypes.data,
                                     None if pv is None else pv.ctypes.data, None if mv is None else mv.ctypes.data, R, threads,
-                                    gzip_level)
+                                    default_gzip_level() if gzip_level is None else gzip_level)
     if rc != 0:
         raise EpilogosIOError(_err())
+
+
+def gzip_fast(data):
+    """One gzip member of `data` from the library's own DEFLATE compressor (what the writers use at gzip_level 0)."""
+    src = np.frombuffer(bytes(data), dtype=np.uint8)
+    out = np.empty(src.size + src.size // 8 + 1100, dtype=np.uint8)
+    n = load().epgio_gzip_fast(src.ctypes.data if src.size else None, src.size, out.ctypes.data, out.size)
+    if n < 0:
+        raise EpilogosIOError(_err())
+    return out[:n].tobytes()
 
 
 def format_f5(values, sep="\t"):

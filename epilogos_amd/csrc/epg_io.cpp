@@ -1,6 +1,7 @@
 // libepilogos_io.so -- native TSV(.gz) parser and "%.5f"/gzip writer (host C++17, zlib + std::thread).
 // Contract: include/epilogos_io.h.
 #include "epilogos_io.h"
+#include "epg_deflate.h"
 
 #include <cmath>
 #include <ctime>
@@ -397,37 +398,59 @@ inline char* fmt_f5(float f, char* o) {
     }
     const uint64_t m = ex ? (man | 0x800000u) : man;
     const int e = ex ? ex - 150 : -149;
-    unsigned __int128 q;
+    uint64_t q64 = 0;
+    bool wide = false;
+    unsigned __int128 q = 0;
     if (e >= 0) {
         if (e > 80) { return o + sprintf(o, "%.5f", (double)f); }
-        q = ((unsigned __int128)(m * 100000ull)) << e;
+        if (e <= 22) q64 = (m * 100000ull) << e;                // < 2^41 * 2^22: fits
+        else { q = ((unsigned __int128)(m * 100000ull)) << e; wide = true; }
     } else {
         const int sh = -e;
         const uint64_t num = m * 100000ull;                 // < 2^41
         if (sh >= 64) {
-            q = 0;                                          // num < 2^41 <= half of 2^sh: rounds to 0
+            q64 = 0;                                        // num < 2^41 <= half of 2^sh: rounds to 0
         } else {
             uint64_t qq = num >> sh;
             const uint64_t rem = num & ((1ull << sh) - 1), half = 1ull << (sh - 1);
             if (rem > half || (rem == half && (qq & 1))) ++qq;
-            q = qq;
+            q64 = qq;
         }
     }
     if (neg) *o++ = '-';
-    const uint64_t frac = (uint64_t)(q % 100000u);
-    unsigned __int128 ip = q / 100000u;
-    char tmp[48];
-    int n = 0;
-    if (ip == 0) tmp[n++] = '0';
-    while (ip) { tmp[n++] = (char)('0' + (int)(ip % 10)); ip /= 10; }
-    while (n) *o++ = tmp[--n];
+    uint64_t frac;
+    if (!wide) {                                            // every score this code has seen: 64-bit division, no __udivti3
+        frac = q64 % 100000u;
+        uint64_t ip = q64 / 100000u;
+        if (ip < 10) {
+            *o++ = (char)('0' + (int)ip);
+        } else {
+            char tmp[24];
+            int n = 0;
+            while (ip) { tmp[n++] = (char)('0' + (int)(ip % 10)); ip /= 10; }
+            while (n) *o++ = tmp[--n];
+        }
+    } else {
+        frac = (uint64_t)(q % 100000u);
+        unsigned __int128 ip = q / 100000u;
+        char tmp[48];
+        int n = 0;
+        if (ip == 0) tmp[n++] = '0';
+        while (ip) { tmp[n++] = (char)('0' + (int)(ip % 10)); ip /= 10; }
+        while (n) *o++ = tmp[--n];
+    }
     *o++ = '.';
     o[4] = (char)('0' + frac % 10); o[3] = (char)('0' + frac / 10 % 10); o[2] = (char)('0' + frac / 100 % 10);
     o[1] = (char)('0' + frac / 1000 % 10); o[0] = (char)('0' + frac / 10000 % 10);
     return o + 5;
 }
 
+// level 1..9: zlib; level 0: the writer's own fast compressor (epg_deflate.h)
 bool gzip_member(const std::vector<char>& in, int level, std::vector<unsigned char>& out) {
+    if (level == 0) {
+        epgdeflate::gzip_member_fast(reinterpret_cast<const unsigned char*>(in.data()), in.size(), out);
+        return true;
+    }
     z_stream zs;
     memset(&zs, 0, sizeof(zs));
     if (deflateInit2(&zs, level, Z_DEFLATED, 15 + 16, 8, Z_DEFAULT_STRATEGY) != Z_OK) return false;
@@ -490,6 +513,14 @@ int epgio_parse_locations(const char* loc, const int64_t* loc_off, int64_t R, in
     return 0;
 }
 
+int64_t epgio_gzip_fast(const void* in, int64_t n, void* out, int64_t cap) {
+    if (n < 0 || (n > 0 && !in) || !out || cap < n + n / 8 + 1100) return fail("gzip_fast: bad argument");
+    std::vector<unsigned char> z;
+    epgdeflate::gzip_member_fast(static_cast<const unsigned char*>(in), (size_t)n, z);
+    memcpy(out, z.data(), z.size());
+    return (int64_t)z.size();
+}
+
 int64_t epgio_format_f5(const float* v, int64_t n, char sep, char* buf, int64_t cap) {
     if (cap < 48 * n) return fail("format_f5: buffer too small");
     char* o = buf;
@@ -500,7 +531,7 @@ int64_t epgio_format_f5(const float* v, int64_t n, char sep, char* buf, int64_t 
 int epgio_write_scores(const char* path, const char* loc, const int64_t* loc_off, const float* scores, int64_t R, int32_t S,
                        int32_t threads, int32_t gzip_level) {
     if (!path || (R > 0 && (!loc || !loc_off || !scores)) || S < 1) return fail("write_scores: bad argument");
-    if (gzip_level < 1 || gzip_level > 9) gzip_level = 6;
+    if (gzip_level < 0 || gzip_level > 9) gzip_level = 6;
     FILE* f = fopen(path, "wb");
     if (!f) return fail("cannot create %s", path);
     const int T = n_threads(threads);
@@ -545,7 +576,7 @@ int epgio_write_scores(const char* path, const char* loc, const int64_t* loc_off
 int epgio_write_states(const char* path, const char* chrom, int64_t start0, int64_t step, const int8_t* states, int64_t R, int32_t N,
                        int64_t ldx, int32_t threads, int32_t gzip_level) {
     if (!path || !chrom || (R > 0 && !states) || N < 1 || ldx < N || step < 1) return fail("write_states: bad argument");
-    if (gzip_level < 1 || gzip_level > 9) gzip_level = 6;
+    if (gzip_level < 0 || gzip_level > 9) gzip_level = 6;
     FILE* f = fopen(path, "wb");
     if (!f) return fail("cannot create %s", path);
     const bool gz = ends_with_gz(path);
@@ -607,7 +638,7 @@ int epgio_write_metrics(const char* path, const char* chrom, const int64_t* chro
     if (!path || (R > 0 && (!chrom || !chrom_off || !chrom_idx || !start || !end || !names || !names_off || !maxdiff || !dist)) ||
         ((pvals == nullptr) != (mh == nullptr)))
         return fail("write_metrics: bad argument");
-    if (gzip_level < 1 || gzip_level > 9) gzip_level = 6;
+    if (gzip_level < 0 || gzip_level > 9) gzip_level = 6;
     FILE* f = fopen(path, "wb");
     if (!f) return fail("cannot create %s", path);
     const int T = n_threads(threads);

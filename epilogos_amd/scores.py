@@ -77,9 +77,9 @@ def writeScores(dataArr, outputTxtPath, locationArr, gzip_level=None):
     the reference's [rows, 3] object array."""
     if not isinstance(locationArr, _io.Locations):
         locationArr = _io.Locations.from_object_array(locationArr)
-    if gzip_level is None:          # 6 by default (the reference's gzip.open default is 9: 3 % smaller, 5x the time); EPILOGOS_GZIP_LEVEL overrides
-        import os
-        gzip_level = int(os.environ.get("EPILOGOS_GZIP_LEVEL", "6"))
+    # gzip_level None: EPILOGOS_GZIP_LEVEL, by default 0 = the library's own compressor (csrc/epg_deflate.h), ~5x the speed of
+    # zlib level 6 for files 4-12 % larger -- writing the text is most of a whole-genome run; 1..9 select zlib (the reference's
+    # gzip.open default is level 9: 3 % smaller than 6, five times its time)
     _io.write_scores(outputTxtPath, locationArr, np.asarray(dataArr, dtype=np.float32), gzip_level=gzip_level)
 
 

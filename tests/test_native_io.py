@@ -168,3 +168,56 @@ def test_binary_input_cache(tmp_path, monkeypatch):
     os.utime(f, ns=(time.time_ns() + 10**9, time.time_ns() + 10**9))
     assert np.array_equal(helpers.readTable(f)[0], x2)
     assert len(list((tmp_path / "cache").iterdir())) == 8
+
+
+def test_fast_gzip_round_trips():
+    """The writer's own DEFLATE compressor (csrc/epg_deflate.h, gzip_level 0, the default): any inflate must read its
+    members back -- empty input, one byte, incompressible bytes (stored blocks), long runs (length-258 matches at distance
+    1), inputs around the 512 KiB block size, all byte values, Fibonacci-distributed symbols (a Huffman tree deeper than
+    15 bits before it is flattened), repeats beyond the 32 KiB window, and score-like text."""
+    import gzip
+    import zlib
+    rng = np.random.default_rng(1)
+
+    def check(data):
+        z = _io.gzip_fast(data)
+        assert gzip.decompress(z) == data
+        d = zlib.decompressobj(31)
+        assert d.decompress(z) == data and d.eof and d.unused_data == b""
+        return len(z)
+
+    assert check(b"") <= 20 and check(b"a") <= 24
+    assert check(bytes(3_000_000)) < 4000
+    n = check(rng.integers(0, 256, 1_000_000, dtype=np.uint8).tobytes())
+    assert 1_000_000 <= n <= 1_000_200                                   # stored: five bytes per 65535
+    for size in (5, 6, 7, 8, 9, 15, 16, 17, 258, 259, (1 << 19) - 1, 1 << 19, (1 << 19) + 1, (1 << 20) + 3):
+        check((b"0.00000\t0.12345\t" * (size // 16 + 1))[:size])
+        check(rng.integers(48, 58, size, dtype=np.uint8).tobytes())
+    fib = [1, 1]
+    while len(fib) < 30:
+        fib.append(fib[-1] + fib[-2])
+    data = np.frombuffer(b"".join(bytes([i + 1]) * f for i, f in enumerate(fib)), dtype=np.uint8)
+    assert check(bytes(rng.permutation(data))) < data.size
+    blk = rng.integers(0, 256, 40000, dtype=np.uint8).tobytes()
+    check(blk + bytes(40000) + blk + blk)
+    vals = (rng.random((20000, 18)) ** 6 * 2).astype(np.float32)
+    text = b"".join(b"chr1\t%d\t%d\t" % (200 * r, 200 * r + 200) + _io.format_f5(vals[r]).rstrip(b"\t") + b"\n" for r in range(len(vals)))
+    assert check(text) < 0.40 * len(text)
+
+
+def test_writer_levels_agree(tmp_path):
+    """gzip_level 0 (own compressor), 1 and 6 (zlib) hold the same text; EPILOGOS_GZIP_LEVEL picks the default."""
+    import gzip
+    rng = np.random.default_rng(2)
+    R = 70000                                                              # three members of 32768 rows
+    sc = (rng.random((R, S)) ** 4).astype(np.float32)
+    blob = "".join("chr2\t%d\t%d\n" % (200 * r, 200 * r + 200) for r in range(R)).encode()
+    off = np.zeros(R + 1, dtype=np.int64)
+    np.cumsum([len(l) + 1 for l in blob.decode().split("\n")[:-1]], out=off[1:])
+    loc = _io.Locations(np.frombuffer(blob, dtype=np.uint8).copy(), off)
+    texts = []
+    for lvl in (0, 1, 6, None):
+        _io.write_scores(tmp_path / "s.gz", loc, sc, gzip_level=lvl)
+        texts.append(gzip.open(tmp_path / "s.gz", "rb").read())
+    assert texts[0] == texts[1] == texts[2] == texts[3] and texts[0].count(b"\n") == R
+    assert _io.default_gzip_level() == 0
