@@ -2,6 +2,7 @@
 // Contract: include/epilogos_io.h.
 #include "epilogos_io.h"
 #include "epg_deflate.h"
+#include "epg_inflate.h"
 
 #include <cmath>
 #include <ctime>
@@ -77,6 +78,78 @@ struct Text {
 
 bool is_gzip(const unsigned char* p, size_t n) { return n >= 18 && p[0] == 0x1f && p[1] == 0x8b; }
 
+// gzip members of in[0, flen) -> t.heap through epginflate, then ISIZE and CRC-32 of every member (the CRCs in parallel:
+// zlib's crc32 runs at ~1 GB/s, a third of what the inflate itself takes on one core).  false = use zlib instead.
+bool inflate_own(const unsigned char* in, size_t flen, size_t cap_hint, Text& t) {
+    struct Member { size_t out0, out1; uint32_t crc, isize; };
+    std::vector<Member> members;
+    epginflate::Out out{nullptr, 0, cap_hint};
+    t.heap = (char*)malloc(cap_hint + 320 + 16);
+    if (!t.heap) return false;
+    out.base = (unsigned char*)t.heap;
+    auto grow = [&](size_t min_cap) {
+        size_t ncap = out.cap + out.cap / 2 + (1u << 24);
+        if (ncap < min_cap) ncap = min_cap + (1u << 24);
+        char* nh = (char*)realloc(t.heap, ncap + 320 + 16);
+        if (!nh) return false;
+        t.heap = nh;
+        out.base = (unsigned char*)nh;
+        out.cap = ncap;
+        return true;
+    };
+    size_t pos = 0;
+    while (pos < flen && is_gzip(in + pos, flen - pos)) {
+        const unsigned char* h = in + pos;
+        if (h[2] != 8 || (h[3] & 0xe0)) return false;
+        size_t hp = pos + 10;
+        const int flg = h[3];
+        if (flg & 4) { if (hp + 2 > flen) return false; hp += 2 + ((size_t)in[hp] | ((size_t)in[hp + 1] << 8)); }
+        if (flg & 8) { while (hp < flen && in[hp]) ++hp; ++hp; }
+        if (flg & 16) { while (hp < flen && in[hp]) ++hp; ++hp; }
+        if (flg & 2) hp += 2;
+        if (hp + 8 > flen) return false;
+        const size_t out0 = out.pos;
+        const size_t used = epginflate::inflate_raw(in + hp, flen - hp - 8, out, grow);
+        if (!used) return false;
+        const unsigned char* tr = in + hp + used;
+        Member m;
+        m.out0 = out0; m.out1 = out.pos;
+        m.crc = (uint32_t)tr[0] | (uint32_t)tr[1] << 8 | (uint32_t)tr[2] << 16 | (uint32_t)tr[3] << 24;
+        m.isize = (uint32_t)tr[4] | (uint32_t)tr[5] << 8 | (uint32_t)tr[6] << 16 | (uint32_t)tr[7] << 24;
+        if ((uint32_t)(m.out1 - m.out0) != m.isize) return false;
+        members.push_back(m);
+        pos = hp + used + 8;
+    }
+    if (members.empty()) return false;
+    // CRC-32: pieces of <= 32 MiB over the threads, stitched per member with crc32_combine
+    struct Piece { size_t off, len; uint32_t crc; };
+    std::vector<Piece> pieces;
+    std::vector<size_t> first(members.size() + 1, 0);
+    const size_t PIECE = (size_t)32 << 20;
+    for (size_t k = 0; k < members.size(); ++k) {
+        first[k] = pieces.size();
+        for (size_t o = members[k].out0; o < members[k].out1; o += PIECE) pieces.push_back(Piece{o, std::min(PIECE, members[k].out1 - o), 0});
+    }
+    first[members.size()] = pieces.size();
+    const int T = (int)std::max<size_t>(1, std::min<size_t>((size_t)n_threads(0), pieces.size()));
+    std::vector<std::thread> th;
+    for (int w = 0; w < T; ++w)
+        th.emplace_back([&, w] {
+            for (size_t i = (size_t)w; i < pieces.size(); i += (size_t)T)
+                pieces[i].crc = (uint32_t)crc32(crc32(0L, Z_NULL, 0), (const Bytef*)t.heap + pieces[i].off, (uInt)pieces[i].len);
+        });
+    for (auto& x : th) x.join();
+    for (size_t k = 0; k < members.size(); ++k) {
+        uLong crc = crc32(0L, Z_NULL, 0);
+        for (size_t i = first[k]; i < first[k + 1]; ++i) crc = crc32_combine(crc, pieces[i].crc, (z_off_t)pieces[i].len);
+        if ((uint32_t)crc != members[k].crc) return false;
+    }
+    memset(t.heap + out.pos, 0, 16);
+    t.data = t.heap;
+    t.size = out.pos;
+    return true;
+}
+
 bool slurp(const char* path, Text& t) {
     const int fd = open(path, O_RDONLY);
     if (fd < 0) { fail("cannot open %s", path); return false; }
@@ -105,6 +178,13 @@ bool slurp(const char* path, Text& t) {
     size_t cap = (size_t)((uint32_t)in[flen - 4] | (uint32_t)in[flen - 3] << 8 | (uint32_t)in[flen - 2] << 16 | (uint32_t)in[flen - 1] << 24);
     if (cap < flen) cap = flen * 4;                     // ISIZE is the LAST member's size mod 2^32: a hint only
     cap += 64;
+    // The library's own inflate first (epg_inflate.h, ~2-3x zlib's rate); every member's ISIZE and CRC-32 are checked, and on
+    // any doubt the file is read again with zlib below.  EPGIO_INFLATE=zlib skips it.
+    {
+        static const bool use_own = [] { const char* e = getenv("EPGIO_INFLATE"); return !(e && e[0] == 'z'); }();
+        if (use_own && inflate_own(in, flen, cap, t)) return true;
+        if (t.heap) { free(t.heap); t.heap = nullptr; }
+    }
     t.heap = (char*)malloc(cap + 16);
     if (!t.heap) { fail("out of memory reading %s", path); return false; }
     z_stream zs;

@@ -221,3 +221,72 @@ def test_writer_levels_agree(tmp_path):
         texts.append(gzip.open(tmp_path / "s.gz", "rb").read())
     assert texts[0] == texts[1] == texts[2] == texts[3] and texts[0].count(b"\n") == R
     assert _io.default_gzip_level() == 0
+
+
+def _table_text(R=3000, N=12, seed=5, crlf=False):
+    rng = np.random.default_rng(seed)
+    x = rng.integers(1, S + 1, size=(R, N))
+    nl = "\r\n" if crlf else "\n"
+    text = "".join("chr7\t%d\t%d\t" % (200 * r, 200 * r + 200) + "\t".join(map(str, x[r])) + nl for r in range(R)).encode()
+    return x, text
+
+
+def test_own_inflate_reads_what_any_deflate_wrote(tmp_path):
+    """The reader's own inflate (csrc/epg_inflate.h) on members written by zlib at every strategy that changes the block types
+    -- stored (level 0), fixed Huffman (Z_FIXED), dynamic (levels 1, 6, 9), Huffman-only and RLE --, by the library's own
+    compressor, with a file name and a comment in the header, several members in one file, and trailing garbage; every result
+    equals the text, and equals what the zlib path (EPGIO_INFLATE=zlib, exercised through a corrupt CRC below) returns."""
+    import gzip
+    import zlib
+    x, text = _table_text()
+    want = (x - 1).astype(np.int8)
+
+    def member(data, level=6, strategy=zlib.Z_DEFAULT_STRATEGY, header=b""):
+        c = zlib.compressobj(level, zlib.DEFLATED, -15, 8, strategy)
+        raw = c.compress(data) + c.flush()
+        flg = 0
+        extra = b""
+        if header:
+            flg = 8 | 16                                            # FNAME + FCOMMENT
+            extra = header + b"\0" + b"a comment\0"
+        return (b"\x1f\x8b\x08" + bytes([flg]) + b"\0\0\0\0\0\xff" + extra + raw
+                + (zlib.crc32(data) & 0xffffffff).to_bytes(4, "little") + (len(data) & 0xffffffff).to_bytes(4, "little"))
+
+    half = text.index(b"\n", len(text) // 2) + 1
+    files = {
+        "stored": member(text, 0), "fixed": member(text, 6, zlib.Z_FIXED), "l1": member(text, 1), "l9": member(text, 9),
+        "huff": member(text, 6, zlib.Z_HUFFMAN_ONLY), "rle": member(text, 6, zlib.Z_RLE), "own": _io.gzip_fast(text),
+        "named": member(text, 6, header=b"matrix_chr7.txt"),
+        "two": member(text[:half], 6) + member(text[half:], 1, header=b"x"),
+        "garbage": member(text, 6) + b"\0\0\0\0 not a gzip member",
+        "empty_first": member(b"", 6) + member(text, 6),
+    }
+    for name, blob in files.items():
+        p = tmp_path / (name + ".txt.gz")
+        p.write_bytes(blob)
+        st, loc = _io.read_table(p)
+        assert np.array_equal(st, want), name
+        assert len(loc) == len(want)
+
+
+def test_own_inflate_never_trusts_itself(tmp_path):
+    """A wrong CRC-32 or ISIZE, a flipped bit in the DEFLATE data and a truncated file are errors (the fast path hands such a
+    file to zlib, whose verdict is reported), never silently different states."""
+    import zlib
+    x, text = _table_text(R=2000)
+    c = zlib.compressobj(6, zlib.DEFLATED, -15)
+    raw = c.compress(text) + c.flush()
+    head = b"\x1f\x8b\x08\0\0\0\0\0\0\xff"
+    good = head + raw + (zlib.crc32(text) & 0xffffffff).to_bytes(4, "little") + len(text).to_bytes(4, "little")
+    p = tmp_path / "t.txt.gz"
+    p.write_bytes(good)
+    st, _ = _io.read_table(p)
+    assert np.array_equal(st, (x - 1).astype(np.int8))
+    bad_crc = good[:-8] + bytes([good[-8] ^ 1]) + good[-7:]
+    bad_size = good[:-4] + (len(text) + 1).to_bytes(4, "little")
+    flipped = bytearray(good)
+    flipped[len(head) + len(raw) // 2] ^= 0x10
+    for blob in (bad_crc, bad_size, bytes(flipped), good[: len(good) // 2], good[:-9]):
+        p.write_bytes(blob)
+        with pytest.raises(_io.EpilogosIOError):
+            _io.read_table(p)
