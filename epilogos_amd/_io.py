@@ -52,6 +52,10 @@ def load():
     lib.epgio_format_f5.argtypes = [p, i64, C.c_char, p, i64]
     lib.epgio_gzip_fast.restype = i64
     lib.epgio_gzip_fast.argtypes = [p, i64, p, i64]
+    lib.epgio_row_sums_f32.restype = C.c_int
+    lib.epgio_row_sums_f32.argtypes = [p, i64, C.c_int32, i64, p, C.c_int32]
+    lib.epgio_rolling_max_f64.restype = C.c_int
+    lib.epgio_rolling_max_f64.argtypes = [p, i64, C.c_int32, p, C.c_int32]
     _lib = lib
     return lib
 
@@ -218,6 +222,26 @@ def write_metrics(path, chrom_names, chrom_idx, start, end, state_names, maxdiff
                                     default_gzip_level() if gzip_level is None else gzip_level)
     if rc != 0:
         raise EpilogosIOError(_err())
+
+
+def row_sums(scores, threads=0):
+    """scores.sum(axis=1) of a float32 [R, S] matrix with numpy's exact rounding (eight accumulators, tree, remainder)."""
+    a = np.asarray(scores)
+    if a.dtype != np.float32 or a.ndim != 2 or a.shape[1] > 128 or a.shape[1] < 1 or a.strides[1] != 4 or a.strides[0] % 4:
+        return np.asarray(scores).sum(axis=1)
+    out = np.empty(a.shape[0], dtype=np.float32)
+    if load().epgio_row_sums_f32(a.ctypes.data, a.shape[0], a.shape[1], a.strides[0] // 4, out.ctypes.data, threads) != 0:
+        raise EpilogosIOError(_err())
+    return out
+
+
+def rolling_max(x, window, threads=0):
+    """pandas' Series(x).rolling(window, center=True).max() for a float64 vector without NaNs."""
+    v = np.ascontiguousarray(x, dtype=np.float64)
+    out = np.empty(v.size, dtype=np.float64)
+    if load().epgio_rolling_max_f64(v.ctypes.data, v.size, int(window), out.ctypes.data, threads) != 0:
+        raise EpilogosIOError(_err())
+    return out
 
 
 def gzip_fast(data):

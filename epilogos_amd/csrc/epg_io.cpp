@@ -593,6 +593,69 @@ int epgio_parse_locations(const char* loc, const int64_t* loc_off, int64_t R, in
     return 0;
 }
 
+int epgio_row_sums_f32(const float* a, int64_t R, int32_t S, int64_t lda, float* out, int32_t threads) {
+    if (R < 0 || S < 1 || S > 128 || lda < S || (R > 0 && (!a || !out))) return fail("row_sums: bad argument (S must be 1..128)");
+    const int T = (int)std::max<int64_t>(1, std::min<int64_t>(n_threads(threads), (R + 65535) / 65536));
+    std::vector<std::thread> th;
+    for (int t = 0; t < T; ++t)
+        th.emplace_back([&, t] {
+            const int n8 = S - S % 8;
+            for (int64_t r = R * t / T; r < R * (t + 1) / T; ++r) {
+                const float* p = a + r * lda;
+                float res;
+                if (S < 8) {
+                    res = 0.f;
+                    for (int i = 0; i < S; ++i) res += p[i];
+                } else {
+                    float q[8];
+                    for (int j = 0; j < 8; ++j) q[j] = p[j];
+                    for (int i = 8; i < n8; i += 8)
+                        for (int j = 0; j < 8; ++j) q[j] += p[i + j];
+                    res = ((q[0] + q[1]) + (q[2] + q[3])) + ((q[4] + q[5]) + (q[6] + q[7]));
+                    for (int i = n8; i < S; ++i) res += p[i];
+                }
+                out[r] = res;
+            }
+        });
+    for (auto& x : th) x.join();
+    return 0;
+}
+
+int epgio_rolling_max_f64(const double* x, int64_t n, int32_t W, double* out, int32_t threads) {
+    if (n < 0 || W < 1 || (n > 0 && (!x || !out))) return fail("rolling_max: bad argument");
+    const int64_t back = W / 2, fwd = (W - 1) / 2;
+    const double nan = std::nan("");
+    const int T = (int)std::max<int64_t>(1, std::min<int64_t>(n_threads(threads), (n + (1 << 20) - 1) >> 20));
+    std::vector<std::thread> th;
+    for (int t = 0; t < T; ++t)
+        th.emplace_back([&, t] {
+            const int64_t i0 = n * t / T, i1 = n * (t + 1) / T;
+            // monotonic deque of candidate indices (values decreasing; a later equal value replaces an earlier one, like
+            // pandas) over the window [i - back, i + fwd], in a power-of-two ring
+            size_t ring = 1;
+            while (ring < (size_t)W + 1) ring <<= 1;
+            const size_t mask = ring - 1;
+            std::vector<int64_t> dq(ring);
+            size_t head = 0, tail = 0;                               // size = tail - head
+            int64_t next = std::max<int64_t>(0, i0 - back);          // next element to push
+            for (int64_t i = i0; i < i1; ++i) {
+                const int64_t lo = i - back, hi = i + fwd;
+                if (lo < 0 || hi >= n) { out[i] = nan; continue; }
+                if (next < lo) next = lo;
+                for (; next <= hi; ++next) {
+                    const double v = x[next];
+                    while (tail != head && !(x[dq[(tail - 1) & mask]] > v)) --tail;
+                    dq[tail & mask] = next;
+                    ++tail;
+                }
+                while (dq[head & mask] < lo) ++head;
+                out[i] = x[dq[head & mask]];
+            }
+        });
+    for (auto& x_ : th) x_.join();
+    return 0;
+}
+
 int64_t epgio_gzip_fast(const void* in, int64_t n, void* out, int64_t cap) {
     if (n < 0 || (n > 0 && !in) || !out || cap < n + n / 8 + 1100) return fail("gzip_fast: bad argument");
     std::vector<unsigned char> z;

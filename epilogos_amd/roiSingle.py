@@ -14,6 +14,7 @@ from time import time
 import numpy as np
 import pandas as pd
 
+from . import _io
 from .helpers import strToBool
 
 
@@ -54,8 +55,10 @@ def maxMean(chrom, start, end, score, roiWidth, maxRegions, _first_candidates=No
     w_start = np.asarray(start)[orig - h]
     w_end = np.asarray(end)[orig + e_off]
     sc = score[lo:hi]
-    roll = pd.Series(sc).rolling(W, center=True)
-    rmax, rmean = roll.max().to_numpy(), roll.mean().to_numpy()
+    # the rolling MEAN stays pandas' own (an online add/remove sum with compensation: its last bits depend on the whole history,
+    # and they break ties); the rolling MAX is exact in any implementation -- the native one is pandas' deque, threaded
+    rmean = pd.Series(sc).rolling(W, center=True).mean().to_numpy()
+    rmax = _io.rolling_max(sc, W)
     ok = ~np.isnan(rmax)                       # incomplete edge windows
     ok &= ~(np.asarray(w_start, dtype=np.int64) >= np.asarray(w_end, dtype=np.int64))   # windows spanning two chromosomes
     keep = np.nonzero(ok)[0]
@@ -112,16 +115,25 @@ def createTopScoresTxt(filePath, locationArr, scoreArr, nameArr, roiWidth):
     """regionsOfInterest*.txt: chromosome, start, end, largest-scoring state, |sum of scores|, sign
     (reference roiSingle.py:95-142)."""
     W = int(roiWidth)
-    total = scoreArr.sum(axis=1)                                  # float32, numpy's pairwise order like the reference
+    # scoreArr: one [R, S] array, or the per-chromosome arrays in genomic order (a whole genome's scores are 1.1 GB: they are
+    # not concatenated, only their row sums are)
+    parts = list(scoreArr) if isinstance(scoreArr, (list, tuple)) else [scoreArr]
+    total = np.concatenate([_io.row_sums(a) for a in parts])      # float32 with numpy's own rounding (scoreArr.sum(axis=1))
+    bounds = np.cumsum([0] + [len(a) for a in parts])
+
+    def rows(lo, hi):                                             # scoreArr[lo:hi] of the concatenation
+        k0, k1 = np.searchsorted(bounds, lo, side="right") - 1, np.searchsorted(bounds, max(hi - 1, lo), side="right") - 1
+        return np.concatenate([parts[k][max(lo - bounds[k], 0):min(hi - bounds[k], len(parts[k]))] for k in range(k0, k1 + 1)])
+
     # locationArr: the reference's [R, 3] object array, or (chromosome, start, end) columns
     c0, c1, c2 = locationArr if isinstance(locationArr, tuple) else (locationArr[:, 0], locationArr[:, 1], locationArr[:, 2])
     chrom, w_start, w_end, sc, centre = maxMean(c0, c1, c2, total, W, 100)
-    S = scoreArr.shape[1]
+    S = parts[0].shape[1]
     lines = []
     for k in range(len(centre)):
         lo = centre[k] - W // 2
         hi = centre[k] + W // 2 + (1 if W % 2 else 0)
-        win = scoreArr[lo:hi]
+        win = rows(int(lo), int(hi))
         # the state with the largest value anywhere in the window; ties go to the higher state number
         state = S - int(np.argmax(np.max(win[:, ::-1], axis=0)))
         v = float(np.float32(sc[k]))
@@ -136,7 +148,7 @@ def mainFromArrays(results, outputDir, stateInfo, fileTag, expFreqPath, roiWidth
     of temp_scores_*.npz files: same output file, no 170 B/bin round trip through compressed pickles."""
     byChr = {v[0]: v for v in results.values()}
     order = orderChromosomes(list(byChr))
-    scoreArr = np.concatenate([byChr[c][1] for c in order])
+    scoreArr = [byChr[c][1] for c in order]                    # per chromosome, not concatenated (createTopScoresTxt)
     cols = [byChr[c][2].columns() for c in order]              # native parse of the verbatim "chr\tstart\tend" text
     locationArr = tuple(np.concatenate([c[k] for c in cols]) for k in range(3))
     if not verbose: print("    Regions of interest txt\t", end="", flush=True)

@@ -82,6 +82,14 @@ int epgio_write_metrics(const char* path, const char* chrom, const int64_t* chro
  * by `sep`; returns the number of bytes written to buf (cap must be >= 48*n).  Exposed for tests. */
 int64_t epgio_format_f5(const float* v, int64_t n, char sep, char* buf, int64_t cap);
 
+/* STEP 4 helpers (roiSingle.py:100 `scoreArr.sum(axis=1)`, helpers.py:262-266 rolling max of filter_regions):
+ * row sums of a float32 [R, S] matrix (row stride lda) in EXACTLY numpy's order for a contiguous row -- eight running
+ * accumulators over groups of eight, their tree sum, then the remainder, S <= 128 -- so that every total has numpy's bits;
+ * and the centred rolling maximum pandas computes for Series.rolling(W, center=True).max(): out[i] = max x[i - W/2 .. i +
+ * (W - 1)/2], NaN where the window is incomplete.  Both threaded over rows. */
+int epgio_row_sums_f32(const float* a, int64_t R, int32_t S, int64_t lda, float* out, int32_t threads);
+int epgio_rolling_max_f64(const double* x, int64_t n, int32_t W, double* out, int32_t threads);
+
 /* One gzip member (RFC 1952) holding in[0, n), written by the library's own fast DEFLATE compressor (csrc/epg_deflate.h) --
  * what the writers above use at gzip_level 0.  cap must be >= n + n/8 + 1100; returns the member's size, < 0 on error.
  * Replaces Python's gzip.open(..., "wt") of scores.py:523 (zlib level 9).  Exposed for tests. */

@@ -290,3 +290,26 @@ def test_own_inflate_never_trusts_itself(tmp_path):
         p.write_bytes(blob)
         with pytest.raises(_io.EpilogosIOError):
             _io.read_table(p)
+
+
+def test_row_sums_and_rolling_max_have_numpys_and_pandas_bits():
+    """STEP 4 helpers: epgio_row_sums_f32 equals ndarray.sum(axis=1) bit for bit (numpy adds a contiguous float32 row with
+    eight accumulators, their tree sum, then the remainder) for every width up to 128 and for row-strided views;
+    epgio_rolling_max_f64 equals Series.rolling(W, center=True).max() including the NaN edges, for odd and even windows,
+    windows longer than the series, ties, and any thread count."""
+    import pandas as pd
+    rng = np.random.default_rng(0)
+    for width in (1, 3, 7, 8, 9, 15, 16, 17, 18, 25, 31, 40, 127, 128):
+        a = (rng.standard_normal((5000, width)) * rng.random((5000, 1)) * 100).astype(np.float32)
+        assert np.array_equal(a.sum(axis=1), _io.row_sums(a)), width
+        b = np.ascontiguousarray(rng.standard_normal((700, width + 5)).astype(np.float32))[:, :width]
+        assert np.array_equal(b.sum(axis=1), _io.row_sums(b)), width
+    assert np.array_equal(_io.row_sums(np.zeros((0, 18), dtype=np.float32)), np.zeros(0, dtype=np.float32))
+    for W in (50, 7, 10, 125, 3, 2, 1, 64):
+        for n in (0, 1, W - 1, W, W + 1, 1000, 1_200_000):
+            x = rng.standard_normal(n)
+            if n > 10:
+                x[rng.integers(0, n, n // 20)] = 1.5                  # equal maxima
+            want = pd.Series(x).rolling(W, center=True).max().to_numpy()
+            for th in (1, 0):
+                assert np.array_equal(want, _io.rolling_max(x, W, threads=th), equal_nan=True), (W, n, th)
