@@ -272,6 +272,15 @@ def _finish(params, locationArr, distanceArrReal, maxDiffArr, chrDict, stateInfo
     remove(Path(expFreqPath))
 
 
+def _is_location_sorted(chrNum, starts, ends):
+    """True when rows are already in non-decreasing (chromosome, start, end) order -- then the stable lexsort is the identity."""
+    if len(chrNum) < 2:
+        return True
+    c0, c1, s0, s1 = chrNum[:-1], chrNum[1:], starts[:-1], starts[1:]
+    up = (c1 > c0) | ((c1 == c0) & ((s1 > s0) | ((s1 == s0) & (ends[1:] >= ends[:-1]))))
+    return bool(up.all())
+
+
 def mainFromArrays(results, stateInfo, outputDir, fileTag, numProcesses, pvalBool, numTrials, samplingSize, expFreqPath,
                    roiWidth, verbose):
     """main() on the arrays driver.run_paired_groups hands back ({stem: dict(chrName, locations, nullDistances,
@@ -290,11 +299,17 @@ def mainFromArrays(results, stateInfo, outputDir, fileTag, numProcesses, pvalBoo
     cols = [byChr[c]["locations"].columns() for c in chrOrder]
     chrNum = np.concatenate([np.full(len(c[1]), i + 1, dtype=np.int64) for i, c in enumerate(cols)])
     starts, ends = np.concatenate([c[1] for c in cols]), np.concatenate([c[2] for c in cols])
-    order = np.lexsort((ends, starts, chrNum))
-    locationArr = np.stack([chrNum[order], starts[order], ends[order]], axis=1)
     chrDict = {i + 1: c for i, c in enumerate(chrOrder)}
-    _finish(params, locationArr, cat("distances")[order], cat("maxDiff")[order], chrDict, stateInfo, outputDirPath, fileTag, pvalBool,
-            roiWidth, expFreqPath, verbose)
+    dist, maxdiff = cat("distances"), cat("maxDiff")
+    if _is_location_sorted(chrNum, starts, ends):
+        # the usual case -- every file lists its bins in genomic order --: the stable three-key sort of 15 M rows (reference :332,
+        # half of this stage's time at genome scale) is the identity
+        locationArr = np.stack([chrNum, starts, ends], axis=1)
+    else:
+        order = np.lexsort((ends, starts, chrNum))
+        locationArr = np.stack([chrNum[order], starts[order], ends[order]], axis=1)
+        dist, maxdiff = dist[order], maxdiff[order]
+    _finish(params, locationArr, dist, maxdiff, chrDict, stateInfo, outputDirPath, fileTag, pvalBool, roiWidth, expFreqPath, verbose)
 
 
 def main(group1Name, group2Name, stateInfo, outputDir, fileTag, numProcesses, pvalBool, diagnosticBool, numTrials,

@@ -150,3 +150,20 @@ def test_hip_pair_metrics_random_against_oracle():
 def test_step4_through_the_abi(g, tmp_path, pval, sidecar):
     from epilogos_amd import backend
     _check_step4(tmp_path, g, "spiked", pval, sidecar, backend.HipBackend())
+
+
+def test_location_order_shortcut_is_exactly_the_stable_sort():
+    """mainFromArrays skips the three-key lexsort of reference :332 when it would be the identity; the predicate must say so
+    exactly then (ties on all three keys included: the sort is stable)."""
+    from epilogos_amd.roiAndVisualPairwise import _is_location_sorted
+    rng = np.random.default_rng(3)
+    for trial in range(200):
+        n = int(rng.integers(0, 40))
+        c = np.sort(rng.integers(1, 4, n)).astype(np.int64)
+        s = rng.integers(0, 5, n).astype(np.int64) * 200
+        e = s + rng.integers(0, 3, n) * 200
+        if trial % 2 == 0 and n:                                    # make it sorted
+            o = np.lexsort((e, s, c))
+            c, s, e = c[o], s[o], e[o]
+        identity = np.array_equal(np.lexsort((e, s, c)), np.arange(n))
+        assert _is_location_sorted(c, s, e) == identity, (c, s, e)
