@@ -38,7 +38,7 @@ def io_is_stale():
     if not IO_LIB_PATH.exists():
         return True
     t = IO_LIB_PATH.stat().st_mtime
-    return any(f.stat().st_mtime > t for f in (IO_SOURCE, IO_HEADER, CSRC / "epg_deflate.h", CSRC / "epg_inflate.h"))
+    return any(f.stat().st_mtime > t for f in (IO_SOURCE, IO_HEADER, CSRC / "epg_deflate.h", CSRC / "epg_inflate.h", CSRC / "epg_crc32.h"))
 
 
 def build_io_library(force=False, verbose=False):

@@ -14,7 +14,7 @@
 #pragma once
 #include <stdint.h>
 #include <string.h>
-#include <zlib.h>   // crc32() for the gzip trailer
+#include "epg_crc32.h"   // CRC-32 of the gzip trailer
 
 #include <algorithm>
 #include <vector>
@@ -369,13 +369,7 @@ inline void gzip_member_fast(const unsigned char* in, size_t n, std::vector<unsi
     static const unsigned char hdr[10] = {0x1f, 0x8b, 8, 0, 0, 0, 0, 0, 0, 0xff};
     memcpy(out.data(), hdr, 10);
     unsigned char* e = deflate_fast(in, n, out.data() + 10);
-    uint32_t crc = 0;
-    for (size_t off = 0; off < n;) {                                 // crc32() takes a uInt length
-        const size_t k = std::min<size_t>(n - off, 1u << 30);
-        crc = (uint32_t)crc32(off ? crc : crc32(0L, Z_NULL, 0), in + off, (uInt)k);
-        off += k;
-    }
-    if (n == 0) crc = (uint32_t)crc32(0L, Z_NULL, 0);
+    const uint32_t crc = epgcrc::crc32_fast(0, in, n);
     const uint32_t isize = (uint32_t)n;
     memcpy(e, &crc, 4);
     memcpy(e + 4, &isize, 4);

@@ -1,6 +1,7 @@
 // libepilogos_io.so -- native TSV(.gz) parser and "%.5f"/gzip writer (host C++17, zlib + std::thread).
 // Contract: include/epilogos_io.h.
 #include "epilogos_io.h"
+#include "epg_crc32.h"
 #include "epg_deflate.h"
 #include "epg_inflate.h"
 
@@ -78,20 +79,33 @@ struct Text {
 
 bool is_gzip(const unsigned char* p, size_t n) { return n >= 18 && p[0] == 0x1f && p[1] == 0x8b; }
 
-// gzip members of in[0, flen) -> t.heap through epginflate, then ISIZE and CRC-32 of every member (the CRCs in parallel:
-// zlib's crc32 runs at ~1 GB/s, a third of what the inflate itself takes on one core).  false = use zlib instead.
+// Ask for transparent huge pages under a big fresh buffer (the pool runs THP in "madvise" mode): a whole genome's text is 26 GB
+// of first-touch pages, 6.5 M faults of 4 KiB.  Harmless where it is not honoured.
+void advise_huge(void* p, size_t n) {
+#ifdef MADV_HUGEPAGE
+    const uintptr_t a = ((uintptr_t)p + (1u << 21) - 1) & ~(uintptr_t)((1u << 21) - 1), e = ((uintptr_t)p + n) & ~(uintptr_t)((1u << 21) - 1);
+    if (n >= (8u << 20) && e > a) madvise((void*)a, (size_t)(e - a), MADV_HUGEPAGE);
+#else
+    (void)p; (void)n;
+#endif
+}
+
+// gzip members of in[0, flen) -> t.heap through epginflate, then ISIZE and CRC-32 of every member (epg_crc32.h: carry-less
+// multiplication, ~20 GB/s where zlib's table-driven crc32 does 1 GB/s; in pieces over the threads).  false = use zlib instead.
 bool inflate_own(const unsigned char* in, size_t flen, size_t cap_hint, Text& t) {
     struct Member { size_t out0, out1; uint32_t crc, isize; };
     std::vector<Member> members;
     epginflate::Out out{nullptr, 0, cap_hint};
     t.heap = (char*)malloc(cap_hint + 320 + 16);
     if (!t.heap) return false;
+    advise_huge(t.heap, cap_hint);
     out.base = (unsigned char*)t.heap;
     auto grow = [&](size_t min_cap) {
         size_t ncap = out.cap + out.cap / 2 + (1u << 24);
         if (ncap < min_cap) ncap = min_cap + (1u << 24);
         char* nh = (char*)realloc(t.heap, ncap + 320 + 16);
         if (!nh) return false;
+        advise_huge(nh, ncap);
         t.heap = nh;
         out.base = (unsigned char*)nh;
         out.cap = ncap;
@@ -136,7 +150,7 @@ bool inflate_own(const unsigned char* in, size_t flen, size_t cap_hint, Text& t)
     for (int w = 0; w < T; ++w)
         th.emplace_back([&, w] {
             for (size_t i = (size_t)w; i < pieces.size(); i += (size_t)T)
-                pieces[i].crc = (uint32_t)crc32(crc32(0L, Z_NULL, 0), (const Bytef*)t.heap + pieces[i].off, (uInt)pieces[i].len);
+                pieces[i].crc = epgcrc::crc32_fast(0, (const unsigned char*)t.heap + pieces[i].off, pieces[i].len);
         });
     for (auto& x : th) x.join();
     for (size_t k = 0; k < members.size(); ++k) {
@@ -223,6 +237,90 @@ bool slurp(const char* path, Text& t) {
 }
 
 }  // namespace
+
+#if defined(__x86_64__)
+// One row's states with AVX-512 (VBMI2): 64 bytes of "\t18\t7\t18..." per step.  Every byte position is treated as if a value
+// started behind it -- first digit d0 = B[i+1] - '0', second d1 = B[i+2] - '0', value = two digits ? 10 d0 + d1 : d0 -- and the
+// results at the TAB positions are packed to the front (vpcompressb) and stored: ~1 cycle per value where the scalar loop
+// below spends ~12 (a data-dependent branch on one or two digits).  Anything that is not a plain row of one- or two-digit
+// values separated by single tabs (a sign, three digits, an empty field, other characters, a '\r' that is not the last
+// byte) makes it return -1 and the scalar code parses -- and judges -- the row.  Loads are masked to the row (through its
+// '\n'), so nothing behind it is touched.  q = the tab in front of the first value, nl = the row's '\n'.
+__attribute__((target("avx512f,avx512bw,avx512vbmi2,bmi2,popcnt")))
+int parse_row_avx512(const char* q, const char* nl, int8_t* out, int cols, __m512i& vmin, __m512i& vmax) {
+    const __m512i c_tab = _mm512_set1_epi8('\t'), c_nl = _mm512_set1_epi8('\n'), c_cr = _mm512_set1_epi8('\r');
+    const __m512i c_0 = _mm512_set1_epi8('0'), c_9 = _mm512_set1_epi8(9), c_30 = _mm512_set1_epi8(30), c_1 = _mm512_set1_epi8(1);
+    const __m512i c_ff = _mm512_set1_epi8((char)0xff);
+    const __m512i lut10 = _mm512_broadcast_i32x4(_mm_setr_epi8(0, 10, 20, 30, 40, 50, 60, 70, 80, 90, 0, 0, 0, 0, 0, 0));
+    int c = 0;
+    while (q < nl) {
+        const long left = nl - q;                                  // bytes before the '\n'
+        const unsigned n = left < 64 ? (unsigned)left : 64u;
+        const unsigned long long in_row = _bzhi_u64(~0ull, n);
+        const long valid = left + 1;                               // readable: through the '\n'
+        const __m512i b0 = _mm512_maskz_loadu_epi8(_bzhi_u64(~0ull, (unsigned)(valid > 64 ? 64 : valid)), q);
+        const __m512i b1 = _mm512_maskz_loadu_epi8(_bzhi_u64(~0ull, (unsigned)(valid - 1 > 64 ? 64 : valid - 1)), q + 1);
+        const __m512i b2 = _mm512_maskz_loadu_epi8(_bzhi_u64(~0ull, (unsigned)(valid - 2 > 64 ? 64 : (valid - 2 < 0 ? 0 : valid - 2))), q + 2);
+        const __m512i b3 = _mm512_maskz_loadu_epi8(_bzhi_u64(~0ull, (unsigned)(valid - 3 > 64 ? 64 : (valid - 3 < 0 ? 0 : valid - 3))), q + 3);
+        const unsigned long long tab = _mm512_cmpeq_epi8_mask(b0, c_tab) & in_row;
+        const __m512i d0 = _mm512_sub_epi8(b1, c_0), d1 = _mm512_sub_epi8(b2, c_0);
+        const unsigned long long dig_here = _mm512_cmple_epu8_mask(_mm512_sub_epi8(b0, c_0), c_9);
+        const unsigned long long cr = _mm512_cmpeq_epi8_mask(b0, c_cr) & in_row;
+        if ((~(tab | dig_here | cr)) & in_row) return -1;          // some other character
+        if (cr && (cr != (1ull << (n - 1)) || left > 64)) return -1;   // a '\r' anywhere but right in front of the '\n'
+        const unsigned long long dig0 = _mm512_cmple_epu8_mask(d0, c_9), two = _mm512_cmple_epu8_mask(d1, c_9);
+        const unsigned long long t2 = _mm512_cmpeq_epi8_mask(b2, c_tab) | _mm512_cmpeq_epi8_mask(b2, c_nl) | _mm512_cmpeq_epi8_mask(b2, c_cr);
+        const unsigned long long t3 = _mm512_cmpeq_epi8_mask(b3, c_tab) | _mm512_cmpeq_epi8_mask(b3, c_nl) | _mm512_cmpeq_epi8_mask(b3, c_cr);
+        const unsigned long long ok = dig0 & ((~two & t2) | (two & t3));
+        if (tab & ~ok) return -1;                                   // empty field, sign, three digits, ...
+        const __m512i v2 = _mm512_add_epi8(_mm512_shuffle_epi8(lut10, d0), d1);
+        const __m512i v = _mm512_mask_blend_epi8(two, d0, v2);     // the value as written (1-based)
+        vmin = _mm512_mask_min_epu8(vmin, tab, vmin, v);
+        vmax = _mm512_mask_max_epu8(vmax, tab, vmax, v);
+        __m512i o = _mm512_sub_epi8(v, c_1);                        // 0-based; 0 wraps to 255
+        o = _mm512_mask_mov_epi8(o, _mm512_cmpgt_epu8_mask(o, c_30), c_ff);   // outside 0..30: "not a state" (-1)
+        const int cnt = (int)_mm_popcnt_u64(tab);
+        if (c + cnt > cols) return -1;
+        _mm512_mask_storeu_epi8(out + c, _bzhi_u64(~0ull, (unsigned)cnt), _mm512_maskz_compress_epi8(tab, o));
+        c += cnt;
+        q += n;
+    }
+    return c;
+}
+
+bool have_avx512_parser() {
+    static const bool ok = [] {
+        const char* e = getenv("EPGIO_SIMD");
+        if (e && e[0] == '0') return false;
+        return __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512bw") && __builtin_cpu_supports("avx512vbmi2") &&
+               __builtin_cpu_supports("bmi2");
+    }();
+    return ok;
+}
+#endif
+
+#if defined(__x86_64__)
+__attribute__((target("avx512f,avx512bw")))
+void init_minmax512(void* mn, void* mx, int T) {
+    for (int i = 0; i < T; ++i) {
+        _mm512_store_si512((char*)mn + 64 * i, _mm512_set1_epi8((char)0xff));
+        _mm512_store_si512((char*)mx + 64 * i, _mm512_setzero_si512());
+    }
+}
+// smallest / largest value byte a thread's vector parser saw, folded into its scalar range
+void fold_minmax512(const void* mn, const void* mx, int T, int* vlo, int* vhi) {
+    for (int i = 0; i < T; ++i) {
+        const unsigned char* a = (const unsigned char*)mn + 64 * i;
+        const unsigned char* b = (const unsigned char*)mx + 64 * i;
+        int lo = 255, hi = 0;
+        for (int k = 0; k < 64; ++k) { lo = a[k] < lo ? a[k] : lo; hi = b[k] > hi ? b[k] : hi; }
+        if (lo <= hi) {                                            // the vector parser saw at least one value
+            if (lo < vlo[i]) vlo[i] = lo;
+            if (hi > vhi[i]) vhi[i] = hi;
+        }
+    }
+}
+#endif
 
 struct epgio_table {
     int64_t rows = 0;
@@ -323,6 +421,7 @@ epgio_table* epgio_open_table(const char* path, int64_t row_lo, int64_t row_hi, 
     t->rows = row_hi - row_lo;
     t->cols = cols;
     t->states.reset(new int8_t[(size_t)t->rows * cols + 1]);
+    advise_huge(t->states.get(), (size_t)t->rows * cols);
     t->loc_off.assign((size_t)t->rows + 1, 0);
 
     // pass 1: location text lengths; pass 2 (after prefix sum): states + location text.  Both per segment.
@@ -358,6 +457,12 @@ epgio_table* epgio_open_table(const char* path, int64_t row_lo, int64_t row_hi, 
     for (int64_t r = 0; r < t->rows; ++r) t->loc_off[(size_t)r + 1] += t->loc_off[(size_t)r];
     t->loc.resize((size_t)t->loc_off[(size_t)t->rows]);
     {
+#if defined(__x86_64__)
+        struct alignas(64) V512 { __m512i v; };
+        const bool simd = have_avx512_parser();
+        std::vector<V512> vmin512((size_t)T), vmax512((size_t)T);
+        if (simd) init_minmax512(vmin512.data(), vmax512.data(), T);
+#endif
         std::vector<std::thread> th;
         for (int i = 0; i < T; ++i)
             th.emplace_back([&, i] {
@@ -368,6 +473,12 @@ epgio_table* epgio_open_table(const char* path, int64_t row_lo, int64_t row_hi, 
                     const char* q = p + len;
                     int8_t* out = t->states.get() + (size_t)r * cols;
                     int c = 0;
+#if defined(__x86_64__)
+                    if (simd) {
+                        if (parse_row_avx512(q, nl, out, cols, vmin512[i].v, vmax512[i].v) == cols) return;
+                        // anything unusual: the scalar code below parses the row again from its first value
+                    }
+#endif
                     // fast path: one- or two-digit values ("\t7", "\t18"), which is every state of a 1..31-state model; the
                     // text has 16 readable bytes after its end, a row ends in '\n' (not a digit), so looking three characters
                     // ahead is safe.  Anything else (sign, three digits, '\r', malformed) leaves the loop for the general one.
@@ -413,6 +524,9 @@ epgio_table* epgio_open_table(const char* path, int64_t row_lo, int64_t row_hi, 
                 });
             });
         for (auto& x : th) x.join();
+#if defined(__x86_64__)
+        if (simd) fold_minmax512(vmin512.data(), vmax512.data(), T, vlo.data(), vhi.data());
+#endif
     }
     lap("parse states + locations");
     for (int i = 0; i < T; ++i) {

@@ -86,6 +86,8 @@ def run(label, out, saliency=None, paired=False):
     info = [json.loads(l[2:]) for l in r.stdout.splitlines() if l.startswith("@@")]
     print("== %s" % label)
     print("".join(l + "\n" for l in r.stdout.splitlines() if "[timing]" in l), end="")
+    if os.environ.get("EPGIO_TIMING"):                     # per-file phases of the native reader (stderr)
+        print("".join(l + "\n" for l in r.stderr.splitlines() if "[epgio]" in l), end="")
     if r.returncode != 0 or not info:
         print(r.stdout[-3000:], r.stderr[-5000:])
         raise SystemExit("%s failed" % label)
