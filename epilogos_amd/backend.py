@@ -141,13 +141,14 @@ class HipBackend:
 
 
 class _HipSession:
-    """Shared plumbing: ordered pinned staging, one asynchronous upload per matrix, the count accumulator."""
+    """Shared plumbing: pinned staging, one asynchronous upload per matrix, the count accumulator."""
 
     def __init__(self, be, S, saliency):
         self.be, self.S, self.sal = be, S, saliency
         self.torch, self.eng, self.device = be.torch, be.engine, be.device
         # staging buffers in flight; paired mode holds a part's A and B at once, so never fewer than two
-        self.pool = be.engine.PinnedPool(max(2, int(__import__("os").environ.get("EPILOGOS_PINNED_BUFFERS", "4"))))
+        # (first come, first served: the driver takes the parts as their parsers finish)
+        self.pool = be.engine.PinnedPool(max(2, int(__import__("os").environ.get("EPILOGOS_PINNED_BUFFERS", "4"))), in_order=False)
         self.copy_stream = self.torch.cuda.Stream(device=self.device)
         self.held = {}                                   # ticket -> pinned buffer handed to the parser
         self.acc = None
@@ -251,10 +252,20 @@ class _HipPairedSession(_HipSession):
         super().__init__(be, S, saliency)
         self.qstate, self.groupSize, self.seed = quiescentState, groupSize, seed
 
+    def stage(self, arr, N, ticket):
+        """One group's matrix of a part -> HBM as soon as it is parsed (its staging buffer goes back to the pool at once: a
+        part must not sit on two of the few buffers while its other half is still being inflated)."""
+        return self._upload(arr, N, ticket)
+
+    def set_row0(self, pid, row0):
+        XA, XB, HA, HB, _ = self.parts[pid]
+        self.parts[pid] = (XA, XB, HA, HB, row0)
+
     def add_part(self, arrA, NA, ticketA, arrB, NB, ticketB, row0):
+        return self.add_staged(self._upload(arrA, NA, ticketA), NA, self._upload(arrB, NB, ticketB), NB, row0)
+
+    def add_staged(self, XA, NA, XB, NB, row0):
         eng, S = self.eng, self.S
-        XA = self._upload(arrA, NA, ticketA)
-        XB = self._upload(arrB, NB, ticketB)
         self.NA, self.NB = NA, NB
         if self.sal == 1:                                # counts over [A|B] = counts of A + counts of B (helpers.py:173)
             HA, _ = eng.bin_hist(XA, NA, S, counts=self._acc(S))

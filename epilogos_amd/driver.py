@@ -192,8 +192,17 @@ class _HostPairedSession(_HostSession):
         super().__init__(be, S, saliency)
         self.qstate, self.groupSize, self.seed = quiescentState, groupSize, seed
 
+    def stage(self, arr, N, ticket):
+        return arr[:, :N]
+
+    def set_row0(self, pid, row0):
+        xa, xb, _ = self.parts[pid]
+        self.parts[pid] = (xa, xb, row0)
+
     def add_part(self, arrA, NA, ticketA, arrB, NB, ticketB, row0):
-        xa, xb = arrA[:, :NA], arrB[:, :NB]
+        return self.add_staged(arrA[:, :NA], NA, arrB[:, :NB], NB, row0)
+
+    def add_staged(self, xa, NA, xb, NB, row0):
         self._add_counts(self.be.expected_counts(np.concatenate((xa, xb), axis=1), self.S, self.sal))
         self.parts.append((xa, xb, row0))
         return len(self.parts) - 1
@@ -244,13 +253,20 @@ def _check_range(path, rng, numStates):
 
 
 def _stream_parts(jobs, sess, numStates):
-    """jobs: [(path, lo, hi or None)].  Parses ahead in threads (inflate is serial per file, files run in parallel; the
-    native parser releases the GIL) and yields (ticket, states [rows, width], N, Locations) in job order.  Destinations
-    come from the session (pinned staging, handed out in ticket order, which also bounds the host memory in flight)."""
-    # files in flight: inflate is one serial stream per file, so more files than cores keeps the cores busy while some workers
-    # wait for their staging buffer (whole genome, 16 cores: 8 workers 22.6 s, 16 workers 17.3 s, 24 workers 14.7 s of parse)
-    default_workers = max(8, min(32, 3 * (len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else 8) // 2))
-    workers = max(1, min(int(os.environ.get("EPILOGOS_PARSE_WORKERS", default_workers)), len(jobs)))
+    """jobs: [(path, lo, hi or None)].  Parses in threads (inflate is serial per file, files run in parallel; the native
+    reader releases the GIL) and yields (ticket = index in jobs, states [rows, width], N, Locations) AS THE PARTS COMPLETE.
+    Destinations come from the session (pinned staging, first come first served).
+    Scheduling: one worker per usable core, largest files first.  Round 2 measured the whole genome on 16 cores with 24
+    workers and parts handed over in file order: every part waited behind chr1, whose inflate -- the longest job, started
+    together with 23 others on 16 cores -- took 7 s instead of 3; the count pass does not care about the order."""
+    ncores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 8)
+    try:                                               # a cgroup CPU quota (containers) is the real limit
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            ncores = max(1, min(ncores, int(int(quota) / int(period) + 0.5)))
+    except (OSError, ValueError):
+        pass
+    workers = max(1, min(int(os.environ.get("EPILOGOS_PARSE_WORKERS", max(4, ncores))), len(jobs)))
 
     def read(ticket):
         path, lo, hi = jobs[ticket]
@@ -265,13 +281,21 @@ def _stream_parts(jobs, sess, numStates):
         except BaseException:
             sess.skip(ticket)
             raise
-        return arr, N[0], loc, rng
+        return ticket, arr, N[0], loc, rng
 
+    def weight(ticket):                                # bytes of input behind a job (a row range: unknown share, the whole file)
+        try:
+            return os.path.getsize(jobs[ticket][0])
+        except OSError:
+            return 0
+
+    from concurrent.futures import as_completed
     pool = ThreadPoolExecutor(max_workers=workers)
+    futs = []
     try:
-        futs = [pool.submit(read, t) for t in range(len(jobs))]
-        for t, f in enumerate(futs):
-            arr, N, loc, rng = f.result()
+        futs = [pool.submit(read, t) for t in sorted(range(len(jobs)), key=lambda t: (-weight(t), t))]
+        for f in as_completed(futs):
+            t, arr, N, loc, rng = f.result()
             _check_range(jobs[t][0], rng, numStates)
             yield t, arr, N, loc
     except BaseException:
@@ -368,12 +392,12 @@ def run_single_group(files, numStates, saliency, outputDir, fileTag, verbose=Fal
     sess = _open_single(be, numStates, saliency)
 
     # STEP 1: every part of this rank is parsed, uploaded once and counted; what the score pass needs stays resident
-    pids, locs, N = [], [], None
+    pids, locs, N = [None] * len(my_parts), [None] * len(my_parts), None
     with closing(_stream_parts([(files[fi], lo, hi) for fi, lo, hi in my_parts], sess, numStates)) as stream:
-        for t, arr, n, loc in stream:
+        for t, arr, n, loc in stream:                  # in order of completion; t = index in my_parts
             N = n
-            pids.append(sess.add_part(arr, n, t))
-            locs.append(loc)
+            pids[t] = sess.add_part(arr, n, t)
+            locs[t] = loc
     if rows is None:
         rows = [len(l) for l in locs]
         my_parts = [(fi, 0, rows[fi]) for fi in range(len(files))]
@@ -453,19 +477,33 @@ def run_paired_groups(files1, files2, numStates, saliency, outputDir, fileTag, q
     jobs = []
     for fi, lo, hi in my_parts:
         jobs += [(files1[fi], lo, hi), (files2[fi], lo, hi)]
-    locs, NA, NB, seen = [], None, None, 0
+    locs, pids, NA, NB = [None] * len(my_parts), [None] * len(my_parts), None, None
+    halves = {}                                        # part index -> its group that arrived first, already in HBM
     with closing(_stream_parts(jobs, sess, numStates)) as stream:
-        for k, (fi, lo, hi) in enumerate(my_parts):
-            ta, xa, NA, loc = next(stream)
-            tb, xb, NB, _ = next(stream)
-            if xb.shape[0] != xa.shape[0]:
+        for t, x, n, loc in stream:                    # in order of completion; jobs 2k and 2k + 1 are part k
+            k, second = t // 2, t % 2
+            if second:
+                NB = n
+            else:
+                NA, locs[k] = n, loc
+            staged = (sess.stage(x, n, t), n, x.shape[0])
+            if k not in halves:
+                halves[k] = (second, staged)
+                continue
+            other_second, other = halves.pop(k)
+            (XA, nA, rA), (XB, nB, rB) = (other, staged) if second else (staged, other)
+            fi, lo, hi = my_parts[k]
+            if rA != rB:
                 raise ValueError("paired inputs differ in length: {} vs {}".format(files1[fi], files2[fi]))
-            # global bin index of the part's first row (keys the null shuffle): from the plan, or -- one rank reading whole
-            # files in order -- the rows seen so far
-            row0 = int(sum(rows[:fi])) + lo if rows is not None else seen
-            sess.add_part(xa, NA, ta, xb, NB, tb, row0)
-            locs.append(loc)
-            seen += len(loc)
+            # global bin index of the part's first row (keys the null shuffle): from the plan; a single rank reading whole
+            # files learns it once every part has been parsed (below)
+            row0 = int(sum(rows[:fi])) + lo if rows is not None else None
+            pids[k] = sess.add_staged(XA, nA, XB, nB, row0)
+    if rows is None:
+        seen = 0
+        for k in range(len(my_parts)):
+            sess.set_row0(pids[k], seen)
+            seen += len(locs[k])
     if rows is None:                                   # single rank: row counts come from the parse
         rows = [len(l) for l in locs]
         my_parts = [(fi, 0, rows[fi]) for fi in range(len(files1))]
@@ -484,7 +522,7 @@ def run_paired_groups(files1, files2, numStates, saliency, outputDir, fileTag, q
     with ThreadPoolExecutor(max_workers=2) as writer:
         wjobs = []
         for k, (fi, lo, hi) in enumerate(my_parts):
-            res = sess.results(k)
+            res = sess.results(pids[k])
             whole = lo == 0 and hi == rows[fi]
             name = ("pairwiseDelta_{}_{}.txt.gz".format(fileTag, fileStem(files1[fi])) if whole
                     else _part_name("pairwiseDelta", fileTag, fi, lo))

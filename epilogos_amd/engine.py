@@ -231,15 +231,18 @@ def null_hist(XA, NA, XB, NB, S, ga, gb, seed, row0=0):
 
 
 class PinnedPool:
-    """A few page-locked host staging buffers handed out IN TICKET ORDER (ticket k waits until tickets < k were served
-    and a buffer is free), so that parser threads running ahead of the consumer can neither exhaust the pool nor starve
-    the part the consumer is waiting for.  Buffers grow to the largest request and are reused for the whole run."""
+    """A few page-locked host staging buffers.  in_order=True hands them out IN TICKET ORDER (ticket k waits until tickets
+    < k were served and a buffer is free): for a consumer that takes the parts in ticket order, parser threads running
+    ahead can neither exhaust the pool nor starve the part it waits for.  in_order=False serves whoever asks first -- for a
+    consumer that takes the parts as they complete (driver._stream_parts).  Buffers grow to the largest request and are
+    reused for the whole run."""
 
-    def __init__(self, n_buffers=3):
+    def __init__(self, n_buffers=3, in_order=True):
         import threading
         self.cv = threading.Condition()
         self.free = [None] * n_buffers          # None = not allocated yet
         self.next = 0
+        self.in_order = in_order
         self.aborted = False
 
     def abort(self):
@@ -250,7 +253,7 @@ class PinnedPool:
 
     def acquire(self, ticket, nbytes):
         with self.cv:
-            self.cv.wait_for(lambda: self.aborted or (self.next == ticket and len(self.free) > 0))
+            self.cv.wait_for(lambda: self.aborted or ((not self.in_order or self.next == ticket) and len(self.free) > 0))
             if self.aborted:
                 raise RuntimeError("staging pool aborted")
             buf = self.free.pop()
@@ -262,6 +265,8 @@ class PinnedPool:
 
     def skip(self, ticket):
         """A part that failed before asking for its buffer must not block the tickets behind it."""
+        if not self.in_order:
+            return
         with self.cv:
             self.cv.wait_for(lambda: self.aborted or self.next >= ticket)
             if self.next == ticket:

@@ -60,14 +60,17 @@ def readTable(path, rowsToCalc=None, alloc=None, with_range=False):
     if cache is None:
         return _io.read_table(Path(path), rowsToCalc, alloc=alloc, with_range=with_range)
     if not all(c.exists() for c in cache):
+        # first run on this input: parse, serve the caller from the arrays just parsed, and write the cache files BEHIND the
+        # caller's back (a whole genome is 12.9 GB of them; written before the part was handed on they were a third of a cold
+        # run).  The writer threads are ordinary (non-daemon) threads: the interpreter waits for them at exit.
         states, loc, rng = _io.read_table(Path(path), None, with_range=True)
-        cache[0].parent.mkdir(parents=True, exist_ok=True)
-        for c, arr in zip(cache, (states, loc.blob, loc.offsets, np.array(rng, dtype=np.int64))):
-            tmp = Path(str(c) + ".tmp%d.npy" % os.getpid())              # atomic: ranks may fill the cache concurrently
-            np.save(tmp, arr, allow_pickle=False)
-            os.replace(tmp, c)
-    states = np.load(cache[0], mmap_mode="r")
-    loc = _io.Locations(np.load(cache[1], mmap_mode="r"), np.load(cache[2], mmap_mode="r"))
+        blob, offsets, rng_arr = loc.blob, loc.offsets, np.array(rng, dtype=np.int64)
+        _save_cache_async(cache, (states, blob, offsets, rng_arr))
+    else:
+        states = np.load(cache[0], mmap_mode="r")
+        blob, offsets = np.load(cache[1], mmap_mode="r"), np.load(cache[2], mmap_mode="r")
+        rng_arr = np.load(cache[3]) if with_range else None
+    loc = _io.Locations(blob, offsets)
     lo, hi = (0, states.shape[0]) if rowsToCalc is None else (max(rowsToCalc[0], 0), min(rowsToCalc[1], states.shape[0]))
     hi = max(hi, lo)
     part = loc.slice(lo, hi)
@@ -79,9 +82,35 @@ def readTable(path, rowsToCalc=None, alloc=None, with_range=False):
         out[:, states.shape[1]:] = -1
     ploc = _io.Locations(np.ascontiguousarray(part.blob), np.ascontiguousarray(part.offsets))
     if with_range:
-        rng = np.load(cache[3])
-        return out, ploc, (int(rng[0]), int(rng[1]))
+        return out, ploc, (int(rng_arr[0]), int(rng_arr[1]))
     return out, ploc
+
+
+_cache_writers = []
+
+
+def _save_cache_async(cache, arrays):
+    import threading
+
+    def work():
+        try:
+            cache[0].parent.mkdir(parents=True, exist_ok=True)
+            for c, arr in zip(cache, arrays):
+                tmp = Path(str(c) + ".tmp%d.npy" % os.getpid())          # atomic: ranks may fill the cache concurrently
+                np.save(tmp, arr, allow_pickle=False)
+                os.replace(tmp, c)
+        except OSError as e:                                               # a cache that cannot be written is not an error of the run
+            print("epilogos_amd: could not write the input cache {}: {}".format(cache[0], e), flush=True)
+
+    th = threading.Thread(target=work, name="epilogos-cache-writer")
+    th.start()
+    _cache_writers.append(th)
+
+
+def flushCacheWrites():
+    """Wait for the cache files of this process's first-time reads (tests, and callers that read the cache back at once)."""
+    while _cache_writers:
+        _cache_writers.pop().join()
 
 
 def _read_int8(path, rowsToCalc):

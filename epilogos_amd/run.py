@@ -206,6 +206,8 @@ def main(mode, commandLineBool, inputDirectory, inputDirectory1, inputDirectory2
                         storedExpPath, roiWidth if roiWidth else 125, False)
             if os.environ.get("EPILOGOS_TIMING"):
                 print("    [timing] %-34s %7.2f s" % ("STEP 4", time.perf_counter() - t0), flush=True)
+    from .helpers import flushCacheWrites
+    flushCacheWrites()                                           # --cache-dir: files of first-time reads, written in the background
     if world > 1:
         import torch.distributed as dist
         dist.destroy_process_group()

@@ -155,6 +155,7 @@ def test_binary_input_cache(tmp_path, monkeypatch):
         st, loc = helpers.readTable(f, (17, 203))
         assert st.dtype == np.int8 and st.flags["C_CONTIGUOUS"] and np.array_equal(st, plain_states)
         assert np.array_equal(loc.blob, plain_loc.blob) and np.array_equal(loc.offsets, plain_loc.offsets)
+        helpers.flushCacheWrites()                               # the cache is written behind the first call's back
     files = sorted(p.name for p in (tmp_path / "cache").iterdir())
     assert len(files) == 4 and all(n.startswith("matrix_chr7_") for n in files)
     full, floc = helpers.readTable(f)
@@ -167,6 +168,7 @@ def test_binary_input_cache(tmp_path, monkeypatch):
     write_tsv(f, x2, chrom="chr7", start0=1000)
     os.utime(f, ns=(time.time_ns() + 10**9, time.time_ns() + 10**9))
     assert np.array_equal(helpers.readTable(f)[0], x2)
+    helpers.flushCacheWrites()
     assert len(list((tmp_path / "cache").iterdir())) == 8
 
 
