@@ -92,7 +92,7 @@ void advise_huge(void* p, size_t n) {
 
 // gzip members of in[0, flen) -> t.heap through epginflate, then ISIZE and CRC-32 of every member (epg_crc32.h: carry-less
 // multiplication, ~20 GB/s where zlib's table-driven crc32 does 1 GB/s; in pieces over the threads).  false = use zlib instead.
-bool inflate_own(const unsigned char* in, size_t flen, size_t cap_hint, Text& t) {
+bool inflate_own(const unsigned char* in, size_t flen, size_t cap_hint, Text& t, int32_t threads) {
     struct Member { size_t out0, out1; uint32_t crc, isize; };
     std::vector<Member> members;
     epginflate::Out out{nullptr, 0, cap_hint};
@@ -145,7 +145,7 @@ bool inflate_own(const unsigned char* in, size_t flen, size_t cap_hint, Text& t)
         for (size_t o = members[k].out0; o < members[k].out1; o += PIECE) pieces.push_back(Piece{o, std::min(PIECE, members[k].out1 - o), 0});
     }
     first[members.size()] = pieces.size();
-    const int T = (int)std::max<size_t>(1, std::min<size_t>((size_t)n_threads(0), pieces.size()));
+    const int T = (int)std::max<size_t>(1, std::min<size_t>((size_t)n_threads(threads), pieces.size()));
     std::vector<std::thread> th;
     for (int w = 0; w < T; ++w)
         th.emplace_back([&, w] {
@@ -164,7 +164,7 @@ bool inflate_own(const unsigned char* in, size_t flen, size_t cap_hint, Text& t)
     return true;
 }
 
-bool slurp(const char* path, Text& t) {
+bool slurp(const char* path, Text& t, int32_t threads = 0) {
     const int fd = open(path, O_RDONLY);
     if (fd < 0) { fail("cannot open %s", path); return false; }
     struct stat st;
@@ -196,7 +196,7 @@ bool slurp(const char* path, Text& t) {
     // any doubt the file is read again with zlib below.  EPGIO_INFLATE=zlib skips it.
     {
         static const bool use_own = [] { const char* e = getenv("EPGIO_INFLATE"); return !(e && e[0] == 'z'); }();
-        if (use_own && inflate_own(in, flen, cap, t)) return true;
+        if (use_own && inflate_own(in, flen, cap, t, threads)) return true;
         if (t.heap) { free(t.heap); t.heap = nullptr; }
     }
     t.heap = (char*)malloc(cap + 16);
@@ -367,7 +367,7 @@ epgio_table* epgio_open_table(const char* path, int64_t row_lo, int64_t row_hi, 
         if (timing) { const double t1 = now_s(); fprintf(stderr, "    [epgio] %-28s %7.3f s\n", what, t1 - t0); t0 = t1; }
     };
     Text buf;
-    if (!slurp(path, buf)) return nullptr;
+    if (!slurp(path, buf, threads)) return nullptr;
     lap("read / inflate");
     const char* base = buf.data;
     const char* end = base + buf.size;

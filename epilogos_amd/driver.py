@@ -17,6 +17,8 @@ name; a file cut by a range border is written as gzip members named from the par
 and concatenated by rank 0 (a multi-member gzip file is a valid gzip file).  The arrays STEP 4 needs travel to rank 0
 through torch.distributed send/recv, not through the file system."""
 import os
+import sys
+import time
 import shutil
 from concurrent.futures import ThreadPoolExecutor
 from contextlib import closing
@@ -267,20 +269,31 @@ def _stream_parts(jobs, sess, numStates):
     except (OSError, ValueError):
         pass
     workers = max(1, min(int(os.environ.get("EPILOGOS_PARSE_WORKERS", max(4, ncores))), len(jobs)))
+    # native threads per file: the cores are shared out.  (With every reader fanning its short parse phases out to all cores
+    # next to fifteen inflating threads, a cgroup CPU quota throttles the whole process for the rest of each 100 ms period:
+    # phases that take 0.03 s alone took 1 s.)
+    file_threads = max(1, ncores // workers)
+
+    trace = os.environ.get("EPILOGOS_TIMING") == "2"        # per-part timeline on stderr
+    t_origin = time.perf_counter()
 
     def read(ticket):
         path, lo, hi = jobs[ticket]
         N = [None]
         alloc0 = sess.alloc(ticket)
+        t_begin = time.perf_counter() - t_origin
 
         def alloc(R, n):
             N[0] = n
             return alloc0(R, n) if alloc0 is not None else np.empty((R, n), dtype=np.int8)
         try:
-            arr, loc, rng = readTable(path, None if hi is None else (lo, hi), alloc=alloc, with_range=True)
+            arr, loc, rng = readTable(path, None if hi is None else (lo, hi), alloc=alloc, with_range=True, threads=file_threads)
         except BaseException:
             sess.skip(ticket)
             raise
+        if trace:
+            print("    [part %2d] %-28s reader %6.2f .. %6.2f s" % (ticket, Path(path).name[:28], t_begin, time.perf_counter() - t_origin),
+                  file=sys.stderr, flush=True)
         return ticket, arr, N[0], loc, rng
 
     def weight(ticket):                                # bytes of input behind a job (a row range: unknown share, the whole file)
@@ -297,7 +310,10 @@ def _stream_parts(jobs, sess, numStates):
         for f in as_completed(futs):
             t, arr, N, loc, rng = f.result()
             _check_range(jobs[t][0], rng, numStates)
+            t_yield = time.perf_counter() - t_origin
             yield t, arr, N, loc
+            if trace:
+                print("    [part %2d] consumed %6.2f .. %6.2f s" % (t, t_yield, time.perf_counter() - t_origin), file=sys.stderr, flush=True)
     except BaseException:
         if hasattr(sess, "pool"):
             sess.pool.abort()

@@ -49,21 +49,22 @@ def _cache_paths(path):
     return [Path(str(base) + ext) for ext in (".states.npy", ".locblob.npy", ".locoff.npy", ".range.npy")]
 
 
-def readTable(path, rowsToCalc=None, alloc=None, with_range=False):
+def readTable(path, rowsToCalc=None, alloc=None, with_range=False, threads=0):
     """Rows [lo, hi) of a matrix file through the native multi-threaded parser: int8 0-based states
     [rows, N] and the rows' first three columns as written (a _io.Locations).  With EPILOGOS_CACHE_DIR set (the command
     line's --cache-dir) the parsed file is kept as an int8 [R, N] .npy plus the coordinate side-car and later runs on the
     same input memory-map it instead of inflating and parsing ~1.7 KB of text per bin again.
     alloc(R, N) -> int8 [R, width >= N] supplies the destination (the driver's pinned, row-padded staging; columns >= N
-    are set to -1); with_range also returns the (lowest, highest) state value of the WHOLE file as written (1-based)."""
+    are set to -1); with_range also returns the (lowest, highest) state value of the WHOLE file as written (1-based);
+    threads = native threads for this one file (0 = all cores; the driver, which reads many files at once, gives each its share)."""
     cache = _cache_paths(path)
     if cache is None:
-        return _io.read_table(Path(path), rowsToCalc, alloc=alloc, with_range=with_range)
+        return _io.read_table(Path(path), rowsToCalc, threads=threads, alloc=alloc, with_range=with_range)
     if not all(c.exists() for c in cache):
         # first run on this input: parse, serve the caller from the arrays just parsed, and write the cache files BEHIND the
         # caller's back (a whole genome is 12.9 GB of them; written before the part was handed on they were a third of a cold
         # run).  The writer threads are ordinary (non-daemon) threads: the interpreter waits for them at exit.
-        states, loc, rng = _io.read_table(Path(path), None, with_range=True)
+        states, loc, rng = _io.read_table(Path(path), None, threads=threads, with_range=True)
         blob, offsets, rng_arr = loc.blob, loc.offsets, np.array(rng, dtype=np.int64)
         _save_cache_async(cache, (states, blob, offsets, rng_arr))
     else:

@@ -82,12 +82,12 @@ def run(label, out, saliency=None, paired=False):
     src = ["-m", "paired", "-a", str(gA), "-b", str(gB), "--null-seed", "7"] if paired else ["-i", str(ind)]
     cmd = [sys.executable, "-c", WRAP, sys.executable, "-m", "epilogos_amd.run", "-l", *src, "-j", str(meta), "-o", str(out),
            "-s", str(saliency or a.saliency), "--cache-dir", str(cache)]
-    r = subprocess.run(cmd, cwd=str(ROOT), capture_output=True, text=True, env=dict(os.environ, EPILOGOS_TIMING="1"))
+    r = subprocess.run(cmd, cwd=str(ROOT), capture_output=True, text=True, env=dict(os.environ, EPILOGOS_TIMING=os.environ.get("EPILOGOS_TIMING", "1")))
     info = [json.loads(l[2:]) for l in r.stdout.splitlines() if l.startswith("@@")]
     print("== %s" % label)
     print("".join(l + "\n" for l in r.stdout.splitlines() if "[timing]" in l), end="")
-    if os.environ.get("EPGIO_TIMING"):                     # per-file phases of the native reader (stderr)
-        print("".join(l + "\n" for l in r.stderr.splitlines() if "[epgio]" in l), end="")
+    if os.environ.get("EPGIO_TIMING") or os.environ.get("EPILOGOS_TIMING") == "2":   # reader phases / part timeline (stderr)
+        print("".join(l + "\n" for l in r.stderr.splitlines() if "[epgio]" in l or "[part" in l), end="")
     if r.returncode != 0 or not info:
         print(r.stdout[-3000:], r.stderr[-5000:])
         raise SystemExit("%s failed" % label)
