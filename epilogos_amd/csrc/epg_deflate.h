@@ -310,7 +310,13 @@ inline unsigned char* deflate_fast(const unsigned char* in, size_t n, unsigned c
     std::vector<Match> mt;
     mt.reserve(kBlockBytes / 16);
     const size_t last_hashable = n >= 8 ? n - 8 : 0;        // positions below it have 8 readable bytes
+    const size_t kSegment = (size_t)1 << 30;                // positions in the hash table are 32-bit offsets into a 1 GiB segment
+    size_t seg0 = 0;
     for (size_t b0 = 0; b0 < n; b0 += kBlockBytes) {
+        if (b0 - seg0 >= kSegment) {                         // (a multiple of the block size) forget the window, start over
+            seg0 = b0;
+            std::fill(head.begin(), head.end(), 0xffffffffu);
+        }
         const size_t b1 = std::min(n, b0 + kBlockBytes);
         const size_t probe_end = std::min(b1, last_hashable);
         mt.clear();
@@ -320,9 +326,11 @@ inline unsigned char* deflate_fast(const unsigned char* in, size_t n, unsigned c
             uint64_t v;
             memcpy(&v, in + pos, 8);
             const uint32_t h = hash6(v);
-            const uint32_t cand = head[h];
-            head[h] = (uint32_t)pos;
-            if (cand != 0xffffffffu && pos - cand <= kWindow) {
+            const uint32_t rel = (uint32_t)(pos - seg0);
+            const uint32_t crel = head[h];
+            head[h] = rel;
+            if (crel != 0xffffffffu && rel - crel <= kWindow) {
+                const size_t cand = seg0 + crel;
                 uint64_t w;
                 memcpy(&w, in + cand, 8);
                 const uint64_t x = v ^ w;
@@ -347,7 +355,7 @@ inline unsigned char* deflate_fast(const unsigned char* in, size_t n, unsigned c
                         for (size_t q = pos + 1; q < end && q < last_hashable; q += 2) {
                             uint64_t u;
                             memcpy(&u, in + q, 8);
-                            head[hash6(u)] = (uint32_t)q;
+                            head[hash6(u)] = (uint32_t)(q - seg0);
                         }
                         pos = end;
                         misses = 0;
