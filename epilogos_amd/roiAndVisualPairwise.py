@@ -76,6 +76,13 @@ def fitOnSubSample(distanceArrNull, samplingSize):
     return params, nnlf
 
 
+_FIT_DATA = None                                     # the null distances of the pool's parent: workers inherit them through fork
+
+
+def _fitOnSharedData(samplingSize):
+    return fitOnSubSample(_FIT_DATA, samplingSize)
+
+
 def fitDistances(outputDirPath, numProcesses, numTrials, samplingSize):
     """Null distances of the non-quiescent bins in chromosome order, `numTrials` fits, the one with the median
     negative log-likelihood wins (reference :175-221)."""
@@ -126,14 +133,35 @@ def readInData(outputDirPath, numStates, backend=None):
     return locationArr, dist[order], maxdiff[order], chrDict
 
 
-def calculatePVals(distanceArrReal, beta, loc, scale):
-    """Two-sided p-value of every distance under the fitted gennorm (reference :496-517)."""
-    below = np.where(distanceArrReal <= loc)[0]
-    above = np.where(distanceArrReal > loc)[0]
-    pvals = np.zeros(len(distanceArrReal))
-    pvals[below] = 2 * st.gennorm.cdf(distanceArrReal[below], beta, loc=loc, scale=scale)
-    pvals[above] = 2 * (1 - st.gennorm.cdf(distanceArrReal[above], beta, loc=loc, scale=scale))
+def _pvals_chunk(x, beta, loc, scale):
+    below = np.where(x <= loc)[0]
+    above = np.where(x > loc)[0]
+    pvals = np.zeros(len(x))
+    pvals[below] = 2 * st.gennorm.cdf(x[below], beta, loc=loc, scale=scale)
+    pvals[above] = 2 * (1 - st.gennorm.cdf(x[above], beta, loc=loc, scale=scale))
     return pvals
+
+
+def calculatePVals(distanceArrReal, beta, loc, scale, threads=0):
+    """Two-sided p-value of every distance under the fitted gennorm (reference :496-517).  The reference's expression,
+    evaluated on slices of the array in threads (scipy's special functions release the GIL; elementwise, so the values are
+    the single-threaded ones): 15 M distances took a third of this stage."""
+    x = np.asarray(distanceArrReal)
+    n = len(x)
+    if threads <= 0:
+        try:
+            import os
+            threads = len(os.sched_getaffinity(0))
+        except (AttributeError, OSError):
+            threads = cpu_count()
+        threads = min(threads, 32)
+    step = max(1 << 18, -(-n // max(threads, 1)))
+    if n <= step:
+        return _pvals_chunk(x, beta, loc, scale)
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=threads) as ex:
+        parts = list(ex.map(lambda lo: _pvals_chunk(x[lo:lo + step], beta, loc, scale), range(0, n, step)))
+    return np.concatenate(parts)
 
 
 def writeMetrics(locationArr, chrDict, maxDiffArr, nameArr, distanceArrReal, outputDirPath, fileTag, pvalBool, pvals=(),
@@ -226,9 +254,22 @@ def _fitParams(distanceArrNull, quiescenceArr, numProcesses, numTrials, sampling
     """Median-likelihood gennorm fit of the non-quiescent null distances (reference :196-221)."""
     data = distanceArrNull[np.where(np.invert(quiescenceArr.astype(bool)))[0]]
     if numProcesses > 1 and numTrials > 1:
-        with closing(Pool(numProcesses)) as pool:
-            results = pool.starmap(fitOnSubSample, zip(repeat(data, numTrials), repeat(samplingSize, numTrials)))
-        pool.join()
+        # the reference pickles the whole array into every one of the numTrials tasks (:206-208, 43 MB x 101 at genome scale);
+        # forked workers already have it
+        global _FIT_DATA
+        import multiprocessing
+        if multiprocessing.get_start_method(allow_none=True) in (None, "fork"):
+            _FIT_DATA = data
+            try:
+                with closing(multiprocessing.get_context("fork").Pool(numProcesses)) as pool:
+                    results = pool.map(_fitOnSharedData, [samplingSize] * numTrials)
+                pool.join()
+            finally:
+                _FIT_DATA = None
+        else:
+            with closing(Pool(numProcesses)) as pool:
+                results = pool.starmap(fitOnSubSample, zip(repeat(data, numTrials), repeat(samplingSize, numTrials)))
+            pool.join()
     else:
         results = [fitOnSubSample(data, samplingSize) for _ in range(numTrials)]
     nnlf = np.array([r[1] for r in results], dtype=np.float64)

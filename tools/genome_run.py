@@ -36,6 +36,7 @@ ap.add_argument("--keep", action="store_true")
 ap.add_argument("--skip-warm", action="store_true")
 ap.add_argument("--also", default="", help="comma list of further saliencies to run from the warm cache, e.g. 2,3")
 ap.add_argument("--paired", action="store_true", help="also write the 379 + 342 column split as two groups and run -m paired (S1)")
+ap.add_argument("--pvals", action="store_true", help="with --paired: one more warm run with -n (null-distribution fit, p-values, BH)")
 a = ap.parse_args()
 N, S = a.biosamples, 18
 base = Path(a.dir or (Path("/dev/shm") if Path("/dev/shm").is_dir() else Path(os.environ.get("TMPDIR", "/tmp"))) / "epg_genome")
@@ -78,8 +79,8 @@ WRAP = ("import resource, subprocess, sys, json, time; t = time.time(); r = subp
         "'peak_rss_gb': resource.getrusage(resource.RUSAGE_CHILDREN).ru_maxrss / 1048576.0})); sys.exit(r.returncode)")
 
 
-def run(label, out, saliency=None, paired=False):
-    src = ["-m", "paired", "-a", str(gA), "-b", str(gB), "--null-seed", "7"] if paired else ["-i", str(ind)]
+def run(label, out, saliency=None, paired=False, extra=()):
+    src = ["-m", "paired", "-a", str(gA), "-b", str(gB), "--null-seed", "7", *extra] if paired else ["-i", str(ind)]
     cmd = [sys.executable, "-c", WRAP, sys.executable, "-m", "epilogos_amd.run", "-l", *src, "-j", str(meta), "-o", str(out),
            "-s", str(saliency or a.saliency), "--cache-dir", str(cache)]
     r = subprocess.run(cmd, cwd=str(ROOT), capture_output=True, text=True, env=dict(os.environ, EPILOGOS_TIMING=os.environ.get("EPILOGOS_TIMING", "1")))
@@ -113,6 +114,9 @@ if a.paired:
     o = base / "out_paired"
     run("paired S1, 379 + 342 biosamples, cold", o, saliency=1, paired=True)
     run("paired S1, 379 + 342 biosamples, warm cache", base / "out_paired2", saliency=1, paired=True)
+    if a.pvals:
+        run("paired S1 with -n (gennorm fit of the null distances, p-values, Benjamini-Hochberg), warm cache", base / "out_paired3",
+            saliency=1, paired=True, extra=("-n", "-c", "16"))
     for name, _ in HG19:
         with gzip.open(o / ("pairwiseDelta_male_female_s1_matrix_%s.txt.gz" % name), "rb") as fh:
             n = sum(chunk.count(b"\n") for chunk in iter(lambda: fh.read(1 << 24), b""))
