@@ -247,7 +247,13 @@ def _stage(verbose, label):
 
 
 def _done(verbose, t0):
-    print("    Time:", time() - t0, flush=True) if verbose else print("\t[Done]", flush=True)
+    import os
+    if verbose:
+        print("    Time:", time() - t0, flush=True)
+    elif os.environ.get("EPILOGOS_TIMING"):
+        print("\t[Done] %.2f s" % (time() - t0), flush=True)
+    else:
+        print("\t[Done]", flush=True)
 
 
 def _fitParams(distanceArrNull, quiescenceArr, numProcesses, numTrials, samplingSize):

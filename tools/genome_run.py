@@ -86,7 +86,7 @@ def run(label, out, saliency=None, paired=False, extra=()):
     r = subprocess.run(cmd, cwd=str(ROOT), capture_output=True, text=True, env=dict(os.environ, EPILOGOS_TIMING=os.environ.get("EPILOGOS_TIMING", "1")))
     info = [json.loads(l[2:]) for l in r.stdout.splitlines() if l.startswith("@@")]
     print("== %s" % label)
-    print("".join(l + "\n" for l in r.stdout.splitlines() if "[timing]" in l), end="")
+    print("".join(l + "\n" for l in r.stdout.splitlines() if "[timing]" in l or ("[Done]" in l and " s" in l)), end="")
     if os.environ.get("EPGIO_TIMING") or os.environ.get("EPILOGOS_TIMING") == "2":   # reader phases / part timeline (stderr)
         print("".join(l + "\n" for l in r.stderr.splitlines() if "[epgio]" in l or "[part" in l), end="")
     if r.returncode != 0 or not info:
