@@ -1,0 +1,48 @@
+"""Random shapes through both S3 score kernels -- k_s3_score_bl (biosample lanes, the default for S <= 20) and k_s3_score
+(EPG_S3_SCORE=bins) --: widths around the multiples of 32 (chunks of biosample lanes), bin counts around the multiples of 48
+and 1440 (half-wave and workgroup slices), 2 to 20 states, skewed state distributions, a q with zero (masked) entries, bytes
+that are not states.  The two kernels must agree to 1e-6, each run must repeat bit for bit, and the small shapes must match the
+float64 oracle (scores.py:455-506 restated)."""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+
+from oracle import oracle_np as onp
+
+pytestmark = pytest.mark.gpu
+
+
+def test_s3_score_kernels_random_shapes(monkeypatch):
+    from epilogos_amd import engine
+    engine.require_gpu()
+    rng = np.random.default_rng(5)
+    checked_oracle = 0
+    for case in range(40):
+        S = int(rng.integers(2, 21))
+        N = int(rng.choice([2, 3, 31, 32, 33, 63, 64, 65, 95, 97, 129, 200, int(rng.integers(2, 260))]))
+        R = int(rng.choice([1, 47, 48, 95, 96, 97, 1439, 1440, 1441, 2881, int(rng.integers(1, 4000))]))
+        if case < 8:                                                       # oracle-sized
+            N, R = int(rng.integers(2, 40)), int(rng.integers(1, 150))
+        x = rng.choice(S, size=(R, N), p=rng.dirichlet(np.full(S, 0.3))).astype(np.int8)
+        small = case < 8                                                   # the oracle scores valid states only
+        if not small and R > 3 and N > 2:
+            x[rng.integers(0, R), rng.integers(0, N)] = -1
+            x[rng.integers(0, R), rng.integers(0, N)] = 31
+        q = rng.random((N, N, S, S)).astype(np.float32) ** 3
+        q[rng.random(q.shape) < 0.05] = 0.0
+        q /= q.sum()
+        X = engine.states_to_device(x)
+        qd = torch.from_numpy(q.reshape(-1)).cuda()
+        monkeypatch.delenv("EPG_S3_SCORE", raising=False)
+        a32, a64 = engine.score_s3(X, N, S, qd, want32=True, want64=True)
+        b32, _ = engine.score_s3(X, N, S, qd, want32=True, want64=False)
+        assert torch.equal(a32, b32), (N, S, R)
+        monkeypatch.setenv("EPG_S3_SCORE", "bins")
+        _, c64 = engine.score_s3(X, N, S, qd, want32=False, want64=True)
+        monkeypatch.delenv("EPG_S3_SCORE")
+        np.testing.assert_allclose(a64.cpu().numpy(), c64.cpu().numpy(), rtol=1e-6, atol=1e-9, err_msg=str((N, S, R)))
+        if small:
+            np.testing.assert_allclose(a64.cpu().numpy(), onp.score_s3_f64(x, q, S), rtol=2e-6, atol=1e-9, err_msg=str((N, S, R)))
+            checked_oracle += 1
+    assert checked_oracle == 8

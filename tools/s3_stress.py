@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Random shapes through both S3 score kernels (k_s3_score_bl, the default, and k_s3_score via EPG_S3_SCORE=bins): the two must
-agree to 1e-6 and repeat bit for bit; a few small shapes are also checked against the float64 oracle.  GPU box only.
+agree to 1e-6 and repeat bit for bit.  GPU box only; tests/test_hip_s3_stress.py is the version that also checks the oracle.
 usage: s3_stress.py [--cases 60] [--seed 1]"""
 import argparse
 import os
@@ -13,7 +13,6 @@ ROOT = Path(__file__).resolve().parents[1]
 sys.path.insert(0, str(ROOT))
 import torch  # noqa: E402
 from epilogos_amd import engine  # noqa: E402
-from oracle import oracle_np as onp  # noqa: E402
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--cases", type=int, default=60)
@@ -28,8 +27,7 @@ for case in range(a.cases):
     R = int(rng.choice([1, 47, 48, 95, 96, 97, 1439, 1440, 1441, 2879, 2880, 2881, 4321, int(rng.integers(1, 6000))]))
     p = rng.dirichlet(np.full(S, 0.3))
     x = rng.choice(S, size=(R, N), p=p).astype(np.int8)
-    small = N <= 40 and R <= 200                                        # checked against the oracle, which scores valid states only
-    if R > 3 and N > 2 and not small:
+    if R > 3 and N > 2:
         x[rng.integers(0, R), rng.integers(0, N)] = -1                 # not a state
         x[rng.integers(0, R), rng.integers(0, N)] = 31
     q = rng.random((N, N, S, S)).astype(np.float32) ** 3
@@ -51,7 +49,4 @@ for case in range(a.cases):
     if not ok:
         print("MISMATCH N=%d S=%d R=%d max rel %.3g" % (N, S, R, err.max()))
         sys.exit(1)
-    if small:
-        ref = onp.score_s3_f64(x, q, S)
-        assert np.allclose(A, ref, rtol=2e-6, atol=1e-9), ("oracle", N, S, R)
 print("s3 stress: %d shapes, both kernels agree (worst relative difference %.2e), runs repeat bit for bit" % (a.cases, worst))
