@@ -77,3 +77,18 @@ def test_s2_counts_full_size(world):
     o32, o64 = eng.score_s2_from_binhist(sub, N, S, q2, want32=True, want64=True)
     assert bool(torch.isfinite(o64).all())
     assert float(o64.sum(dim=1).min().item()) > -1e-9                # a KL divergence per bin
+
+
+def test_placed_histogram_cache(world):
+    """engine.place_hist: the histogram cache in another memory class than the matrix -- a view of a held block, the same
+    integers as a plain allocation, a report of what was tried, and never slower than the first candidate."""
+    eng, X, H, counts = world
+    Hp, rep = eng.place_hist(X, N, S)
+    assert Hp.shape == (R, S) and Hp.dtype == torch.int16 and Hp.is_contiguous()
+    acc = torch.zeros(S, dtype=torch.int64, device="cuda")
+    eng.bin_hist(X, N, S, counts=acc, H=Hp)
+    assert torch.equal(Hp, H) and torch.equal(acc, counts)
+    assert 1 <= rep["blocks_tried"] <= 40 and 0 <= rep["picked"] < rep["blocks_tried"]
+    assert rep["ms_picked"] <= rep[[k for k in rep if k.startswith("ms_with_H")][0]][0] + 1e-9
+    small, rep1 = eng.place_hist(X[:1000], N, S)                      # under 1 GiB: a plain allocation
+    assert rep1 == {"tries": 1} and small.shape == (1000, S)
