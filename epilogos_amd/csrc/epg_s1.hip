@@ -165,7 +165,7 @@ __global__ __launch_bounds__(256) void k_score_s1(const char* __restrict__ X, lo
 template <typename OT, bool LDS_T>
 __global__ __launch_bounds__(LDS_T ? 1024 : 256) void k_score_s1_from_hist(const u16* __restrict__ H, long total, int S,
                                                                              const OT* __restrict__ Tg, int nent, OT* __restrict__ out,
-                                                                             u64* __restrict__ zero_counts) {
+                                                                             u64* __restrict__ zero_counts, int rev) {
     extern __shared__ __attribute__((aligned(16))) char smem_t[];
     // the job's state counts are spent once the table exists (this launch is ordered after k_s1_combine): zero them for the
     // next job's accumulation here instead of in a launch of its own
@@ -180,13 +180,16 @@ __global__ __launch_bounds__(LDS_T ? 1024 : 256) void k_score_s1_from_hist(const
     const long nquads = total >> 2;
     const long stride = (long)gridDim.x * blockDim.x;
     long qd = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    // rev: the grid walks the quads from the LAST to the first.  The histograms were written front to back by the count pass
+    // just before, so the ones written last are the ones still in the memory-side cache (DESIGN.md, K1 / score pass).
+    const long qtop = nquads - 1, qsgn = rev ? -1 : 1, qoff = rev ? qtop : 0;     // quad index = qoff + qsgn * qd
     for (; qd + 3 * stride < nquads; qd += 4 * stride) {
         uint2 h[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) h[u] = *reinterpret_cast<const uint2*>(H + 4 * (qd + u * stride));
+        for (int u = 0; u < 4; ++u) h[u] = *reinterpret_cast<const uint2*>(H + 4 * (qoff + qsgn * (qd + u * stride)));
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const long e0 = 4 * (qd + u * stride);
+            const long e0 = 4 * (qoff + qsgn * (qd + u * stride));
             int s = (int)(e0 % S);
             const u32 c[4] = {h[u].x & 0xffffu, h[u].x >> 16, h[u].y & 0xffffu, h[u].y >> 16};
             OT v[4];
@@ -204,7 +207,7 @@ __global__ __launch_bounds__(LDS_T ? 1024 : 256) void k_score_s1_from_hist(const
         }
     }
     for (; qd < nquads; qd += stride) {
-        const long e0 = 4 * qd;
+        const long e0 = 4 * (qoff + qsgn * qd);
         int s = (int)(e0 % S);
         for (int k = 0; k < 4; ++k) {
             const u32 c = H[e0 + k];
@@ -378,6 +381,7 @@ template <typename OT>
 static int launch_score_s1_from_hist_t(const uint16_t* H, long total, int32_t S, const OT* T, int nent, OT* out, u64* zero_counts, hipStream_t st) {
     const size_t tbytes = (size_t)nent * sizeof(OT);
     static const bool no_lds = [] { const char* e = getenv("EPG_S1_SCORE"); return e && e[0] == 'g'; }();   // A/B: gather from memory
+    static const int rev = [] { const char* e = getenv("EPG_S1_SCORE_ORDER"); return (e && e[0] == 'f') ? 0 : 1; }();   // A/B: "forward"
     if (tbytes <= 150 * 1024 && !no_lds) {             // the table in LDS: blocks of 16 waves, as many per CU as tables fit (<= 2)
         const int per_cu = tbytes <= 75 * 1024 ? 2 : 1;
         long nb = (total / 4 + 4095) / 4096;
@@ -389,12 +393,12 @@ static int launch_score_s1_from_hist_t(const uint16_t* H, long total, int32_t S,
             EPG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
             attr_set = true;
         }
-        hipLaunchKernelGGL(kern, dim3((int)nb), dim3(1024), tbytes, st, H, total, S, T, nent, out, zero_counts);
+        hipLaunchKernelGGL(kern, dim3((int)nb), dim3(1024), tbytes, st, H, total, S, T, nent, out, zero_counts, rev);
     } else {
         long nb = (total / 4 + 1023) / 1024;
         if (nb > num_cus() * 8L) nb = num_cus() * 8L;  // 8 blocks/CU measured best (16: +5 %); nt stores: no gain
         if (nb < 1) nb = 1;
-        hipLaunchKernelGGL((k_score_s1_from_hist<OT, false>), dim3((int)nb), dim3(256), 0, st, H, total, S, T, nent, out, zero_counts);
+        hipLaunchKernelGGL((k_score_s1_from_hist<OT, false>), dim3((int)nb), dim3(256), 0, st, H, total, S, T, nent, out, zero_counts, rev);
     }
     EPG_LAUNCH_CHECK("k_score_s1_from_hist");
     return EPG_OK;
