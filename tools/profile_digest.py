@@ -30,6 +30,19 @@ if stats.exists():
     for r in keep:
         lines.append("| `%s` | %s | %.0f | %s | %s |" % (r["Name"].split("(")[0], r["Calls"], float(r["AverageNs"]), r["MinNs"], r["MaxNs"]))
     lines.append("")
+trace = src / "stats" / "p_kernel_trace.csv"
+if trace.exists() and bench:
+    # engine.place_hist times the same kernel on candidate blocks before the steps (slow candidates included), so the table
+    # above mixes those probe launches in; the bench's own launches are the LAST warmup + steps dispatches with the H store
+    k1 = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) for r in csv.DictReader(open(trace))
+          if "k_bin_hist" in r["Kernel_Name"]]
+    k1.sort()
+    steps = 20
+    if len(k1) >= steps:
+        d = [x[1] for x in k1[-steps:]]
+        lines += ["k_bin_hist over the LAST %d dispatches of the trace (the timed steps; the rows above include the %d launches of "
+                  "the placement probe and the warm-up): avg %.0f ns, min %d, max %d -- bench line (HIP events, un-profiled run): %.0f ns"
+                  % (steps, len(k1) - steps, sum(d) / len(d), min(d), max(d), bench["kernels_ms"]["k_bin_hist"] * 1e6), ""]
 stats_all = src / "stats_all" / "p_kernel_stats.csv"
 if stats_all.exists():
     rows = list(csv.DictReader(open(stats_all)))
