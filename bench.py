@@ -206,7 +206,12 @@ def main():
 
     last_counts = torch.zeros(S, dtype=torch.int64, device=dev)
 
+    if os.environ.get("EPG_BENCH_NOEVENTS"):         # diagnostic: what the three event records per step cost (kernels_ms is then NaN)
+        ev = []
+
     def step(k=None, keep=False):
+        if not ev:
+            k = None
         if k is not None:
             ev[k][0].record()
         engine.bin_hist(X, N, S, counts=counts, H=H)                       # STEP 1: expected pass (counts start zeroed)
@@ -252,8 +257,8 @@ def main():
     if os.environ.get("EPG_BENCH_TRACE") and rank == 0:      # per-step k_bin_hist times (clock ramps, box variance)
         print("k_bin_hist ms per step:", " ".join("%.3f" % e[0].elapsed_time(e[1]) for e in ev), file=sys.stderr, flush=True)
         print("host enqueue done at ms:", " ".join("%.1f" % (t * 1e3) for t in host_t), file=sys.stderr, flush=True)
-    hist_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in ev])) if args.steps else float("nan")
-    rest_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in ev])) if args.steps else float("nan")
+    hist_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in ev])) if ev else float("nan")
+    rest_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in ev])) if ev else float("nan")
 
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
