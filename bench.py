@@ -70,8 +70,16 @@ def cpu_baseline(n_biosamples, n_states, target_seconds=10.0):
     q = onp.normalise(onp.expected_s1(x[:2000], n_states))
     bps1, secs1, _, bins1 = rb.timed_pool_run(x, q, n_states, 1, seconds=min(4.0, target_seconds))
     bps, secs, cores, bins = rb.timed_pool_run(x, q, n_states, cores, seconds=target_seconds)
+    # second, fairer line: the vectorised numpy restatement (whole-array histogram + masked KL), one core
+    xv = x[:20000]
+    t0, nv = time.perf_counter(), 0
+    while time.perf_counter() - t0 < 2.0:
+        onp.score_s1(xv, onp.normalise(onp.expected_s1(xv, n_states)), n_states)
+        nv += xv.shape[0]
+    vec = nv / (time.perf_counter() - t0)
     return {"value": round(bps / 1e6, 6), "unit": "Mbins/s", "cores": cores, "kind": "port",
             "one_worker_bins_per_s": round(bps1, 1), "per_core_bins_per_s": round(bps / cores, 1),
+            "vectorised_numpy_one_core_bins_per_s": round(vec, 1),
             "parallel_efficiency": round(bps / (cores * bps1), 3),
             "sample": "%d bin-scorings in %.1f s wall (plus %d in %.1f s on one worker) over %d distinct synthetic bins x %d "
                       "biosamples (same state frequencies as the GPU workload): per-bin numpy loop of oracle/rowloop_baseline.py "
@@ -292,7 +300,10 @@ def main():
                        "partition": "contiguous bin ranges per GPU (helpers.splitRows rule), one RCCL all-reduce of int64[%d]" % S},
             "roofline": {"bound": "hbm", "kernel": "k_bin_hist", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": traffic_note,
-                         "algorithmic_bytes_per_bin": N, "avg_launch_ms": round(hist_ms, 4)},
+                         "algorithmic_bytes_per_bin": N, "avg_launch_ms": round(hist_ms, 4),
+                         # the whole step against the bytes it has to move: X read once, H written and read, float32 scores written
+                         "step_bytes_per_bin": N + 2 * 2 * S + 4 * S,
+                         "step_GBps": round(R * (N + 2 * 2 * S + 4 * S) / (ms_per_step * 1e-3) / 1e9, 1)},
             "kernels_ms": {"k_bin_hist": round(hist_ms, 4), "allreduce+combine(normalise,table)+score_from_hist": round(rest_ms, 4)},
             "placement": placement,
             "cpu_baseline": cpu,
