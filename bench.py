@@ -209,7 +209,7 @@ def main():
     out32 = torch.empty((R, S), dtype=torch.float32, device=dev)
     ws_s1 = engine.workspace(1, 0, N, S, device=dev)
     try:
-        H, placement = engine.place_hist(X, N, S)
+        H, placement = engine.place_hist(X, N, S, park=True)   # the blocks it did not keep go back after the timed region
     except Exception as e:                     # the search is an optimisation: never let it take the measurement down
         torch.cuda.empty_cache()
         H, placement = torch.empty((R, S), dtype=torch.int16, device=dev), {"tries": 1, "search_failed": repr(e)[:200]}
@@ -256,6 +256,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
 
+    engine.release_parked()
     # sanity of the last step (cheap, outside the timed region): every state byte counted, scores finite
     total = int(last_counts.sum().item())
     assert total == R_global * N, "state counts %d != bins*biosamples %d" % (total, R_global * N)

@@ -39,7 +39,10 @@ def alloc_states(R, N, device="cuda"):
     return torch.empty((R, padded_width(N)), dtype=torch.int8, device=device)
 
 
-def place_hist(X, N, S, tries=None, block_bytes=None):
+_parked = []
+
+
+def place_hist(X, N, S, tries=None, block_bytes=None, park=False):
     """The [R, S] uint16 histogram cache for a RESIDENT state matrix X, allocated in another memory CLASS than X.
     The 288 GB of an MI355X fall into three classes of a third each, in contiguous runs of 4-64 GiB of the driver's
     allocation order (tools/placement_map.py, placement_map2.py; profiles/r02ae_*: 21 + 21 + 21 of 70 blocks of 4 GiB, the
@@ -51,6 +54,9 @@ def place_hist(X, N, S, tries=None, block_bytes=None):
     so that the driver walks on through its memory -- and the head of each is tried as H with four launches of the real kernel;
     the first whose store costs < 13 % over the counts-only launch is kept, else the best; the other blocks go back to the
     driver.  H is a view of its block (the block's tail stays allocated with it).  Returns (H, report).
+    park=True keeps the other blocks allocated until `release_parked()`: device memory that goes back to the driver is scrubbed
+    in the background (~30 GB/s), and while that lasts every HBM-bound kernel runs ~5 % slower (bench.py: the first ~100 steps
+    after 8 GiB were returned, 2.45 against 2.32 ms) -- a measurement that follows the search should not pay for it.
     EPILOGOS_PLACEMENT_TRIES overrides `tries` (default 40 blocks; 1 = a plain allocation); a matrix under 1 GiB is not worth it."""
     import os
     R = X.shape[0]
@@ -97,9 +103,20 @@ def place_hist(X, N, S, tries=None, block_bytes=None):
     report = {"blocks_tried": len(blocks), "block_GiB": round(block_bytes / 2**30, 2), "picked": pick,
               "ms_counts_only": round(base, 3), "ms_picked": round(times[pick], 3),
               "ms_with_H" + ("" if len(times) <= 12 else "_first4_last8"): [round(v, 3) for v in shown]}
+    if park:
+        _parked.extend(b for i, b in enumerate(blocks) if i != pick)
+        report["parked_GiB"] = round(sum(b.numel() for b in _parked) / 2**30, 1)
+        del blocks, counts
+        return H, report
     del blocks, counts
     torch.cuda.empty_cache()
     return H, report
+
+
+def release_parked():
+    """Hand the blocks a `place_hist(..., park=True)` search did not keep back to the driver."""
+    _parked.clear()
+    torch.cuda.empty_cache()
 
 
 def states_to_device(x, device="cuda"):
