@@ -187,7 +187,9 @@ __global__ __launch_bounds__(256, S2W_MAXPASS == 1 ? 4 : 2) void k_s2_hist_wave(
     auto fetch = [&](long tile, int c) -> uint4 {
         uint4 v = make_uint4(0, 0, 0, 0);
         if (tile >= ntiles || c >= nchunks) return v;
-        const long off = tile * raw_bytes + 16L * c;
+        // the grid walks the tiles from the LAST to the first: the count pass wrote H front to back just before, its tail is
+        // what the memory-side cache still holds (a sum: the order does not matter to the result)
+        const long off = (ntiles - 1 - tile) * raw_bytes + 16L * c;
         if (off + 16 <= total_bytes && 16 * c + 16 <= raw_bytes) {
             v = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(H) + off);
             if (H2) {
@@ -255,7 +257,7 @@ __global__ __launch_bounds__(256, S2W_MAXPASS == 1 ? 4 : 2) void k_s2_hist_wave(
                 for (int c = 0; c < 3; ++c) rs[p][c] += ps[c];
             }
         } else {                                               // counts >= 4096: 64-bit products straight from the raw tile
-            const long r0 = tile * 64;
+            const long r0 = (ntiles - 1 - tile) * 64;
             const int rows = (int)(R - r0 < 64 ? R - r0 : 64);
 #pragma unroll
             for (int p = 0; p < S2W_MAXPASS; ++p) {
