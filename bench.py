@@ -202,12 +202,12 @@ def main():
     else:
         X = engine.alloc_states(R, N, device=dev)
     generate_shard(torch, X, N, S, bin0, dist=args.dist)
-    # the histogram cache goes where k_bin_hist's writes do not collide with its reads of X (engine.place_hist: the device
-    # memory has classes of regions, same class = up to 20 % slower); what was tried and measured is in the JSON line
     counts = torch.zeros(S, dtype=torch.int64, device=dev)
     q = torch.empty(S, dtype=torch.float32, device=dev)
     out32 = torch.empty((R, S), dtype=torch.float32, device=dev)
     ws_s1 = engine.workspace(1, 0, N, S, device=dev)
+    # last, the histogram cache: it goes where k_bin_hist's writes do not collide with its reads of X (engine.place_hist: the
+    # device memory has three classes of regions, X and H in one class = 17 % slower); what was tried is in the JSON line
     try:
         H, placement = engine.place_hist(X, N, S, park=True)   # the blocks it did not keep go back after the timed region
     except Exception as e:                     # the search is an optimisation: never let it take the measurement down
