@@ -52,6 +52,7 @@ constexpr int G_PATCH_P = 8, G_PATCH_Q = G_WN == 2 ? 8 : 4;           // workgro
 static_assert(G_LA == 2 || G_LA == 3, "five or six loads per wave and stage");
 constexpr long G_KC_MAX = 1048576;                      // bins per chunk the workspace size is quoted for (multiple of 512; < 2^24)
 constexpr long G_KC_MIN = 16384;
+constexpr long G_REDUCED_MIN_BINS = 262144;             // calls shorter than this take the full contraction (see hist_s3_gemm)
 
 __host__ __device__ inline int g_rows_padded(int NS) { return (NS + G_BN - 1) / G_BN * G_BN; }
 
@@ -63,20 +64,25 @@ __device__ __forceinline__ u32 g_eq_pair_fp4(u32 w0, u32 w1, u32 pat) {
     return ((d0 >> 6) & 0x02020202u) | ((d1 >> 2) & 0x20202020u);
 }
 
+// gate / want (also k_s3_syrk_fp4): the launch does its work only when *gate == want (gate == nullptr: always) -- the reduced
+// and the full contraction are both enqueued and the "a byte of this call is not a state" flag on the device picks one
 __global__ __launch_bounds__(256) void k_s3_onehot_fp4(const char* __restrict__ XT, long Rp, int N, int S, int NS, int NT, long k0,
-                                                        long nksteps, uint4* __restrict__ E4) {
+                                                        long nksteps, uint4* __restrict__ E4, const int* __restrict__ gate, int want) {
+    if (gate && *gate != want) return;
     const int lane = threadIdx.x & 63;
-    const long id = (long)blockIdx.x * 4 + (threadIdx.x >> 6);          // (kstep, tile), tile fastest: 1 KiB per wave, in order
-    if (id >= nksteps * NT) return;
-    const int tile = (int)(id % NT);
-    const long kstep = id / NT;
-    const int r = tile * 32 + (lane & 31);
-    const int a = r < NS ? r / S : N - 1;
-    const u32 pat = (u32)(r < NS ? r - a * S : 30) * 0x01010101u;        // rows past N*S match nothing (states <= 29 or 31)
-    const char* src = XT + (long)a * Rp + k0 + 64 * kstep + 32 * (lane >> 5);
-    const uint4 r0 = *reinterpret_cast<const uint4*>(src), r1 = *reinterpret_cast<const uint4*>(src + 16);
-    E4[id * 64 + lane] = make_uint4(g_eq_pair_fp4(r0.x, r0.y, pat), g_eq_pair_fp4(r0.z, r0.w, pat), g_eq_pair_fp4(r1.x, r1.y, pat),
-                                    g_eq_pair_fp4(r1.z, r1.w, pat));
+    // (kstep, tile), tile fastest: 1 KiB per wave, in order; a bounded grid strides over them (a gated-off launch of one
+    // block per four tiles -- 1.9 M blocks per 1 M bins -- took 0.39 ms to do nothing)
+    for (long id = (long)blockIdx.x * 4 + (threadIdx.x >> 6); id < nksteps * NT; id += (long)gridDim.x * 4) {
+        const int tile = (int)(id % NT);
+        const long kstep = id / NT;
+        const int r = tile * 32 + (lane & 31);
+        const int a = r < NS ? r / S : N - 1;
+        const u32 pat = (u32)(r < NS ? r - a * S : 30) * 0x01010101u;    // rows past N*S match nothing (states <= 29 or 31)
+        const char* src = XT + (long)a * Rp + k0 + 64 * kstep + 32 * (lane >> 5);
+        const uint4 r0 = *reinterpret_cast<const uint4*>(src), r1 = *reinterpret_cast<const uint4*>(src + 16);
+        E4[id * 64 + lane] = make_uint4(g_eq_pair_fp4(r0.x, r0.y, pat), g_eq_pair_fp4(r0.z, r0.w, pat), g_eq_pair_fp4(r1.x, r1.y, pat),
+                                        g_eq_pair_fp4(r1.z, r1.w, pat));
+    }
 }
 
 // Workgroup tasks (P = G_WM-tuple of A blocks, Q = G_WN-tuple of B blocks; needed when some bm <= bn, i.e. P <= g_pmax(Q)),
@@ -164,7 +170,9 @@ __device__ __forceinline__ void g_mfma_loads(const GOps& o, bool active, v16f (&
 
 __global__ __launch_bounds__(64 * G_NW, 2) void k_s3_syrk_fp4(const char* __restrict__ E4, int NT, long nstages, long stages_per_split,
                                                          const int* __restrict__ tasks, int ntasks, int N, int S,
-                                                         int* __restrict__ counts, int dbg) {
+                                                         int* __restrict__ counts, int dbg, const int* __restrict__ gate, int want,
+                                                         int* __restrict__ marg) {
+    if (gate && *gate != want) return;
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -289,6 +297,8 @@ __global__ __launch_bounds__(64 * G_NW, 2) void k_s3_syrk_fp4(const char* __rest
                     const int m = m0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                     const int a = m / S, i = m - a * S;
                     if (v && m < NS && n < NS && a != b) atomicAdd(&counts[((long)a * N + b) * SS + i * S + j], v);
+                    // the diagonal cell of (a, i) is the number of bins in which biosample a is in state i: the marginals
+                    if (marg && v && m == n && m < NS) atomicAdd(&marg[a * 32 + i], v);
                 }
             }
             if (bm != bn) {
@@ -313,6 +323,7 @@ __global__ __launch_bounds__(64 * G_NW, 2) void k_s3_syrk_fp4(const char* __rest
 int transpose_states(const char* X, int64_t R, int32_t N, int64_t ldx, int32_t S, char* XT, int64_t Rp, int shift, hipStream_t st);
 
 static long g_chunk_bins(long Rp) { return Rp < G_KC_MAX ? Rp : G_KC_MAX; }
+static int64_t g_reduced_bytes(int N, int S);
 
 static int64_t g_fixed_bytes(long Rp, int N, int NQ) {
     return align_up((int64_t)N * Rp + 64, 1024) + align_up((int64_t)g_ntasks(NQ) * 4, 1024);
@@ -331,22 +342,122 @@ int64_t s3_gemm_ws_min_bytes(int64_t R, int N, int S) {
 int64_t s3_gemm_ws_bytes(int64_t R, int N, int S) {
     const long Rp = align_up(R, 512);
     const int NSP = g_rows_padded(N * S), NT = NSP / 32, NQ = NSP / G_BN;
-    return g_fixed_bytes(Rp, N, NQ) + (int64_t)NT * 1024 * (g_chunk_bins(Rp) / 64);
+    return g_fixed_bytes(Rp, N, NQ) + (int64_t)NT * 1024 * (g_chunk_bins(Rp) / 64) + (S >= 3 ? g_reduced_bytes(N, S) : 0);
 }
+
+int transpose_states_flag(const char* X, int64_t R, int32_t N, int64_t ldx, int32_t S, char* XT, int64_t Rp, int shift, int bad, int* dirty,
+                          hipStream_t st);
+
+// ---------------------------------------------------------------------------------------------------------------
+// The REDUCED contraction.  In a bin every biosample is in exactly one state, so the one-hot column of ONE state per biosample
+// is 1 minus the others: with m = S - 1 left out of the operand the contraction runs on N (S - 1) rows -- (17/18)^2 of the
+// matrix work at S = 18, 1406 instead of 1640 workgroup tasks at N = 833 -- and the cells of state m follow from the
+// marginals M_a[i] = #{bins : x_a = i} (the contraction's own diagonal cells) and the number of bins R:
+//     C[a,b,m,j] = M_b[j] - sum_{i != m} C[a,b,i,j]        C[a,b,i,m] = M_a[i] - sum_{j != m} C[a,b,i,j]
+//     C[a,b,m,m] = R - sum_{i != m} M_a[i] - sum_{j != m} M_b[j] + sum_{i,j != m} C[a,b,i,j]
+// Integers: exact.  The identity needs every state byte of the call to be a state; k_transpose_states reports whether one is
+// not, on the device, and BOTH contractions are enqueued, gated on that flag: a clean call (every call of the command line,
+// whose parser checks the range) runs the reduced one plus k_s3_reconstruct, a call with a "not a state" byte the full one.
+// No host synchronisation, the same counts either way (tests/test_hip_s3_n833.py runs both on one matrix).
+// ---------------------------------------------------------------------------------------------------------------
+// A block takes RC_P consecutive (a, b) pairs: their reduced cells (RC_P * (S-1)^2 contiguous ints) go through LDS, row and
+// column sums are formed there, and every thread then adds whole contiguous runs of the full cells to counts (coalesced
+// read-modify-write; nothing else writes counts while this runs).  ~0.8 GB read + 1.8 GB read-modify-write at N = 833.
+constexpr int RC_P = 16;
+__global__ __launch_bounds__(256) void k_s3_reconstruct(const int* __restrict__ Cr, const int* __restrict__ marg, long R, int N, int S,
+                                                         int* __restrict__ counts, const int* __restrict__ gate, int want) {
+    if (gate && *gate != want) return;
+    extern __shared__ int rc_s[];
+    const int S1 = S - 1, c1 = S1 * S1, c2 = S * S;
+    int* s_cr = rc_s;                         // [RC_P][S1][S1]
+    int* s_row = s_cr + RC_P * c1;            // [RC_P][S1]  sum over j of the reduced cell's row i
+    int* s_col = s_row + RC_P * S1;           // [RC_P][S1]  sum over i of column j
+    long long* s_mm = reinterpret_cast<long long*>(s_col + RC_P * S1 + ((RC_P * (c1 + 2 * S1)) & 1));   // [RC_P] the (m, m) cell
+    const long npairs = (long)N * N;
+    for (long p0 = (long)blockIdx.x * RC_P; p0 < npairs; p0 += (long)gridDim.x * RC_P) {
+        const int np = (int)(npairs - p0 < RC_P ? npairs - p0 : RC_P);
+        __syncthreads();
+        for (int e = threadIdx.x; e < np * c1; e += 256) s_cr[e] = Cr[p0 * c1 + e];
+        __syncthreads();
+        for (int t = threadIdx.x; t < np * 2 * S1; t += 256) {
+            const int p = t / (2 * S1), k = t - p * 2 * S1;
+            const int* cr = s_cr + p * c1;
+            int acc = 0;
+            if (k < S1) {
+                for (int j = 0; j < S1; ++j) acc += cr[k * S1 + j];
+                s_row[p * S1 + k] = acc;
+            } else {
+                for (int i = 0; i < S1; ++i) acc += cr[i * S1 + (k - S1)];
+                s_col[p * S1 + (k - S1)] = acc;
+            }
+        }
+        __syncthreads();
+        if ((int)threadIdx.x < np) {
+            const int p = threadIdx.x;
+            const long ab = p0 + p;
+            const int a = (int)(ab / N), b = (int)(ab - (long)a * N);
+            long long all = 0, ma = 0, mb = 0;
+            for (int i = 0; i < S1; ++i) {
+                all += s_row[p * S1 + i];
+                ma += marg[a * 32 + i];
+                mb += marg[b * 32 + i];
+            }
+            s_mm[p] = (long long)R - ma - mb + all;
+        }
+        __syncthreads();
+        int* out = counts + p0 * c2;
+        const int nout = np * c2;
+        for (int e0 = threadIdx.x; e0 < nout; e0 += 256 * 4) {                // four cells per thread and turn: their loads in flight together
+            int old[4], add[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int e = e0 + 256 * u;
+                old[u] = e < nout ? out[e] : 0;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int e = e0 + 256 * u;
+                add[u] = 0;
+                if (e >= nout) continue;
+                const int p = e / c2, rem = e - p * c2, i = rem / S, j = rem - i * S;
+                const long ab = p0 + p;
+                const int a = (int)(ab / N), b = (int)(ab - (long)a * N);
+                if (a == b) continue;                                       // the diagonal stays zero (expected.py:183-200)
+                if (i < S1 && j < S1) add[u] = s_cr[p * c1 + i * S1 + j];
+                else if (i == S1 && j < S1) add[u] = marg[b * 32 + j] - s_col[p * S1 + j];     // x_a = m, x_b = j
+                else if (j == S1 && i < S1) add[u] = marg[a * 32 + i] - s_row[p * S1 + i];     // x_a = i, x_b = m
+                else add[u] = (int)s_mm[p];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int e = e0 + 256 * u;
+                if (e < nout && add[u]) out[e] = old[u] + add[u];
+            }
+        }
+    }
+}
+
+static int64_t g_reduced_bytes(int N, int S) {      // reduced counts | marginals [N][32] | flag
+    return align_up((int64_t)N * N * (S - 1) * (S - 1) * 4, 1024) + align_up((int64_t)N * 32 * 4, 1024) + 1024;
+}
+
+static int hist_s3_gemm_run(const char* XT, long Rp, int N, int S, int32_t* counts, int* tasks, char* E4, long KC, int dbg_env,
+                            const int* gate, int want, int* marg, hipStream_t st);
 
 int hist_s3_gemm(const char* X, int64_t R, int32_t N, int64_t ldx, int32_t S, int32_t* counts, void* ws, int64_t ws_bytes,
                  hipStream_t st) {
     static const int dbg_env = [] { const char* e = getenv("EPG_S3_DBG"); return e ? atoi(e) : 0; }();
+    // EPG_S3_REDUCED (read per call: the tests run both in one process): 0 = full contraction only, 1 = the reduced one whenever
+    // the workspace allows; default: from G_REDUCED_MIN_BINS bins on -- its fixed cost per call (zeroing and re-expanding a
+    // 0.8 GB count array: ~1.4 ms at N = 833) is what it saves on ~260 K bins
+    const char* red_env = getenv("EPG_S3_REDUCED");
+    const bool no_reduced = red_env ? red_env[0] == '0' : R < G_REDUCED_MIN_BINS;
     const long Rp = align_up(R, 512);                  // whole stages; padded bins hold 31, which matches no row
     const int NS = N * S, NSP = g_rows_padded(NS), NT = NSP / 32, NQ = NSP / G_BN;
     const int ntasks = g_ntasks(NQ);
     char* XT = reinterpret_cast<char*>(ws);
     int* tasks = reinterpret_cast<int*>(XT + align_up((int64_t)N * Rp + 64, 1024));
     char* E4 = reinterpret_cast<char*>(tasks) + align_up((int64_t)ntasks * 4, 1024);
-    int rc = transpose_states(X, R, N, ldx, S, XT, Rp, 0, st);
-    if (rc) return rc;
-    hipLaunchKernelGGL(k_s3_tasks, dim3(1), dim3(1), 0, st, NQ, tasks);
-    EPG_LAUNCH_CHECK("k_s3_tasks");
     static bool attr_set = false;
     if (dbg_env & 4) {
         int nblk = -1;
@@ -360,18 +471,70 @@ int hist_s3_gemm(const char* X, int64_t R, int32_t N, int64_t ldx, int32_t S, in
     }
     // chunk = as many bins of the operand as the caller's workspace holds (every chunk ends in one epilogue of ~2 atomics
     // per cell of counts, so fewer, longer chunks are better); EPG_S3_KC overrides for measurements
-    long KC = (ws_bytes - g_fixed_bytes(Rp, N, NQ)) / ((int64_t)NT * 1024) * 64 / 512 * 512;
     static const long kc_env = [] { const char* e = getenv("EPG_S3_KC"); return e ? atol(e) / 512 * 512 : 0L; }();
-    if (kc_env > 0 && kc_env < KC) KC = kc_env;
-    if (KC > Rp) KC = Rp;
-    if (KC > (1L << 24) - 512) KC = (1L << 24) - 512;   // float32 accumulators hold exact integers
+    auto chunk_bins = [&](int64_t bytes_for_e4) {
+        long KC = bytes_for_e4 / ((int64_t)NT * 1024) * 64 / 512 * 512;
+        if (kc_env > 0 && kc_env < KC) KC = kc_env;
+        if (KC > Rp) KC = Rp;
+        if (KC > (1L << 24) - 512) KC = (1L << 24) - 512;   // float32 accumulators hold exact integers
+        return KC;
+    };
+    const int64_t fixed = g_fixed_bytes(Rp, N, NQ);
+    // the reduced path when the workspace also holds its count array and still a 16 K-bin chunk of the operand
+    const int64_t red = g_reduced_bytes(N, S);
+    const bool reduced = !no_reduced && S >= 3 && ws_bytes - fixed - red >= (int64_t)NT * 1024 * (G_KC_MIN / 64 < Rp / 64 ? G_KC_MIN / 64 : Rp / 64);
+    if (!reduced) {
+        const long KC = chunk_bins(ws_bytes - fixed);
+        if (KC < 512) return fail(EPG_ERR_WORKSPACE, "hist_s3: workspace too small for the precomputed-operand kernel");
+        int rc = transpose_states(X, R, N, ldx, S, XT, Rp, 0, st);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_s3_tasks, dim3(1), dim3(1), 0, st, NQ, tasks);
+        EPG_LAUNCH_CHECK("k_s3_tasks");
+        return hist_s3_gemm_run(XT, Rp, N, S, counts, tasks, E4, KC, dbg_env, nullptr, 0, nullptr, st);
+    }
+    char* tail = reinterpret_cast<char*>(ws) + (ws_bytes - red) / 1024 * 1024;
+    int* Cr = reinterpret_cast<int*>(tail);
+    int* marg = reinterpret_cast<int*>(tail + align_up((int64_t)N * N * (S - 1) * (S - 1) * 4, 1024));
+    int* dirty = marg + (align_up((int64_t)N * 32 * 4, 1024) / 4);
+    const long KC = chunk_bins(tail - E4);
     if (KC < 512) return fail(EPG_ERR_WORKSPACE, "hist_s3: workspace too small for the precomputed-operand kernel");
+    EPG_HIP(hipMemsetAsync(tail, 0, (size_t)red - 1024 + 64, st));        // reduced counts, marginals, flag
+    int rc = transpose_states_flag(X, R, N, ldx, S, XT, Rp, 0, 31, dirty, st);
+    if (rc) return rc;
+    // clean call: the contraction without state S - 1 (same XT: a byte S - 1 matches none of the N (S - 1) rows), then the rest
+    const int NQ1 = g_rows_padded(N * (S - 1)) / G_BN;
+    int* tasks1 = tasks;                                                   // the reduced task list is a prefix-compatible rebuild
+    hipLaunchKernelGGL(k_s3_tasks, dim3(1), dim3(1), 0, st, NQ1, tasks1);
+    EPG_LAUNCH_CHECK("k_s3_tasks");
+    rc = hist_s3_gemm_run(XT, Rp, N, S - 1, Cr, tasks1, E4, KC, dbg_env, dirty, 0, marg, st);
+    if (rc) return rc;
+    {
+        long blocks = ((long)N * N + RC_P - 1) / RC_P;
+        if (blocks > num_cus() * 16L) blocks = num_cus() * 16L;
+        const int S1 = S - 1;
+        const size_t shmem = (size_t)(RC_P * (S1 * S1 + 2 * S1) + 2) * 4 + RC_P * 8;
+        hipLaunchKernelGGL(k_s3_reconstruct, dim3((unsigned)blocks), dim3(256), shmem, st, Cr, marg, (long)R, N, S, counts, dirty, 0);
+        EPG_LAUNCH_CHECK("k_s3_reconstruct");
+    }
+    // a call with a "not a state" byte: the full contraction (its launches return at once on a clean call)
+    hipLaunchKernelGGL(k_s3_tasks, dim3(1), dim3(1), 0, st, NQ, tasks);
+    EPG_LAUNCH_CHECK("k_s3_tasks");
+    return hist_s3_gemm_run(XT, Rp, N, S, counts, tasks, E4, KC, dbg_env, dirty, 1, nullptr, st);
+}
+
+// the chunk loop of one contraction over the transposed matrix: one-hot operand of a chunk, then the SYRK kernel
+static int hist_s3_gemm_run(const char* XT, long Rp, int N, int S, int32_t* counts, int* tasks, char* E4, long KC, int dbg_env,
+                            const int* gate, int want, int* marg, hipStream_t st) {
+    const int NS = N * S, NSP = g_rows_padded(NS), NT = NSP / 32, NQ = NSP / G_BN;
+    const int ntasks = g_ntasks(NQ);
     for (long k0 = 0; k0 < Rp; k0 += KC) {
         const long kc = Rp - k0 < KC ? Rp - k0 : KC;   // multiple of 512
         const long nksteps = kc / 64, nstages = nksteps / G_KS;
         const long waves = nksteps * NT;
-        hipLaunchKernelGGL(k_s3_onehot_fp4, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, XT, Rp, N, S, NS, NT, k0, nksteps,
-                           reinterpret_cast<uint4*>(E4));
+        long oh_blocks = (waves + 3) / 4;
+        if (oh_blocks > num_cus() * 64L) oh_blocks = num_cus() * 64L;
+        hipLaunchKernelGGL(k_s3_onehot_fp4, dim3((unsigned)oh_blocks), dim3(256), 0, st, XT, Rp, N, S, NS, NT, k0, nksteps,
+                           reinterpret_cast<uint4*>(E4), gate, want);
         EPG_LAUNCH_CHECK("k_s3_onehot_fp4");
         // Split the chunk's stages over blockIdx.y: few tasks (small N) need it to give every CU work, and with one
         // workgroup per CU the last round of a launch is only partly full -- 1640 tasks on 256 CUs are 6.4 rounds, paid as
@@ -391,7 +554,7 @@ int hist_s3_gemm(const char* X, int64_t R, int32_t N, int64_t ldx, int32_t S, in
         const long per = (nstages + splits - 1) / splits;
         const long nsplit = (nstages + per - 1) / per;
         hipLaunchKernelGGL(k_s3_syrk_fp4, dim3((unsigned)ntasks, (unsigned)nsplit), dim3(64 * G_NW), G_LDS_BYTES, st, E4, NT, nstages,
-                           per, tasks, ntasks, N, S, counts, dbg_env);
+                           per, tasks, ntasks, N, S, counts, dbg_env, gate, want, marg);
         EPG_LAUNCH_CHECK("k_s3_syrk_fp4");
     }
     return EPG_OK;

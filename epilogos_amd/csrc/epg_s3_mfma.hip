@@ -35,11 +35,12 @@ constexpr int MF_T = 3;               // tiles per block side
 constexpr int MF_ROWS = 32 * MF_T;    // (sample, state) rows per block
 
 __global__ __launch_bounds__(256) void k_transpose_states(const char* __restrict__ X, long R, int N, long ldx, int S,
-                                                           char* __restrict__ XT, long Rp, int shift, int bad) {
+                                                           char* __restrict__ XT, long Rp, int shift, int bad, int* __restrict__ dirty) {
     __shared__ unsigned char tile[64][65];
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const long b0 = (long)blockIdx.x * 64;
     const int s0 = blockIdx.y * 64;
+    bool seen_bad = false;                            // a byte of the matrix proper that is not a state
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
         const long bin = b0 + ty + 4 * i;
@@ -47,10 +48,11 @@ __global__ __launch_bounds__(256) void k_transpose_states(const char* __restrict
         unsigned char v = (unsigned char)bad;         // "not a state": bins past R, states outside [0, S)
         if (bin < R && smp < N) {
             v = (unsigned char)X[bin * ldx + smp];
-            if (v >= S) v = (unsigned char)bad;
+            if (v >= S) { v = (unsigned char)bad; seen_bad = true; }
         }
         tile[ty + 4 * i][tx] = (unsigned char)(v << shift);
     }
+    if (dirty && __any(seen_bad) && (threadIdx.x & 63) == 0) atomicOr(dirty, 1);
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
@@ -462,11 +464,16 @@ int64_t s3_mfma_ws_bytes(int64_t R, int N) { return align_up((int64_t)N * align_
 // bytes are stored shifted left by `shift` (the S3 score kernel wants 4 * state, a ready-made LDS byte offset)
 // `bad` is the code stored for "not a state" (31 for the kernels of this file and k_s3_score; S for k_s3_score_bl, whose
 // table rows have exactly one zero column after the S states)
-int transpose_states_bad(const char* X, int64_t R, int32_t N, int64_t ldx, int32_t S, char* XT, int64_t Rp, int shift, int bad, hipStream_t st) {
+// `dirty` (optional, device int, caller-zeroed): set to 1 when a byte of the first N columns of a row < R is not a state
+int transpose_states_flag(const char* X, int64_t R, int32_t N, int64_t ldx, int32_t S, char* XT, int64_t Rp, int shift, int bad, int* dirty,
+                          hipStream_t st) {
     hipLaunchKernelGGL(k_transpose_states, dim3((unsigned)((Rp + 63) / 64), (unsigned)((N + 63) / 64)), dim3(256), 0, st, X, (long)R, N,
-                       (long)ldx, S, XT, (long)Rp, shift, bad);
+                       (long)ldx, S, XT, (long)Rp, shift, bad, dirty);
     EPG_LAUNCH_CHECK("k_transpose_states");
     return EPG_OK;
+}
+int transpose_states_bad(const char* X, int64_t R, int32_t N, int64_t ldx, int32_t S, char* XT, int64_t Rp, int shift, int bad, hipStream_t st) {
+    return transpose_states_flag(X, R, N, ldx, S, XT, Rp, shift, bad, nullptr, st);
 }
 int transpose_states(const char* X, int64_t R, int32_t N, int64_t ldx, int32_t S, char* XT, int64_t Rp, int shift, hipStream_t st) {
     return transpose_states_bad(X, R, N, ldx, S, XT, Rp, shift, 31, st);

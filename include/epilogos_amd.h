@@ -71,6 +71,10 @@ int epg_hist_s2_from_binhist(const uint16_t* H, int64_t R, int32_t S, int64_t* c
  * materialised.  (S1 counts of [A|B] are simply epg_bin_hist of A and of B into the same counts.) */
 int epg_hist_s2_from_binhist_pair(const uint16_t* HA, const uint16_t* HB, int64_t R, int32_t S, int64_t* counts,
                                   void* stream);
+/* epg_hist_s3: with ws == NULL the LDS-counter kernel runs; with epg_ws_bytes(3, R, N, S) bytes of workspace the matrix-core
+ * contraction (the transposed matrix, a chunk of the one-hot operand and -- for calls of 262 144 bins or more -- a count array
+ * over S - 1 states per biosample from which the cells of the last state are re-derived; a byte that is not a state anywhere in
+ * the call switches, on the device, to the contraction over all S states).  The counts are the same integers on every path. */
 int epg_hist_s3(const int8_t* X, int64_t R, int32_t N, int64_t ldx, int32_t S, int32_t* counts,
                 void* ws, int64_t ws_bytes, void* stream);
 

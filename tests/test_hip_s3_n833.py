@@ -66,6 +66,39 @@ def test_s3_counts_oracle_n833(case, oracle_counts):
     assert np.array_equal(got, oracle_counts)
 
 
+def test_s3_reduced_contraction(eng, case, oracle_counts, monkeypatch):
+    """The contraction without each biosample's state S - 1 (its cells follow from the marginals, epg_s3_gemm.hip) against the
+    full one: on the matrix WITH bytes that are not states the device-side flag must send the call down the full path, on the
+    cleaned matrix the reduced path runs -- the same integers as the oracle either way, and accumulating into non-zero counts."""
+    monkeypatch.setenv("EPG_S3_REDUCED", "1")
+    dirty = eng.hist_s3(case["X"], N, S)
+    assert torch.equal(dirty, case["mfma"])
+    x = case["x"].copy()
+    fix = {}
+    for r, c, _v in BAD:
+        fix[(r, c)] = (r * 7 + c) % S
+        x[r, c] = fix[(r, c)]
+    Xc = eng.states_to_device(x)
+    red = eng.hist_s3(Xc, N, S)                                  # reduced contraction + reconstruction
+    red2 = eng.hist_s3(Xc, N, S, counts=case["mfma"].clone())    # += into non-zero counts
+    monkeypatch.setenv("EPG_S3_REDUCED", "0")
+    full = eng.hist_s3(Xc, N, S)
+    monkeypatch.delenv("EPG_S3_REDUCED")
+    assert torch.equal(red, full)
+    assert torch.equal(red2, full + case["mfma"])
+    assert int(red.sum(dtype=torch.int64)) == R * N * (N - 1)
+    # against the oracle: the cleaned matrix differs from the fixture's in three bytes, i.e. in the pairs of three bins
+    want = oracle_counts.astype(np.int64).copy()
+    for (r, c), v in fix.items():
+        row = x[r]
+        for b in range(N):
+            if b != c:
+                want[c, b, v, row[b]] += 1
+                want[b, c, row[b], v] += 1
+    # (5, 0) and (R - 1, 832), (70001, 416) are in different bins: no pair involves two fixed bytes
+    assert np.array_equal(red.cpu().numpy().reshape(N, N, S, S), want)
+
+
 def test_s3_counts_accumulate(eng, case, oracle_counts):
     c = case["mfma"].clone()
     eng.hist_s3(case["X"], N, S, counts=c)                 # += like expectedCombination.py:30-35
