@@ -52,7 +52,8 @@ if stats_all.exists():
         w.writeheader()
         w.writerows(keep)
     lines += ["## `rocprofv3 --kernel-trace --stats -- python3 tools/kbench_all.py --bins 15000000 --s3-bins 1000000 --null-bins 1000000`",
-              "(S2 on 15 M bins, S3 and the null shuffle on 1 M bins, 833 biosamples)", "",
+              "(S2 on 15 M bins, S3 and the null shuffle on 1 M bins, 833 biosamples; `k_s3_syrk_fp4` / `k_s3_onehot_fp4`: every second",
+              "launch is the gated-off contraction of the other kind and returns after a few us, so the real launch is the MAX column)", "",
               "| kernel | calls | avg ns | min ns | max ns |", "|---|---|---|---|---|"]
     for r in keep:
         lines.append("| `%s` | %s | %.0f | %s | %s |" % (r["Name"].split("(")[0], r["Calls"], float(r["AverageNs"]), r["MinNs"], r["MaxNs"]))
