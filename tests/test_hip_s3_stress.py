@@ -46,3 +46,34 @@ def test_s3_score_kernels_random_shapes(monkeypatch):
             np.testing.assert_allclose(a64.cpu().numpy(), onp.score_s3_f64(x, q, S), rtol=2e-6, atol=1e-9, err_msg=str((N, S, R)))
             checked_oracle += 1
     assert checked_oracle == 8
+
+
+def test_s3_expected_kernels_random_shapes(monkeypatch):
+    """Random shapes through the three expected-count paths: the matrix-core contraction over all S states, the reduced one
+    (S - 1 states per biosample, the last state's cells re-derived from the marginals; EPG_S3_REDUCED=1 forces it below its
+    size threshold) and the LDS-counter kernel -- with and without bytes that are not states (which must switch the reduced
+    path off on the device), and accumulating into non-zero counts.  expected.py:183-200."""
+    from epilogos_amd import engine
+    engine.require_gpu()
+    rng = np.random.default_rng(11)
+    for case in range(30):
+        S = int(rng.integers(2, 31))
+        N = int(rng.choice([2, 3, 5, 31, 32, 33, 64, 97, int(rng.integers(2, 140))]))
+        R = int(rng.choice([1, 63, 64, 65, 511, 512, 513, 2049, int(rng.integers(1, 3000))]))
+        x = rng.choice(S, size=(R, N), p=rng.dirichlet(np.full(S, 0.5))).astype(np.int8)
+        dirty = case % 3 == 0 and R > 2
+        if dirty:
+            x[rng.integers(0, R), rng.integers(0, N)] = -1
+            x[rng.integers(0, R), rng.integers(0, N)] = S          # the first value that is not a state
+        X = engine.states_to_device(x)
+        monkeypatch.setenv("EPG_S3_REDUCED", "1")
+        red = engine.hist_s3(X, N, S)
+        red2 = engine.hist_s3(X, N, S, counts=red.clone())
+        monkeypatch.setenv("EPG_S3_REDUCED", "0")
+        full = engine.hist_s3(X, N, S)
+        monkeypatch.delenv("EPG_S3_REDUCED")
+        lds = engine.hist_s3(X, N, S, use_workspace=False)
+        assert torch.equal(red, full) and torch.equal(full, lds), (N, S, R, dirty)
+        assert torch.equal(red2, 2 * full), (N, S, R, dirty)
+        if not dirty and N * N * S * S * R < 4e8:                  # oracle-sized and clean: the reference's own counts
+            assert np.array_equal(full.cpu().numpy().reshape(N, N, S, S), onp.expected_s3(x, S)), (N, S, R)
