@@ -92,3 +92,15 @@ def test_placed_histogram_cache(world):
     assert rep["ms_picked"] <= rep[[k for k in rep if k.startswith("ms_with_H")][0]][0] + 1e-9
     small, rep1 = eng.place_hist(X[:1000], N, S)                      # under 1 GiB: a plain allocation
     assert rep1 == {"tries": 1} and small.shape == (1000, S)
+    # park=True: what the search did not keep stays allocated until release_parked() (bench.py: freed memory is scrubbed in
+    # the background at the expense of whatever runs next)
+    free0, _ = torch.cuda.mem_get_info()
+    Hq, rep2 = eng.place_hist(X, N, S, park=True)
+    assert rep2["parked_GiB"] == round((rep2["blocks_tried"] - 1) * rep2["block_GiB"], 1)
+    eng.bin_hist(X, N, S, counts=torch.zeros(S, dtype=torch.int64, device="cuda"), H=Hq)
+    assert torch.equal(Hq, H)
+    del Hq
+    eng.release_parked()
+    assert not eng._parked
+    free1, _ = torch.cuda.mem_get_info()
+    assert free1 >= free0 - (1 << 30)                                 # everything went back
