@@ -41,8 +41,9 @@ inline uint32_t symbol_entry(bool litlen, int sym, int len) {
     return ((uint32_t)DIST_BASE[sym] << 16) | ((uint32_t)DIST_EXTRA[sym] << 8) | (uint32_t)len;
 }
 
-// Decode tables of one Huffman code.  Returns false for an over-subscribed code; an incomplete one is accepted (unused entries
-// are invalid and end the decode if they are ever hit) -- the one-code distance tree of RFC 1951 3.2.7 is such a code.
+// Decode tables of one Huffman code.  Returns false for an over-subscribed code and for an incomplete one, with zlib's one
+// exception: a code whose longest length is 1 (the one-code distance tree of RFC 1951 3.2.7; an empty distance tree of a
+// block without matches) -- its unused entries are invalid and end the decode if they are ever hit.
 inline bool build(const uint8_t* lens, int n, bool litlen, int root, uint32_t* table, std::vector<uint32_t>& sub) {
     int count[16] = {0};
     for (int i = 0; i < n; ++i) ++count[lens[i]];
@@ -51,6 +52,11 @@ inline bool build(const uint8_t* lens, int n, bool litlen, int root, uint32_t* t
     for (int b = 1; b < 16; ++b) {
         left = (left << 1) - count[b];
         if (left < 0) return false;
+    }
+    if (left > 0) {                                       // incomplete: a corrupt stream should fail here, not at the CRC
+        int maxl = 0;
+        for (int b = 1; b < 16; ++b) if (count[b]) maxl = b;
+        if (maxl > 1) return false;
     }
     uint32_t next[16];
     uint32_t code = 0;
@@ -109,6 +115,8 @@ template <typename Grow>
 inline size_t inflate_raw(const unsigned char* in, size_t in_avail, Out& out, Grow&& grow) {
     static const uint8_t CL_ORDER[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
     const unsigned char* const in0 = in;
+    const size_t out0 = out.pos;                          // a match never reaches back past this stream's first byte (an offset:
+                                                          // grow() may move the buffer)
     const unsigned char* in_end = in + in_avail;        // true end of the readable input (of the tail copy once switched)
     const unsigned char* in_lim = in_avail >= 16 ? in_end - 16 : in - 1;   // refills are allowed while in <= in_lim
     unsigned char tail[48];
@@ -195,6 +203,7 @@ inline size_t inflate_raw(const unsigned char* in, size_t in_avail, Out& out, Gr
                 count[0] = 0;
                 long left = 1;
                 for (int b = 1; b < 8; ++b) { left = (left << 1) - count[b]; if (left < 0) return 0; }
+                if (left > 0) return 0;                   // an incomplete code-length code (zlib rejects it as well)
                 uint32_t next[8], code = 0;
                 for (int b = 1; b < 8; ++b) { code = (code + (uint32_t)count[b - 1]) << 1; next[b] = code; }
                 for (int i = 0; i < 128; ++i) ct[i] = 0xffffffffu;
@@ -300,7 +309,7 @@ inline size_t inflate_raw(const unsigned char* in, size_t in_avail, Out& out, Gr
                 const uint32_t dx = (d >> 8) & 0xf;
                 const size_t dist = (size_t)(d >> 16) + (size_t)(bitbuf & ((1u << dx) - 1));
                 EPG_TAKE((int)dx);
-                if (dist > (size_t)(o - out.base)) return 0;         // before the start of the output
+                if (dist > (size_t)(o - out.base) - out0) return 0;  // before the start of THIS member's output
                 const unsigned char* sp = o - dist;
                 unsigned char* const oe = o + len;
                 if (dist >= 8) {

@@ -504,6 +504,9 @@ epgio_table* epgio_open_table(const char* path, int64_t row_lo, int64_t row_hi, 
                         if (c == cols && q < nl && *q == '\r') ++q;                    // CRLF line ends
                     }
                     while (q < nl && c < cols) {
+                        // a value is introduced by a TAB and by nothing else: the fast path above can stop on any byte
+                        // ("1.5", "1x5", "1 5"), and that byte must not be swallowed as if it were the separator
+                        if (*q != '\t') { err[i] = 1; if (bad_row[i] < 0) bad_row[i] = r; return; }
                         ++q;                                // the tab before the value
                         int v = 0;
                         bool neg = false, any = false;

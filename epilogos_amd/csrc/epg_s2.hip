@@ -753,15 +753,15 @@ int score_s2_from_hist_impl(const uint16_t* H, int64_t R, int32_t N, int32_t S, 
     const long ntiles = (R + 63) / 64;
     long bblocks = (ntiles + 3) / 4;
     if (bblocks > num_cus() * 4L) bblocks = num_cus() * 4L;
+    // k_score_s2_bin holds a static staging area of 4 waves x 64 rows x S outputs next to the log table: the table goes to LDS
+    // only while both fit the 64 KB a workgroup gets without asking (S = 25 with float64 outputs: N <= 1791)
+    const bool lds32 = lds_lh && (size_t)256 * S * 4 + lh_bytes <= 65536, lds64 = lds_lh && (size_t)256 * S * 8 + lh_bytes <= 65536;
 #define EPG_S2_FAST(SV)                                                                                                         \
     if (S == SV && !use_pair) {                                                                                                 \
-        if (lds_lh) {                                                                                                           \
-            if (out32) hipLaunchKernelGGL((k_score_s2_bin<SV, float, true>), dim3((int)bblocks), dim3(256), lh_bytes, st, H, (long)R, inv, N, LH, LPQ, out32);   \
-            if (out64) hipLaunchKernelGGL((k_score_s2_bin<SV, double, true>), dim3((int)bblocks), dim3(256), lh_bytes, st, H, (long)R, inv, N, LH, LPQ, out64);  \
-        } else {                                                                                                                \
-            if (out32) hipLaunchKernelGGL((k_score_s2_bin<SV, float, false>), dim3((int)bblocks), dim3(256), 0, st, H, (long)R, inv, N, LH, LPQ, out32);   \
-            if (out64) hipLaunchKernelGGL((k_score_s2_bin<SV, double, false>), dim3((int)bblocks), dim3(256), 0, st, H, (long)R, inv, N, LH, LPQ, out64);  \
-        }                                                                                                                       \
+        if (out32 && lds32) hipLaunchKernelGGL((k_score_s2_bin<SV, float, true>), dim3((int)bblocks), dim3(256), lh_bytes, st, H, (long)R, inv, N, LH, LPQ, out32);   \
+        if (out32 && !lds32) hipLaunchKernelGGL((k_score_s2_bin<SV, float, false>), dim3((int)bblocks), dim3(256), 0, st, H, (long)R, inv, N, LH, LPQ, out32);         \
+        if (out64 && lds64) hipLaunchKernelGGL((k_score_s2_bin<SV, double, true>), dim3((int)bblocks), dim3(256), lh_bytes, st, H, (long)R, inv, N, LH, LPQ, out64);  \
+        if (out64 && !lds64) hipLaunchKernelGGL((k_score_s2_bin<SV, double, false>), dim3((int)bblocks), dim3(256), 0, st, H, (long)R, inv, N, LH, LPQ, out64);        \
     } else if (S == SV && lds_lh) {                                                                                             \
         if (out32) hipLaunchKernelGGL((k_score_s2_fast<SV, float, true>), dim3((int)blocks), dim3(256), lh_bytes, st, H, (long)R, inv, N, LH, LPQ, out32);   \
         if (out64) hipLaunchKernelGGL((k_score_s2_fast<SV, double, true>), dim3((int)blocks), dim3(256), lh_bytes, st, H, (long)R, inv, N, LH, LPQ, out64);  \

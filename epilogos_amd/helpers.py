@@ -87,31 +87,55 @@ def readTable(path, rowsToCalc=None, alloc=None, with_range=False, threads=0):
     return out, ploc
 
 
-_cache_writers = []
+_cache_writers = {}                  # cache key (first file of the set) -> writer thread
+_cache_lock = __import__("threading").Lock()
 
 
 def _save_cache_async(cache, arrays):
+    """Writes the cache files of one input behind the caller's back.  One writer per cache key and process (paired mode can
+    read the same path for both groups, the driver parses in many threads); temp names carry pid AND a per-writer token, and
+    reach their final name by os.replace, so concurrent ranks or threads can only ever publish complete files."""
     import threading
+    import uuid
+    key = str(cache[0])
+    token = "%d.%s" % (os.getpid(), uuid.uuid4().hex[:12])
 
     def work():
+        tmps = []
         try:
             cache[0].parent.mkdir(parents=True, exist_ok=True)
             for c, arr in zip(cache, arrays):
-                tmp = Path(str(c) + ".tmp%d.npy" % os.getpid())          # atomic: ranks may fill the cache concurrently
+                tmp = Path(str(c) + ".tmp%s.npy" % token)
+                tmps.append(tmp)
                 np.save(tmp, arr, allow_pickle=False)
                 os.replace(tmp, c)
         except OSError as e:                                               # a cache that cannot be written is not an error of the run
             print("epilogos_amd: could not write the input cache {}: {}".format(cache[0], e), flush=True)
+        finally:
+            for tmp in tmps:                                               # whatever did not reach its final name
+                try:
+                    tmp.unlink()
+                except OSError:
+                    pass
 
-    th = threading.Thread(target=work, name="epilogos-cache-writer")
-    th.start()
-    _cache_writers.append(th)
+    with _cache_lock:
+        th = _cache_writers.get(key)
+        if th is not None and th.is_alive():
+            return                                                         # this input's cache is being written already
+        th = threading.Thread(target=work, name="epilogos-cache-writer")
+        _cache_writers[key] = th
+        th.start()
 
 
 def flushCacheWrites():
-    """Wait for the cache files of this process's first-time reads (tests, and callers that read the cache back at once)."""
-    while _cache_writers:
-        _cache_writers.pop().join()
+    """Wait for the cache files of this process's first-time reads: end of main, the error exits of the command line (which
+    leave through os._exit and would otherwise kill the writers half-way), tests, callers that read the cache back at once."""
+    while True:
+        with _cache_lock:
+            if not _cache_writers:
+                return
+            _key, th = _cache_writers.popitem()
+        th.join()
 
 
 def _read_int8(path, rowsToCalc):

@@ -232,6 +232,11 @@ if __name__ == "__main__":
     # Everything is written, flushed and closed at this point.  Tearing the interpreter down -- the HIP context, 13 GB of
     # pinned and mapped host memory, torch's module state -- took 0.7 s of a 4.5 s whole-genome run: leave at once.
     # (EPILOGOS_FAST_EXIT=0 restores the ordinary exit, e.g. under a coverage tool.)
+    try:                                                     # error exits too: let the --cache-dir writers finish their files
+        from .helpers import flushCacheWrites
+        flushCacheWrites()
+    except Exception:
+        pass
     sys.stdout.flush()
     sys.stderr.flush()
     if os.environ.get("EPILOGOS_FAST_EXIT", "1") != "0":

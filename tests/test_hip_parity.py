@@ -192,7 +192,7 @@ def test_s1_meets_north_star_tolerance(eng, golden_synth):
 
 
 # ---------------------------------------------------------------------------------------------- S2
-def _s2_check(eng, x, q_np, g64=None, g32=None, perms=None):
+def _s2_check(eng, x, q_np, g64=None, g32=None, perms=None, S=S):
     N = x.shape[1]
     X = eng.states_to_device(x)
     q = torch.from_numpy(np.ascontiguousarray(q_np).reshape(-1)).cuda()
@@ -238,6 +238,15 @@ def test_s2_random_vs_oracle(eng, N, R):
     H, _ = eng.bin_hist(X, N, S)
     assert np.array_equal(_np(eng.hist_s2_from_binhist(H, S)).reshape(S, S), c2)
     _s2_check(eng, x, onp.normalise(c2))
+
+
+@pytest.mark.parametrize("S_,N,R", [(25, 2000, 300), (18, 3500, 200), (25, 1791, 130), (25, 1792, 130), (15, 4000, 100)])
+def test_s2_score_wide_groups_float64_output(eng, S_, N, R):
+    """The bin-per-lane score kernel stages 4 x 64 x S outputs in static LDS next to the dynamic log table; with float64
+    outputs and N in the thousands the two no longer fit 64 KB together and the table must stay in memory (round-2 advisory:
+    the launch would have failed and left the scores unwritten)."""
+    x = synth_states(R, N, S=S_, seed=S_ * N, uniform=True)
+    _s2_check(eng, x, onp.normalise(onp.expected_s2(x, S_)), S=S_)
 
 
 # ---------------------------------------------------------------------------------------------- paired extras

@@ -60,6 +60,24 @@ def test_parser_edge_cases(tmp_path):
     (tmp_path / "crlf.txt").write_text("chr1\t0\t200\t3\t4\r\nchr1\t200\t400\t5\t6\r\n")
     st, _ = _io.read_table(tmp_path / "crlf.txt")
     assert st.tolist() == [[2, 3], [4, 5]]
+    # a row that is one column short but holds a junk byte inside a field must not pass as a full row (round-2 advisory:
+    # the scalar fast path stopped on the junk byte and the general loop swallowed it as if it were the separator)
+    for k, junk in enumerate(("1.5\t7", "1x5\t7", "1 5\t7", "1\t5.7", "15\t7x", "1\t\t7", "1\r5\t7")):
+        f = tmp_path / ("junk%d.txt" % k)
+        f.write_text("chr1\t0\t200\t1\t2\t3\nchr1\t200\t400\t%s\n" % junk)
+        with pytest.raises(_io.EpilogosIOError):
+            _io.read_table(f)
+        with pytest.raises(_io.EpilogosIOError):
+            _io.read_table(f, threads=1)
+    # the same with more columns than one AVX-512 step covers, junk far from either end
+    good = "\t".join(str(1 + i % 18) for i in range(200))
+    for k, (a, b) in enumerate((("\t7\t8\t", "\t7x8\t"), ("\t17\t18\t", "\t17.18\t"), ("\t3\t4\t", "\t3 4\t"))):
+        bad = good.replace(a, b, 1)
+        assert bad != good
+        f = tmp_path / ("wide%d.txt" % k)
+        f.write_text("chr1\t0\t200\t%s\nchr1\t200\t400\t%s\n" % (good, bad))
+        with pytest.raises(_io.EpilogosIOError):
+            _io.read_table(f)
 
 
 def test_writer_reproduces_reference_bytes(tmp_path, golden_real, golden_edge):
@@ -292,6 +310,81 @@ def test_own_inflate_never_trusts_itself(tmp_path):
         p.write_bytes(blob)
         with pytest.raises(_io.EpilogosIOError):
             _io.read_table(p)
+
+
+def _fuzz_outcomes(paths):
+    import hashlib
+    out = []
+    for p in paths:
+        try:
+            st, loc = _io.read_table(p)
+            out.append(hashlib.sha256(st.tobytes() + np.asarray(loc.blob).tobytes()).hexdigest())
+        except _io.EpilogosIOError:
+            out.append("error")
+    return out
+
+
+def test_own_inflate_differential_fuzz(tmp_path):
+    """Differential fuzz of csrc/epg_inflate.h against zlib (round-2 advisory): a few hundred mutated gzip files -- bit flips
+    in the header, the Huffman tables, the symbols and the trailer, truncations, spliced members, members whose matches would
+    reach back into the PREVIOUS member's output -- are read in this process (own inflate first) and in a child process with
+    EPGIO_INFLATE=zlib; every file must give the same verdict and the same bytes in both."""
+    import json
+    import os
+    import subprocess
+    import sys
+    import zlib
+    rng = np.random.default_rng(77)
+    _, text = _table_text(R=150, N=24)
+
+    def member(data, level=6, strategy=zlib.Z_DEFAULT_STRATEGY, raw=None, crc_of=None):
+        if raw is None:
+            c = zlib.compressobj(level, zlib.DEFLATED, -15, 8, strategy)
+            raw = c.compress(data) + c.flush()
+        crc_of = data if crc_of is None else crc_of
+        return (b"\x1f\x8b\x08\0\0\0\0\0\0\xff" + raw + (zlib.crc32(crc_of) & 0xffffffff).to_bytes(4, "little")
+                + (len(crc_of) & 0xffffffff).to_bytes(4, "little"))
+
+    half = text.index(b"\n", len(text) // 2) + 1
+    seeds = [member(text, 6), member(text, 1), member(text, 9), member(text, 6, zlib.Z_FIXED), member(text, 6, zlib.Z_RLE),
+             member(text, 6, zlib.Z_HUFFMAN_ONLY), member(text, 0), _io.gzip_fast(text), member(text[:half]) + member(text[half:], 1)]
+    # second member compressed WITH the first as preset dictionary: its matches point before its own first byte; the CRC and
+    # ISIZE in its trailer are those of the bytes a window-sharing decoder would produce, so only the distance check stops it
+    c = zlib.compressobj(9, zlib.DEFLATED, -15, 9, zlib.Z_DEFAULT_STRATEGY, text[:half][-32768:])
+    raw2 = c.compress(text[half:]) + c.flush()
+    blobs = [member(text[:half]) + member(None, raw=raw2, crc_of=text[half:])] + seeds
+    for k in range(260):
+        b = bytearray(seeds[k % len(seeds)])
+        kind = k % 5
+        if kind == 0:
+            b[int(rng.integers(10, min(len(b), 120)))] ^= 1 << int(rng.integers(0, 8))      # block header / code lengths
+        elif kind == 1:
+            for _ in range(int(rng.integers(1, 4))):
+                b[int(rng.integers(0, len(b)))] ^= 1 << int(rng.integers(0, 8))
+        elif kind == 2:
+            b = b[: int(rng.integers(1, len(b)))]
+        elif kind == 3:
+            i = int(rng.integers(10, len(b) - 8))
+            b[i:i + int(rng.integers(1, 9))] = bytes(rng.integers(0, 256, size=int(rng.integers(0, 9)), dtype=np.uint8))
+        else:
+            b[-int(rng.integers(1, 9))] ^= 1 << int(rng.integers(0, 8))                      # trailer
+        blobs.append(bytes(b))
+    paths = []
+    for k, b in enumerate(blobs):
+        p = tmp_path / ("f%03d.txt.gz" % k)
+        p.write_bytes(b)
+        paths.append(str(p))
+    mine = _fuzz_outcomes(paths)
+    (tmp_path / "paths.json").write_text(json.dumps(paths))
+    env = dict(os.environ, EPGIO_INFLATE="zlib")
+    code = ("import json, sys; sys.path.insert(0, %r); from tests.test_native_io import _fuzz_outcomes; "
+            "print(json.dumps(_fuzz_outcomes(json.load(open(%r)))))" % (str(__import__("tests.conftest").conftest.ROOT), str(tmp_path / "paths.json")))
+    res = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr[-2000:]
+    theirs = json.loads(res.stdout.strip().splitlines()[-1])
+    assert mine == theirs, [k for k in range(len(mine)) if mine[k] != theirs[k]]
+    assert mine[0] == "error"                                   # the dictionary member: no decoder may accept it
+    assert all(m != "error" for m in mine[1:1 + len(seeds)]) and len(set(mine[1:1 + len(seeds)])) == 1   # the unmutated files
 
 
 def test_row_sums_and_rolling_max_have_numpys_and_pandas_bits():
