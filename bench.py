@@ -20,6 +20,17 @@ global chunk seed, so the matrix does not depend on the GPU count.
 Prints ONE JSON line on rank 0 (contract in the task statement), with `roofline` for the dominant kernel
 (k_bin_hist, HBM-bound, 833 algorithmic bytes per bin) and `cpu_baseline` (the per-bin numpy loop of
 oracle/rowloop_baseline.py on the host cores, N = 1 only).
+
+The same line carries `configs`: BASELINE.json's configurations 3, 4 and 5 measured in the same run, device-resident,
+through the sessions the command line uses (backend.HipBackend.open_single / open_paired -- the product's own sequence
+of launches), each with its own roofline figure:
+    "s2"     whole S2 job on the S1 matrix (K1, pair counts from the histograms, all-reduce, normalise, score pass),
+    "s3"     S3 expected pass (matrix-core contraction) and score pass (LDS gathers) on `--s3-bins` bins,
+    "paired" paired S1 on 379 + 342 biosamples: two count passes, all-reduce, the hypergeometric null groups, four score
+             passes, deltas, null distances, STEP 4's per-bin reduction and the quiescence mask.
+`--configs none` skips them.  The headline step allocates like the product does (plain torch allocations); the effect of
+putting the histogram cache into another memory class than the matrix (engine.place_hist) is measured after
+the timed region and reported as the secondary field `placement_experiment`.
 """
 import argparse
 import json
@@ -99,7 +110,7 @@ def k1_source_sha():
     return h.hexdigest()[:16]
 
 
-def generate_shard(torch, X, n_biosamples, n_states, bin0, dist="chr1"):
+def generate_shard(torch, X, n_biosamples, n_states, bin0, dist="chr1", seed=1234):
     """Fill X[:, :N] with synthetic states for global bins [bin0, bin0 + R): global chunk k of 2^20 bins is drawn
     from torch.Generator seeded 1234 + k in fixed sub-blocks, so the matrix does not depend on the GPU count.
     dist: "chr1" = i.i.d. empirical chr1 state frequencies (the headline workload); "uniform" = uniform
@@ -115,7 +126,7 @@ def generate_shard(torch, X, n_biosamples, n_states, bin0, dist="chr1"):
     gen = torch.Generator(device=dev)
     k0, k1 = bin0 // CHUNK_BINS, (bin0 + R - 1) // CHUNK_BINS
     for k in range(k0, k1 + 1):
-        gen.manual_seed(1234 + k)
+        gen.manual_seed(seed + k)
         for sub in range(CHUNK_BINS // SUB_BINS):
             g0 = k * CHUNK_BINS + sub * SUB_BINS
             u = torch.rand((SUB_BINS, n_biosamples), generator=gen, device=dev, dtype=torch.float32)
@@ -139,6 +150,152 @@ def generate_shard(torch, X, n_biosamples, n_states, bin0, dist="chr1"):
             X[idx, :n_biosamples] = X[idx - 1, :n_biosamples]    # copies the (already final) predecessor of most bins
 
 
+LDS_GATHER_PEAK = 256 * 2.4e9 / 2 * 64   # ds_read_b32 lanes/s of the chip: one wave instruction per 2 cycles and CU (MI355X_MICROARCH.md)
+FP4_DENSE_PEAK = 10.0e15                 # dense fp4 MFMA FLOP/s (MI355X_MICROARCH.md; 2x the fp8 figure)
+
+
+def _max_over_ranks(torch, d, value, dev):
+    if d.world == 1:
+        return value
+    t = torch.tensor([value], dtype=torch.float64, device=dev)
+    d.dist.all_reduce(t, op=d.dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def _event_ms(torch, fn, reps=3):
+    """Median device time of fn() between two events on the current stream (one untimed call first)."""
+    ts = []
+    for k in range(reps + 1):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        fn()
+        e1.record()
+        torch.cuda.synchronize()
+        if k:
+            ts.append(e0.elapsed_time(e1))
+    return float(np.median(ts))
+
+
+def bench_single(torch, be, d, sal, X, N, S, R, R_global, world, reps, fence):
+    """One whole single-group job of saliency 2 or 3 per repetition, through the session the command line uses
+    (backend._HipSingleSession: add_device -> all_reduce -> finish_device -> scores_device), inputs resident.  Wall time
+    between fences (max over ranks) and device time of the phases from events on the launch stream."""
+    dev = X.device
+    walls, phases = [], []
+    for rep in range(reps + 1):                                   # the first repetition warms allocations and attributes up
+        sess = be.open_single(S, sal)
+        fence()
+        e = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+        t0 = time.perf_counter()
+        e[0].record()
+        pid = sess.add_device(X, N)                               # STEP 1 (expected counts; histograms / matrix stay resident)
+        e[1].record()
+        sess.ensure_acc(N)
+        sess.all_reduce(d)                                        # the one collective: int64[S*S] or int32[N*N*S*S]
+        sess.finish_device(R_global, N)                           # count check + STEP 2
+        e[2].record()
+        o32 = sess.scores_device(pid)                             # STEP 3
+        e[3].record()
+        fence()
+        wall = time.perf_counter() - t0
+        if rep:
+            walls.append(_max_over_ranks(torch, d, wall, dev))
+            phases.append([e[i].elapsed_time(e[i + 1]) for i in range(3)])
+        ok = bool(torch.isfinite(o32[:: max(R // 4096, 1)]).all()) if R else True
+        del sess, o32
+    wall_ms = float(np.median(walls)) * 1e3
+    exp_ms, comb_ms, score_ms = (float(v) for v in np.median(np.array(phases), axis=0))
+    out = {"bins_total": R_global, "bins_per_gpu": R, "biosamples": N, "states": S, "saliency": sal, "reps": reps,
+           "job_ms": round(wall_ms, 3), "value": round(R_global / wall_ms / 1e3, 3), "unit": "Mbins/s", "scores_finite": ok,
+           "phases_ms": {"expected": round(exp_ms, 3), "allreduce+check+normalise": round(comb_ms, 3), "scores": round(score_ms, 3)},
+           "path": "backend._HipSingleSession (the command line's session), device-resident"}
+    if sal == 2:
+        # bytes the job has to move per bin: X read, H written, H read by the pair counts, H read + float32 scores written
+        bpb = N + 2 * S + 2 * S + 2 * S + 4 * S
+        eng = be.engine
+        H, _ = eng.bin_hist(X, N, S, want_counts=False)
+        c2 = eng.hist_s2_from_binhist(H, S)
+        q2 = eng.normalise(c2)
+        o = torch.empty((R, S), dtype=torch.float32, device=dev)
+        ws = eng.workspace(2, 0, N, S, device=dev)
+        k1 = _event_ms(torch, lambda: eng.bin_hist(X, N, S, want_counts=False, H=H))
+        kc = _event_ms(torch, lambda: eng.hist_s2_from_binhist(H, S, counts=c2))
+        ks = _event_ms(torch, lambda: eng.score_s2_from_binhist(H, N, S, q2, out32=o, ws=ws))
+        out["kernels_ms"] = {"k_bin_hist": round(k1, 4), "k_s2_hist_wave": round(kc, 4), "k_score_s2_bin(+tables)": round(ks, 4)}
+        gb = R * bpb / (exp_ms + comb_ms + score_ms) / 1e6
+        out["roofline"] = {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBPS, "algorithmic_bytes_per_bin": bpb,
+                           "achieved": round(gb, 1), "frac": round(gb / HBM_PEAK_GBPS, 4),
+                           "what": "whole job (device time of the three phases) against the bytes it has to move",
+                           "kernel_fracs": {"k_bin_hist (N + 2S B/bin)": round(R * (N + 2 * S) / k1 / 1e6 / HBM_PEAK_GBPS, 4),
+                                            "k_s2_hist_wave (2S B/bin)": round(R * 2 * S / kc / 1e6 / HBM_PEAK_GBPS, 4),
+                                            "k_score_s2_bin (6S B/bin)": round(R * 6 * S / ks / 1e6 / HBM_PEAK_GBPS, 4)}}
+    else:
+        pairs = float(R) * N * (N - 1)
+        M = N * (S - 1) if R >= 262144 else N * S                 # the reduced contraction leaves one state per biosample out
+        flops = float(R) * M * M                                  # 2 * R * M^2 / 2: the upper triangle of E^T E
+        out["ms_per_Mbins"] = {"expected": round(exp_ms / R * 1e6, 3), "scores": round(score_ms / R * 1e6, 3)}
+        out["pair_terms_per_s"] = {"expected": float("%.4g" % (pairs / exp_ms * 1e3)), "scores": float("%.4g" % (pairs / score_ms * 1e3))}
+        out["roofline"] = {"expected": {"bound": "mfma", "unit": "TFLOP/s", "peak": FP4_DENSE_PEAK / 1e12,
+                                        "achieved": round(flops / exp_ms / 1e9, 1), "frac": round(flops / exp_ms * 1e3 / FP4_DENSE_PEAK, 4),
+                                        "flops": "R * M^2 with M = N * (S - 1) rows of the reduced one-hot operand (upper triangle, "
+                                                 "fp4 E2M1); the phase also holds the transpose, the operand build and the reconstruction"},
+                           "scores": {"bound": "lds", "unit": "gathers/s", "peak": LDS_GATHER_PEAK, "achieved": float("%.4g" % (pairs / score_ms * 1e3)),
+                                      "frac": round(pairs / score_ms * 1e3 / LDS_GATHER_PEAK, 4),
+                                      "what": "N (N - 1) table terms per bin against the chip's ds_read_b32 lane rate; the phase "
+                                              "also holds the table build and the transpose"}}
+    return out
+
+
+def bench_paired(torch, be, d, R, R_global, bin0, S, world, reps, fence, dev, dist_name, NA=379, NB=342):
+    """Paired S1 (BASELINE config 5: male vs female, 379 + 342 biosamples) through backend._HipPairedSession: both groups'
+    count passes, the all-reduce of the [A|B] counts, normalise, the hypergeometric null groups, four score passes, deltas, null
+    distances, STEP 4's per-bin reduction and the quiescence mask -- everything the command line computes before it writes."""
+    eng = be.engine
+    XA, XB = eng.alloc_states(R, NA, device=dev), eng.alloc_states(R, NB, device=dev)
+    generate_shard(torch, XA, NA, S, bin0, dist=dist_name, seed=4321)
+    generate_shard(torch, XB, NB, S, bin0, dist=dist_name, seed=8765)
+    walls, phases = [], []
+    for rep in range(reps + 1):
+        sess = be.open_paired(S, 1, S - 1, -1, 20240229)
+        fence()
+        e = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+        t0 = time.perf_counter()
+        e[0].record()
+        pid = sess.add_staged(XA, NA, XB, NB, bin0)
+        e[1].record()
+        sess.ensure_acc(NA + NB)
+        sess.all_reduce(d)
+        sess.finish_device(R_global, NA + NB)
+        e[2].record()
+        res = sess.results_device(pid)
+        e[3].record()
+        fence()
+        wall = time.perf_counter() - t0
+        if rep:
+            walls.append(_max_over_ranks(torch, d, wall, dev))
+            phases.append([e[i].elapsed_time(e[i + 1]) for i in range(3)])
+        ok = bool(torch.isfinite(res["delta"][:: max(R // 4096, 1)]).all()) and bool(torch.isfinite(res["null"][:: max(R // 4096, 1)]).all())
+        nq = int(res["quies"].sum().item())
+        del sess, res
+    wall_ms = float(np.median(walls)) * 1e3
+    exp_ms, comb_ms, res_ms = (float(v) for v in np.median(np.array(phases), axis=0))
+    # bytes per bin: both matrices read + two histograms written; null groups: 2 H read, 2 written; four score passes (H read,
+    # float32 written); two pair_finish (2 score rows read, one written, + the distance); metrics (delta read, 8 B written);
+    # quiescence (2 H read, 1 B written)
+    bpb = (NA + NB) + 2 * 2 * S + 4 * 2 * S + 4 * (2 * S + 4 * S) + 2 * (3 * 4 * S) + 4 + (4 * S + 8) + (2 * 2 * S + 1)
+    gb = R * bpb / (exp_ms + comb_ms + res_ms) / 1e6
+    return {"bins_total": R_global, "bins_per_gpu": R, "biosamples": [NA, NB], "states": S, "saliency": 1, "reps": reps,
+            "job_ms": round(wall_ms, 3), "value": round(R_global / wall_ms / 1e3, 3), "unit": "Mbins/s",
+            "outputs_finite": ok, "quiescent_bins": nq,
+            "phases_ms": {"two count passes": round(exp_ms, 3), "allreduce+check+normalise": round(comb_ms, 3),
+                          "null groups + 4 score passes + deltas + metrics + quiescence": round(res_ms, 3)},
+            "roofline": {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBPS, "algorithmic_bytes_per_bin": bpb,
+                         "achieved": round(gb, 1), "frac": round(gb / HBM_PEAK_GBPS, 4),
+                         "what": "whole job (device time of the three phases) against the bytes it has to move; the null groups "
+                                 "are compute-bound (Philox + selection sampling), see DESIGN.md 3"},
+            "path": "backend._HipPairedSession (the command line's session), device-resident"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -152,6 +309,13 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--packed", action="store_true", help="row pitch = biosamples (unaligned rows) instead of 16-byte padded")
     ap.add_argument("--dist", choices=["chr1", "uniform", "correlated"], default="chr1", help="synthetic state distribution")
+    ap.add_argument("--configs", default="s2,s3,paired", help="BASELINE configs 3-5 measured next to the headline: any of s2,s3,paired; none")
+    ap.add_argument("--s3-bins", type=int, default=2_000_000, help="bins of the S3 measurement (whole job, all ranks)")
+    ap.add_argument("--config-reps", type=int, default=3)
+    ap.add_argument("--graph", action="store_true", help="capture the step (K1, all-reduce, combine, score) in a hipGraph and replay it "
+                                                         "(kernels_ms then comes from an un-captured probe after the timed region)")
+    ap.add_argument("--pg", action="store_true", help="one GPU: still join a one-rank RCCL process group, so that the step contains the all-reduce")
+    ap.add_argument("--placement-experiment", type=int, default=1, help="0: skip the histogram-placement experiment after the timed region")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to test the "
                                                       "multi-rank path on a box with one GPU, ranks then share cuda:0)")
     args = ap.parse_args()
@@ -188,14 +352,19 @@ def main():
         local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_pg = world > 1 or args.pg
+    if use_pg:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:
+            os.environ.setdefault("MASTER_PORT", str(29500 + os.getpid() % 2000))
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         if args.backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=dev)
         else:
             dist.init_process_group(backend=args.backend)
 
-    # ---- resident inputs and preallocated outputs
+    # ---- resident inputs and preallocated outputs: plain allocations, like the sessions of the command line
     if args.packed:
         flat = torch.empty(R * N + 64, dtype=torch.int8, device=dev)
         X = flat[:R * N].view(R, N)
@@ -206,57 +375,67 @@ def main():
     q = torch.empty(S, dtype=torch.float32, device=dev)
     out32 = torch.empty((R, S), dtype=torch.float32, device=dev)
     ws_s1 = engine.workspace(1, 0, N, S, device=dev)
-    # last, the histogram cache: it goes where k_bin_hist's writes do not collide with its reads of X (engine.place_hist: the
-    # device memory has three classes of regions, X and H in one class = 17 % slower); what was tried is in the JSON line
-    try:
-        H, placement = engine.place_hist(X, N, S, park=True)   # the blocks it did not keep go back after the timed region
-    except Exception as e:                     # the search is an optimisation: never let it take the measurement down
-        torch.cuda.empty_cache()
-        H, placement = torch.empty((R, S), dtype=torch.int16, device=dev), {"tries": 1, "search_failed": repr(e)[:200]}
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-          for _ in range(args.steps)]
-
+    H = torch.empty((R, S), dtype=torch.int16, device=dev)
     last_counts = torch.zeros(S, dtype=torch.int64, device=dev)
 
-    if os.environ.get("EPG_BENCH_NOEVENTS"):         # diagnostic: what the three event records per step cost (kernels_ms is then NaN)
-        ev = []
-
-    def step(k=None, keep=False):
-        if not ev:
-            k = None
-        if k is not None:
-            ev[k][0].record()
+    def step(H, e=None, keep=False):
+        if e is not None:
+            e[0].record()
         engine.bin_hist(X, N, S, counts=counts, H=H)                       # STEP 1: expected pass (counts start zeroed)
-        if k is not None:
-            ev[k][1].record()
-        if world > 1:
+        if e is not None:
+            e[1].record()
+        if use_pg:
             dist.all_reduce(counts, op=dist.ReduceOp.SUM)                  # the single collective (144 bytes)
+        if e is not None:
+            e[2].record()
         if keep:
             last_counts.copy_(counts)                                      # outside the timed steps: for the sanity check
-        # STEP 2 + STEP 3: normalise + table in one single-block kernel (it leaves counts zeroed for the next job), score pass
+        # STEP 2 + STEP 3: normalise + table in one kernel (it leaves counts zeroed for the next job), score pass
         engine.combine_score_s1(counts, H, N, S, q=q, out32=out32, ws=ws_s1, rezero=True)
-        if k is not None:
-            ev[k][2].record()
+        if e is not None:
+            e[3].record()
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_pg:
             dist.barrier()
         torch.cuda.synchronize()
 
-    step(keep=True)                                                        # untimed: sanity of one whole job
-    for _ in range(args.warmup):
-        step()
-    fence()
-    t0 = time.perf_counter()
-    host_t = []
-    for k in range(args.steps):
-        step(k)
-        host_t.append(time.perf_counter() - t0)
-    fence()
-    dt = time.perf_counter() - t0
+    def timed_steps(H, steps, warmup, graph=False, events=True):
+        """-> (wall seconds of `steps` steps, per-step event tuples or [], host enqueue times)."""
+        ev = [tuple(torch.cuda.Event(enable_timing=True) for _ in range(4)) for _ in range(steps)] if (events and not graph) else []
+        g = None
+        if graph:
+            # the whole step as ONE hipGraph launch: on a 1.9 M-bin shard the step is ~0.35 ms and the host side of three
+            # launches + a collective (ctypes, torch.distributed) is no longer hidden behind it
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(3):
+                    step(H)
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                step(H)
+        for _ in range(warmup):
+            g.replay() if g is not None else step(H)
+        fence()
+        t0 = time.perf_counter()
+        host_t = []
+        for k in range(steps):
+            if g is not None:
+                g.replay()
+            else:
+                step(H, ev[k] if ev else None)
+            host_t.append(time.perf_counter() - t0)
+        fence()
+        return time.perf_counter() - t0, ev, host_t
 
-    engine.release_parked()
+    step(H, keep=True)                                                     # untimed: sanity of one whole job
+    dt, ev, host_t = timed_steps(H, args.steps, args.warmup, graph=args.graph,
+                                 events=not os.environ.get("EPG_BENCH_NOEVENTS"))
+
     # sanity of the last step (cheap, outside the timed region): every state byte counted, scores finite
     total = int(last_counts.sum().item())
     assert total == R_global * N, "state counts %d != bins*biosamples %d" % (total, R_global * N)
@@ -267,11 +446,72 @@ def main():
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
+    if not ev:                                                             # graph replay / no events: per-kernel times from a probe
+        _, ev, _ = timed_steps(H, min(args.steps, 10), 1)
     if os.environ.get("EPG_BENCH_TRACE") and rank == 0:      # per-step k_bin_hist times (clock ramps, box variance)
         print("k_bin_hist ms per step:", " ".join("%.3f" % e[0].elapsed_time(e[1]) for e in ev), file=sys.stderr, flush=True)
         print("host enqueue done at ms:", " ".join("%.1f" % (t * 1e3) for t in host_t), file=sys.stderr, flush=True)
-    hist_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in ev])) if ev else float("nan")
-    rest_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in ev])) if ev else float("nan")
+    hist_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))
+    ar_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in ev]))
+    rest_ms = float(np.mean([e[2].elapsed_time(e[3]) for e in ev]))
+
+    # ---- the all-reduce by itself (device time between events, host time of the call), when there is a process group
+    allreduce_probe = None
+    if use_pg:
+        t = torch.zeros(S, dtype=torch.int64, device=dev)
+        for _ in range(20):
+            dist.all_reduce(t)
+        fence()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        n_ar = 200
+        e0.record()
+        th = time.perf_counter()
+        for _ in range(n_ar):
+            dist.all_reduce(t)
+        host_us = (time.perf_counter() - th) / n_ar * 1e6
+        e1.record()
+        torch.cuda.synchronize()
+        allreduce_probe = {"tensor": "int64[%d]" % S, "calls": n_ar, "device_us_per_call_back_to_back": round(e0.elapsed_time(e1) / n_ar * 1e3, 2),
+                           "host_us_per_call": round(host_us, 2), "backend": args.backend, "world": world}
+
+    # ---- secondary: the histogram cache in another memory class than the matrix (not what the product does: DESIGN.md 3)
+    placement = {"headline": "plain torch allocations for X, H and the scores -- the same code path as backend._HipSession"}
+    if args.placement_experiment and R * X.stride(0) >= (1 << 30) and not args.packed:
+        try:
+            Hp, rep = engine.place_hist(X, N, S, park=True)
+            dtp, evp, _ = timed_steps(Hp, min(args.steps, 10), 2)
+            rep["k_bin_hist_ms"] = round(float(np.mean([e[0].elapsed_time(e[1]) for e in evp])), 4)
+            rep["frac"] = round(R * N / (rep["k_bin_hist_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)
+            rep["ms_per_step"] = round(dtp / min(args.steps, 10) * 1e3, 4)
+            placement["experiment"] = rep
+            del Hp
+        except Exception as e:                 # an experiment: never let it take the measurement down
+            placement["experiment"] = {"failed": repr(e)[:200]}
+        engine.release_parked()
+
+    # ---- BASELINE configs 3-5 through the product's sessions
+    want = [] if args.configs in ("none", "") else [c.strip() for c in args.configs.split(",") if c.strip()]
+    configs = {}
+    if want:
+        from epilogos_amd import backend as _backend
+        from epilogos_amd.driver import _Dist
+        be = _backend.HipBackend(device=dev)
+        d = _Dist()
+        for name in want:
+            try:
+                if name == "s2":
+                    configs["s2"] = bench_single(torch, be, d, 2, X, N, S, R, R_global, world, args.config_reps, fence)
+                elif name == "s3":
+                    r3g = min(args.s3_bins, R_global)
+                    lo, hi = rank * r3g // world, (rank + 1) * r3g // world
+                    configs["s3"] = bench_single(torch, be, d, 3, X[: hi - lo], N, S, hi - lo, r3g, world, args.config_reps, fence)
+                elif name == "paired":
+                    configs["paired"] = bench_paired(torch, be, d, R, R_global, bin0, S, world, args.config_reps, fence, dev, args.dist)
+                else:
+                    configs[name] = {"error": "unknown config"}
+            except Exception as e:
+                configs[name] = {"error": repr(e)[:300]}
+            torch.cuda.empty_cache()
 
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
@@ -302,6 +542,7 @@ def main():
                        "bins_total": R_global, "bins_per_gpu": R, "biosamples": N, "states": S, "saliency": 1,
                        "state_distribution": args.dist,
                        "row_pitch_bytes": int(X.stride(0)),
+                       "step_launch": "hipGraph replay" if args.graph else "three launches + collective per step",
                        "partition": "contiguous bin ranges per GPU (helpers.splitRows rule), one RCCL all-reduce of int64[%d]" % S},
             "roofline": {"bound": "hbm", "kernel": "k_bin_hist", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": traffic_note,
@@ -309,12 +550,15 @@ def main():
                          # the whole step against the bytes it has to move: X read once, H written and read, float32 scores written
                          "step_bytes_per_bin": N + 2 * 2 * S + 4 * S,
                          "step_GBps": round(R * (N + 2 * 2 * S + 4 * S) / (ms_per_step * 1e-3) / 1e9, 1)},
-            "kernels_ms": {"k_bin_hist": round(hist_ms, 4), "allreduce+combine(normalise,table)+score_from_hist": round(rest_ms, 4)},
+            "kernels_ms": {"k_bin_hist": round(hist_ms, 4), "allreduce": round(ar_ms, 4),
+                           "combine(normalise,table)+score_from_hist": round(rest_ms, 4)},
+            "allreduce_probe": allreduce_probe,
             "placement": placement,
+            "configs": configs,
             "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_pg:
         dist.destroy_process_group()
 
 

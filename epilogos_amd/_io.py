@@ -64,7 +64,17 @@ def _err():
     return load().epgio_last_error().decode(errors="replace")
 
 
+def _log_io(op, path, lo=0, hi=-1):
+    """EPILOGOS_IO_LOG=<file>: one line per pass over an input file (every call below inflates the whole file); the
+    multi-rank tests count them."""
+    log = os.environ.get("EPILOGOS_IO_LOG")
+    if log:
+        with open(log, "a") as f:
+            f.write("%d\t%s\t%s\t%d\t%d\n" % (os.getpid(), op, os.path.abspath(str(path)), lo, hi))
+
+
 def count_rows(path):
+    _log_io("count", path)
     n = load().epgio_count_rows(str(path).encode())
     if n < 0:
         raise EpilogosIOError(_err())
@@ -129,6 +139,7 @@ def read_table(path, rows=None, threads=0, ldx=None, alloc=None, with_range=Fals
     the destination (e.g. a pinned, row-padded staging buffer); columns >= N are filled with -1."""
     lib = load()
     lo, hi = (0, -1) if rows is None else rows
+    _log_io("read", path, lo, hi)
     h = lib.epgio_open_table(str(path).encode(), lo, hi, threads)
     if not h:
         raise EpilogosIOError(_err())

@@ -156,6 +156,8 @@ class _HipSession:
         self.parts = []
         self.n_uploads = 0
         self.upload_bytes = 0
+        self._releaser = None
+        self._ws3 = None                                 # S3 expected pass: ONE workspace for all parts of the session
 
     def alloc(self, ticket):
         """-> alloc(R, N) for _io.read_table / helpers.readTable: a pinned, row-padded destination for part `ticket`."""
@@ -171,21 +173,40 @@ class _HipSession:
             self.pool.skip(ticket)
 
     def _upload(self, arr, N, ticket):
-        """One H2D copy of the staged matrix (pinned -> HBM on the copy stream); the staging buffer goes back to the pool."""
+        """One H2D copy of the staged matrix (pinned -> HBM on the copy stream).  The device buffer is allocated ON the copy
+        stream, so the copy waits for nothing the compute stream is doing (round 2 made it wait for the previous part's
+        kernels and then blocked the host until the copy was over); the compute stream waits for the copy's event, and the
+        staging buffer goes back to the pool from a helper thread once that event has completed."""
         R = arr.shape[0]
         buf = self.held.pop(ticket, None)
         if buf is None:                                  # not staged through alloc(): pageable fallback of the same layout
             self.pool.skip(ticket)
             X = self.eng.states_to_device(arr[:, :N], device=self.device)
         else:
-            self.copy_stream.wait_stream(self.torch.cuda.current_stream())
             X, ev = self.eng.upload_states(buf, R, arr.shape[1], self.copy_stream, device=self.device)
             self.torch.cuda.current_stream().wait_event(ev)
-            ev.synchronize()
-            self.pool.release(buf)
+            self._release_later(ev, buf)
         self.n_uploads += 1
         self.upload_bytes += X.numel()
         return X
+
+    def _release_later(self, ev, buf):
+        import queue
+        import threading
+        if self._releaser is None:
+            self._release_q = queue.SimpleQueue()
+
+            def work():
+                while True:
+                    item = self._release_q.get()
+                    if item is None:
+                        return
+                    e, b = item
+                    e.synchronize()                      # (releases the GIL) the copy out of this staging buffer is over
+                    self.pool.release(b)
+            self._releaser = threading.Thread(target=work, name="epilogos-staging-release", daemon=True)
+            self._releaser.start()
+        self._release_q.put((ev, buf))
 
     def _acc(self, n, dtype=None):
         if self.acc is None:
@@ -195,20 +216,26 @@ class _HipSession:
     def all_reduce(self, d):
         d.all_reduce_tensor(self.acc)                    # RCCL over xGMI: the tensor never leaves HBM
 
-    def _finish(self, total_rows, N, shape):
+    def finish_device(self, total_rows, N):
         """Count check (the reference dies on a state outside the model, expected.py:113; here such a byte is counted
-        nowhere, so the total comes out short), then STEP 2 on the device."""
+        nowhere, so the total comes out short), then STEP 2 on the device.  Returns exp_freq as a flat device tensor."""
         total = int(self.acc.sum(dtype=self.torch.int64).item())
         self.be.check_counts(total, total_rows, N, self.sal)
         self.q = self.eng.normalise(self.acc)
         self.acc = None
-        return self.q.cpu().numpy().reshape(shape)
+        return self.q
+
+    def _finish(self, total_rows, N, shape):
+        return self.finish_device(total_rows, N).cpu().numpy().reshape(shape)
 
 
 class _HipSingleSession(_HipSession):
     def add_part(self, arr, N, ticket):
+        return self.add_device(self._upload(arr, N, ticket), N)
+
+    def add_device(self, X, N):
+        """Count pass over a RESIDENT part (what add_part does after its upload; bench.py enters here)."""
         eng, S = self.eng, self.S
-        X = self._upload(arr, N, ticket)
         self.N = N
         if self.sal == 1:
             H, _ = eng.bin_hist(X, N, S, counts=self._acc(S))
@@ -218,31 +245,67 @@ class _HipSingleSession(_HipSession):
             eng.hist_s2_from_binhist(H, S, counts=self._acc(S * S))
             self.parts.append(H)
         elif self.sal == 3:
-            eng.hist_s3(X, N, S, counts=self._acc(N * N * S * S, self.torch.int32))
+            # the ~8 GB workspace of the matrix-core contraction is allocated once per session and grows to the largest
+            # part (round 2 allocated and freed one per part: freed device memory is scrubbed at every HBM kernel's expense)
+            need = eng.hist_s3_ws_bytes(X.shape[0], N, S)
+            if self._ws3 is None or self._ws3.numel() < need:
+                self._ws3 = None
+                self._ws3 = self.torch.empty(need, dtype=self.torch.uint8, device=self.device)
+            eng.hist_s3(X, N, S, counts=self._acc(N * N * S * S, self.torch.int32), ws=self._ws3)
             self.parts.append(X)
         else:
             raise ValueError("Please ensure that saliency metric is either 1, 2, or 3")
         return len(self.parts) - 1
 
+    # ---- multi-rank hand-over (driver._redistribute): a part is what the score pass reads -- per-bin histograms (S1, S2)
+    # or state rows (S3)
+    n_export = 1
+
+    def slice_part(self, pid, lo, hi, row0=None):
+        self.parts.append(self.parts[pid][lo:hi])
+        return len(self.parts) - 1
+
+    def export_rows(self, pid, lo, hi):
+        return [self.parts[pid][lo:hi]]
+
+    def import_rows(self, tensors, N, row0=None):
+        self.N = N
+        self.parts.append(tensors[0].to(self.device))
+        return len(self.parts) - 1
+
+    def drop_part(self, pid):
+        self.parts[pid] = None
+
     def ensure_acc(self, N):
         S = self.S                                       # a rank without bins still takes part in the all-reduce
+        self.N = N
         self._acc({1: S, 2: S * S, 3: N * N * S * S}[self.sal], self.torch.int32 if self.sal == 3 else None)
 
     def finish(self, total_rows, N):
         S = self.S
+        self._ws3 = None
         return self._finish(total_rows, N, {1: (S,), 2: (S, S), 3: (N, N, S, S)}[self.sal])
 
-    def scores(self, pid):
+    def scores_device(self, pid, keep=False):
+        """float32 [R, S] scores of part `pid` from its resident data, as a device tensor."""
         eng, S, N = self.eng, self.S, self.N
         D = self.parts[pid]
-        self.parts[pid] = None                           # the part's device data is released with its scores
+        if not keep:
+            self.parts[pid] = None                       # the part's device data is released with its scores
         if self.sal == 1:
             o32, _ = eng.score_s1_from_binhist(D, N, S, self.q)
         elif self.sal == 2:
             o32, _ = eng.score_s2_from_binhist(D, N, S, self.q)
-        else:
-            o32, _ = eng.score_s3(D, N, S, self.q)
-        return o32.cpu().numpy()
+        else:                                            # one score workspace (table, transposed matrix, cells) for all parts
+            need = eng.hist_s3_ws_bytes(D.shape[0], N, S)
+            if self._ws3 is None or self._ws3.numel() < need:
+                self._ws3 = None
+                self._ws3 = self.torch.empty(need, dtype=self.torch.uint8, device=self.device)
+            o32, _ = eng.score_s3(D, N, S, self.q, ws=self._ws3)
+        return o32
+
+    def scores(self, pid):
+        return self.scores_device(pid).cpu().numpy()
 
 
 class _HipPairedSession(_HipSession):
@@ -277,6 +340,26 @@ class _HipPairedSession(_HipSession):
         self.parts.append((XA, XB, HA, HB, row0))
         return len(self.parts) - 1
 
+    # ---- multi-rank hand-over: the score pass of paired mode reads the two groups' histograms only
+    n_export = 2
+
+    def slice_part(self, pid, lo, hi, row0=None):
+        _XA, _XB, HA, HB, _ = self.parts[pid]
+        self.parts.append((None, None, HA[lo:hi], HB[lo:hi], row0))
+        return len(self.parts) - 1
+
+    def export_rows(self, pid, lo, hi):
+        _XA, _XB, HA, HB, _ = self.parts[pid]
+        return [HA[lo:hi], HB[lo:hi]]
+
+    def import_rows(self, tensors, widths, row0=None):
+        self.NA, self.NB = widths
+        self.parts.append((None, None, tensors[0].to(self.device), tensors[1].to(self.device), row0))
+        return len(self.parts) - 1
+
+    def drop_part(self, pid):
+        self.parts[pid] = None
+
     def ensure_acc(self, N):
         self._acc(self.S if self.sal == 1 else self.S * self.S)
 
@@ -284,10 +367,13 @@ class _HipPairedSession(_HipSession):
         S = self.S
         return self._finish(total_rows, N, (S,) if self.sal == 1 else (S, S))
 
-    def results(self, pid):
+    def results_device(self, pid, keep=False):
+        """Scores of A, B and the two null groups, deltas, null distances, STEP 4's per-bin reduction and the quiescence mask
+        of part `pid` from its resident histograms, as device tensors."""
         eng, S, NA, NB, q = self.eng, self.S, self.NA, self.NB, self.q
         XA, XB, HA, HB, row0 = self.parts[pid]
-        self.parts[pid] = None
+        if not keep:
+            self.parts[pid] = None
         ga, gb = (NA, NB) if self.groupSize == -1 else (self.groupSize, self.groupSize)
         # the null groups' histograms straight from the real groups' (multivariate hypergeometric, no pass over X)
         HnA, HnB = eng.null_hist_from_binhist(HA, HB, NA + NB, S, ga, gb, self.seed, row0)
@@ -305,8 +391,12 @@ class _HipPairedSession(_HipSession):
         _, null = eng.pair_finish(nA, nB)
         rdist, mdiff = eng.pair_metrics(delta, roundtrip=True)     # what STEP 4 would recompute from the text
         quies = eng.quiescent_from_binhist(HA, NA, HB, NB, S, self.qstate)
-        return {"delta": delta.cpu().numpy(), "null": null.cpu().numpy(), "quies": quies.cpu().numpy().astype(bool),
-                "rdist": rdist.cpu().numpy(), "mdiff": mdiff.cpu().numpy()}
+        return {"delta": delta, "null": null, "quies": quies, "rdist": rdist, "mdiff": mdiff}
+
+    def results(self, pid):
+        r = self.results_device(pid)
+        return {"delta": r["delta"].cpu().numpy(), "null": r["null"].cpu().numpy(), "quies": r["quies"].cpu().numpy().astype(bool),
+                "rdist": r["rdist"].cpu().numpy(), "mdiff": r["mdiff"].cpu().numpy()}
 
 
 def get():

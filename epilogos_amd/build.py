@@ -61,20 +61,49 @@ def build_io_library(force=False, verbose=False):
     return IO_LIB_PATH
 
 
-def build_library(force=False, verbose=False, extra_flags=()):
-    """Compile every HIP source into one shared library.  Returns the path."""
-    if not force and not is_stale():
-        return LIB_PATH
-    LIB_DIR.mkdir(parents=True, exist_ok=True)
-    tmp = LIB_DIR / (LIB_PATH.name + ".tmp.%d" % os.getpid())
-    cmd = [_hipcc(), "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-I" + str(ROOT / "include"), "-I" + str(CSRC), *extra_flags,
-           *[str(CSRC / s) for s in SOURCES], "-o", str(tmp)]
+OBJ_DIR = LIB_DIR / "obj"
+
+
+def _compile_one(src, obj, extra_flags, verbose):
+    cmd = [_hipcc(), "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-c",
+           "-I" + str(ROOT / "include"), "-I" + str(CSRC), *extra_flags, str(src), "-o", str(obj)]
     if verbose:
         print(" ".join(cmd), flush=True)
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode != 0:
-        raise RuntimeError("hipcc failed:\n" + res.stdout + res.stderr)
+        raise RuntimeError("hipcc failed on %s:\n%s%s" % (src.name, res.stdout, res.stderr))
+
+
+def build_library(force=False, verbose=False, extra_flags=()):
+    """Compile every HIP source into one shared library (one object per source, the stale ones in parallel, then one
+    link).  Returns the path."""
+    if not force and not is_stale():
+        return LIB_PATH
+    from concurrent.futures import ThreadPoolExecutor
+    OBJ_DIR.mkdir(parents=True, exist_ok=True)
+    flag_tag = OBJ_DIR / "flags.txt"
+    flags_now = " ".join(extra_flags)
+    same_flags = flag_tag.exists() and flag_tag.read_text() == flags_now
+    hdr_t = max(h.stat().st_mtime for h in HEADERS)
+    todo, objs = [], []
+    for s in SOURCES:
+        src, obj = CSRC / s, OBJ_DIR / (s + ".o")
+        objs.append(obj)
+        if force or not same_flags or not obj.exists() or obj.stat().st_mtime < max(src.stat().st_mtime, hdr_t):
+            todo.append((src, obj))
+    jobs = max(1, min(len(todo), int(os.environ.get("EPILOGOS_BUILD_JOBS", os.cpu_count() or 4))))
+    if todo:
+        with ThreadPoolExecutor(max_workers=jobs) as pool:
+            for f in [pool.submit(_compile_one, src, obj, extra_flags, verbose) for src, obj in todo]:
+                f.result()
+        flag_tag.write_text(flags_now)
+    tmp = LIB_DIR / (LIB_PATH.name + ".tmp.%d" % os.getpid())
+    cmd = [_hipcc(), "--offload-arch=" + ARCH, "-fPIC", "-shared", *[str(o) for o in objs], "-o", str(tmp)]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise RuntimeError("hipcc link failed:\n" + res.stdout + res.stderr)
     os.replace(tmp, LIB_PATH)
     return LIB_PATH
 

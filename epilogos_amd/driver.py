@@ -28,7 +28,7 @@ import numpy as np
 
 from . import _io
 from . import backend as _backend
-from .helpers import countRows, fileStem, readStates, readTable, splitRows
+from .helpers import fileStem, readStates, readTable, splitRows
 from .scores import writeScores
 
 
@@ -67,7 +67,7 @@ class _Timer:
             print("    [timing] " + text, flush=True)
 
 
-_DTYPES = [np.float32, np.uint8, np.int64, np.int32, np.bool_]
+_DTYPES = [np.float32, np.uint8, np.int64, np.int32, np.bool_, np.int16, np.int8]
 
 
 class _Dist:
@@ -105,147 +105,70 @@ class _Dist:
         if self.dist:
             self.dist.barrier()
 
-    # point-to-point hand-over of result arrays to rank 0: a small header (dtype, shape), then the bytes
-    def _tensor(self, arr):
+    def max_ints(self, values):
+        """Element-wise maximum of a short list of non-negative integers over the ranks (a rank without files learns the
+        column counts this way instead of opening a file)."""
+        if not self.dist:
+            return [int(v) for v in values]
         import torch
-        t = torch.from_numpy(arr)
-        return t.to(self.comm_device) if self.comm_device is not None else t
+        t = torch.tensor([int(v) for v in values], dtype=torch.int64)
+        if self.comm_device is not None:
+            t = t.to(self.comm_device)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return [int(v) for v in t.cpu().tolist()]
 
-    def send_arrays(self, arrays, dst):
+    # point-to-point hand-over of arrays / tensors: a small header (dtype, shape), then the bytes.  Device tensors travel
+    # device to device over RCCL; with a host-side backend (gloo) they are staged through the host.
+    def send_tensors(self, tensors, dst):
         import torch
-        for a in arrays:
-            a = np.ascontiguousarray(a)
-            if a.ndim > 2:
-                raise ValueError("send_arrays: at most two dimensions")
-            shape = list(a.shape) + [1] * (2 - a.ndim)
-            head = np.array([_DTYPES.index(a.dtype.type), a.ndim] + shape, dtype=np.int64)
-            self.dist.send(self._tensor(head), dst)
-            if a.size:
-                self.dist.send(self._tensor(a.reshape(-1).view(np.uint8)), dst)
+        for t in tensors:
+            if isinstance(t, np.ndarray):
+                t = torch.from_numpy(np.ascontiguousarray(t))
+            if t.dim() > 2:
+                raise ValueError("send_tensors: at most two dimensions")
+            t = t.contiguous()
+            np_dtype = np.dtype(str(t.dtype).replace("torch.", "")).type
+            shape = list(t.shape) + [1] * (2 - t.dim())
+            head = torch.tensor([_DTYPES.index(np_dtype), t.dim()] + shape, dtype=torch.int64)
+            self.dist.send(head.to(self.comm_device) if self.comm_device is not None else head, dst)
+            if t.numel():
+                flat = t.reshape(-1).view(torch.uint8)
+                flat = flat.to(self.comm_device) if self.comm_device is not None else flat.cpu()
+                self.dist.send(flat, dst)
 
-    def recv_arrays(self, n, src):
+    def recv_tensors(self, n, src):
+        """-> n tensors, on the communicator's device (RCCL) or on the host (gloo)."""
         import torch
         out = []
         for _ in range(n):
             head = torch.zeros(4, dtype=torch.int64, device=self.comm_device)
             self.dist.recv(head, src)
             code, ndim, d0, d1 = (int(v) for v in head.cpu().tolist())
-            dtype = np.dtype(_DTYPES[code])
+            dtype = getattr(torch, np.dtype(_DTYPES[code]).name)
             shape = (d0, d1)[:ndim]
-            nbytes = int(np.prod(shape)) * dtype.itemsize
+            nbytes = int(np.prod(shape)) * np.dtype(_DTYPES[code]).itemsize
+            buf = torch.empty(nbytes, dtype=torch.uint8, device=self.comm_device)
             if nbytes:
-                buf = torch.empty(nbytes, dtype=torch.uint8, device=self.comm_device)
                 self.dist.recv(buf, src)
-                out.append(buf.cpu().numpy().view(dtype).reshape(shape))
-            else:
-                out.append(np.zeros(shape, dtype=dtype))
+            out.append(buf.view(dtype).reshape(shape))
         return out
 
+    def send_arrays(self, arrays, dst):
+        self.send_tensors([np.ascontiguousarray(a) for a in arrays], dst)
 
-# ---- sessions over a host-array backend (the oracle-backed stand-in of the CPU tests): same protocol as the device-
-# resident sessions of backend.HipBackend, arithmetic through the backend's array methods
-class _HostSession:
-    def __init__(self, be, S, saliency):
-        self.be, self.S, self.sal = be, S, saliency
-        self.counts, self.parts, self.q = None, [], None
-        self.n_uploads = 0
-
-    def alloc(self, ticket):
-        return None
-
-    def skip(self, ticket):
-        pass
-
-    def _add_counts(self, c):
-        self.counts = c if self.counts is None else self.counts + c
-
-    def all_reduce(self, d):
-        self.counts = d.all_reduce_counts(self.counts)
-
-    def _finish(self, total_rows, N, shape):
-        self.be.check_counts(self.counts, total_rows, N, self.sal)
-        self.q = self.be.normalise(self.counts)
-        return self.q
-
-
-class _HostSingleSession(_HostSession):
-    def add_part(self, arr, N, ticket):
-        x = arr[:, :N]
-        self._add_counts(self.be.expected_counts(x, self.S, self.sal))
-        self.parts.append(x)
-        return len(self.parts) - 1
-
-    def ensure_acc(self, N):
-        if self.counts is None:                        # a rank without bins still takes part in the all-reduce
-            S = self.S
-            self.counts = np.zeros({1: (S,), 2: (S, S), 3: (N, N, S, S)}[self.sal], dtype=np.int32 if self.sal == 3 else np.int64)
-
-    def finish(self, total_rows, N):
-        S = self.S
-        return self._finish(total_rows, N, {1: (S,), 2: (S, S), 3: (N, N, S, S)}[self.sal])
-
-    def scores(self, pid):
-        x, self.parts[pid] = self.parts[pid], None
-        return self.be.scores(x, self.S, self.sal, self.q)
-
-
-class _HostPairedSession(_HostSession):
-    def __init__(self, be, S, saliency, quiescentState, groupSize, seed):
-        super().__init__(be, S, saliency)
-        self.qstate, self.groupSize, self.seed = quiescentState, groupSize, seed
-
-    def stage(self, arr, N, ticket):
-        return arr[:, :N]
-
-    def set_row0(self, pid, row0):
-        xa, xb, _ = self.parts[pid]
-        self.parts[pid] = (xa, xb, row0)
-
-    def add_part(self, arrA, NA, ticketA, arrB, NB, ticketB, row0):
-        return self.add_staged(arrA[:, :NA], NA, arrB[:, :NB], NB, row0)
-
-    def add_staged(self, xa, NA, xb, NB, row0):
-        self._add_counts(self.be.expected_counts(np.concatenate((xa, xb), axis=1), self.S, self.sal))
-        self.parts.append((xa, xb, row0))
-        return len(self.parts) - 1
-
-    def ensure_acc(self, N):
-        if self.counts is None:
-            self.counts = np.zeros((self.S,) if self.sal == 1 else (self.S, self.S), dtype=np.int64)
-
-    def finish(self, total_rows, N):
-        return self._finish(total_rows, N, (self.S,) if self.sal == 1 else (self.S, self.S))
-
-    def results(self, pid):
-        be, S, sal, q = self.be, self.S, self.sal, self.q
-        (xa, xb, row0), self.parts[pid] = self.parts[pid], None
-        n1, n2 = xa.shape[1], xb.shape[1]
-        s1 = be.scores(xa, S, sal, q, perms=n1 * (n1 - 1))
-        s2 = be.scores(xb, S, sal, q, perms=n2 * (n2 - 1))
-        na, nb = be.null_scores(xa, xb, S, sal, q, self.groupSize, self.seed, row0=row0)
-        delta, _ = be.pair_finish(s1, s2)
-        _, null = be.pair_finish(na, nb)
-        rdist, mdiff = be.pair_metrics(delta, roundtrip=True)      # what STEP 4 would recompute from the text
-        return {"delta": delta, "null": null, "quies": be.quiescent(xa, xb, self.qstate), "rdist": rdist, "mdiff": mdiff}
+    def recv_arrays(self, n, src):
+        return [t.cpu().numpy() for t in self.recv_tensors(n, src)]
 
 
 def _open_single(be, S, saliency):
-    return be.open_single(S, saliency) if hasattr(be, "open_single") else _HostSingleSession(be, S, saliency)
+    return be.open_single(S, saliency)
 
 
 def _open_paired(be, S, saliency, quiescentState, groupSize, seed):
-    if hasattr(be, "open_paired"):
-        return be.open_paired(S, saliency, quiescentState, groupSize, seed)
-    return _HostPairedSession(be, S, saliency, quiescentState, groupSize, seed)
+    return be.open_paired(S, saliency, quiescentState, groupSize, seed)
 
 
 # ---- input side
-def _count_rows(files):
-    """countRows of every file (a gunzip pass each), files in parallel: the native counter releases the GIL."""
-    with ThreadPoolExecutor(max_workers=max(1, min(16, len(files)))) as pool:
-        return list(pool.map(countRows, files))
-
-
 def _check_range(path, rng, numStates):
     """The reference indexes a numStates-long array with (file value - 1) and dies on anything outside the model
     (expected.py:113 IndexError); a state model smaller than the data must not run to completion here either."""
@@ -380,14 +303,87 @@ def _gather_parts(d, plans, my_payloads, n_arrays):
     return got
 
 
-def _plan(files, d, tm, known_rows=None):
-    """(rows per file or None, jobs of this rank).  A single rank reads whole files and learns the row counts from the
-    parse instead of a separate gunzip pass per file."""
+def _cached_rows(path):
+    """Rows of an input file if the --cache-dir side-car of an earlier run knows them (no pass over the file), else None."""
+    from .helpers import _cache_paths
+    cache = _cache_paths(path)
+    if cache is None or not all(c.exists() for c in cache):
+        return None
+    return int(np.load(cache[2], mmap_mode="r").shape[0]) - 1
+
+
+def _assign_files(files, world):
+    """Parser rank of every file while the row counts are still unknown: the bin-range partition ESTIMATED from the file
+    sizes (bytes stand in for bins), every file to the rank that would own most of it -- so that, once the real counts
+    are in, only the short pieces at the range borders have to change hands."""
+    sizes = [max(os.path.getsize(f), 1) for f in files]
+    owner, share = [0] * len(files), [-1] * len(files)
+    for g, parts in enumerate(plan_partition(sizes, world)):
+        for fi, lo, hi in parts:
+            if hi - lo > share[fi]:
+                share[fi], owner[fi] = hi - lo, g
+    return owner
+
+
+def _plan(files, d, tm):
+    """-> (mode, rows per file or None, jobs [(file index, lo, hi or None)] of this rank, parser rank per file or None).
+    "whole":    one rank; whole files, the row counts come out of the parse.
+    "ranges":   several ranks and every row count is known from the --cache-dir side-cars: each rank reads exactly its own
+                row ranges from the cache; nothing is inflated, nothing changes hands.
+    "assigned": several ranks, text inputs.  Every file is inflated and parsed ONCE, by ONE rank (_assign_files), which
+                also runs the count pass over it -- the counts are summed over the ranks anyway, whoever owns the bins.
+                The row counts are then exchanged (one all-reduce of a vector with an entry per file), the exact bin-range
+                partition follows, and what the score pass needs of the rows a rank parsed for another (per-bin histograms
+                for S1 / S2 / paired, state rows for S3) is handed over device to device.  (Round 2 let EVERY rank gunzip
+                EVERY file just to count its lines before the first byte was parsed: the reference's helpers.py:154
+                re-read, one level up.)"""
+    F = len(files)
     if d.world == 1:
-        return None, [(fi, 0, None) for fi in range(len(files))]
-    rows = _count_rows(files)
-    tm.lap("count rows")
-    return rows, plan_partition(rows, d.world)[d.rank]
+        return "whole", None, [(fi, 0, None) for fi in range(F)], None
+    rows = [_cached_rows(f) for f in files]
+    if all(r is not None for r in rows):
+        return "ranges", rows, plan_partition(rows, d.world)[d.rank], None
+    owner = _assign_files(files, d.world)
+    return "assigned", None, [(fi, 0, None) for fi in range(F) if owner[fi] == d.rank], owner
+
+
+def _exchange_rows(d, jobs, locs, F):
+    """Row count of every file from the ranks that parsed them: one all-reduce of an int64 vector."""
+    vec = np.zeros(F, dtype=np.int64)
+    for t, (fi, _lo, _hi) in enumerate(jobs):
+        vec[fi] = len(locs[t])
+    return [int(v) for v in d.all_reduce_counts(vec)]
+
+
+def _redistribute(d, sess, plans, owner, mine, starts, widths):
+    """"assigned" mode, after the exact plan is known.  mine: {file index: (session part id of the whole file, Locations)}
+    of the files this rank parsed.  Walks every part of every rank's range in ONE global order (all ranks run the same
+    loop, so each blocking send meets its receive): a part whose parser is its owner becomes a row slice of the resident
+    data; otherwise the parser sends what the score pass needs plus the rows' coordinates, and the owner takes them in.
+    Returns the session part ids and the Locations of this rank's parts, in plan order."""
+    pid_of, loc_of = {}, {}
+    for g, parts in enumerate(plans):
+        for fi, lo, hi in parts:
+            p = owner[fi]
+            row0 = int(starts[fi]) + lo
+            if p == g:
+                if d.rank == g:
+                    pid, loc = mine[fi]
+                    part = loc.slice(lo, hi)
+                    pid_of[(fi, lo)] = sess.slice_part(pid, lo, hi, row0)
+                    loc_of[(fi, lo)] = _io.Locations(np.ascontiguousarray(part.blob), np.ascontiguousarray(part.offsets))
+            elif d.rank == p:
+                pid, loc = mine[fi]
+                part = loc.slice(lo, hi)
+                d.send_tensors(list(sess.export_rows(pid, lo, hi)) + [np.ascontiguousarray(part.blob), np.ascontiguousarray(part.offsets)], g)
+            elif d.rank == g:
+                got = d.recv_tensors(sess.n_export + 2, p)
+                pid_of[(fi, lo)] = sess.import_rows(got[:-2], widths, row0)
+                loc_of[(fi, lo)] = _io.Locations(got[-2].cpu().numpy(), got[-1].cpu().numpy())
+    for pid, _loc in mine.values():                    # the whole-file entries; the slices keep alive what they use
+        sess.drop_part(pid)
+    my = plans[d.rank]
+    return [pid_of[(fi, lo)] for fi, lo, _hi in my], [loc_of[(fi, lo)] for fi, lo, _hi in my]
 
 
 def run_single_group(files, numStates, saliency, outputDir, fileTag, verbose=False, backend=None, device=None,
@@ -404,7 +400,7 @@ def run_single_group(files, numStates, saliency, outputDir, fileTag, verbose=Fal
     if d.rank == 0:
         _clean_parts(outputDir, "scores", fileTag)
     d.barrier()
-    rows, my_parts = _plan(files, d, tm)
+    mode, rows, my_parts, owner = _plan(files, d, tm)
     sess = _open_single(be, numStates, saliency)
 
     # STEP 1: every part of this rank is parsed, uploaded once and counted; what the score pass needs stays resident
@@ -414,13 +410,25 @@ def run_single_group(files, numStates, saliency, outputDir, fileTag, verbose=Fal
             N = n
             pids[t] = sess.add_part(arr, n, t)
             locs[t] = loc
-    if rows is None:
+    if mode == "whole":
         rows = [len(l) for l in locs]
         my_parts = [(fi, 0, rows[fi]) for fi in range(len(files))]
-    plans = plan_partition(rows, d.world) if d.world > 1 else [my_parts]
-    if N is None:
+    if d.world > 1:
+        N = d.max_ints([N or 0])[0]                    # a rank without bins learns the width from the others
+    if mode == "assigned":
+        rows = _exchange_rows(d, my_parts, locs, len(files))
+        tm.lap("parse + upload + expected counts (each file once, on one rank)")
+        plans = plan_partition(rows, d.world)
+        starts = np.concatenate([[0], np.cumsum(rows)])
+        mine = {fi: (pids[t], locs[t]) for t, (fi, _lo, _hi) in enumerate(my_parts)}
+        pids, locs = _redistribute(d, sess, plans, owner, mine, starts, N)
+        my_parts = plans[d.rank]
+        tm.lap("hand border pieces to their owners")
+    else:
+        plans = plan_partition(rows, d.world) if d.world > 1 else [my_parts]
+        tm.lap("parse + upload + expected counts")
+    if not N:
         N = _columns_of(files[0])
-    tm.lap("parse + upload + expected counts")
     sess.ensure_acc(N)
     sess.all_reduce(d)                                # the one exchange step; a rank without bins contributes zeros
     q = sess.finish(int(sum(rows)), N)                # count check, STEP 2: identical normalisation on every rank
@@ -486,7 +494,7 @@ def run_paired_groups(files1, files2, numStates, saliency, outputDir, fileTag, q
     if d.rank == 0:
         _clean_parts(outputDir, "pairwiseDelta", fileTag)
     d.barrier()
-    rows, my_parts = _plan(files1, d, tm)
+    mode, rows, my_parts, owner = _plan(files1, d, tm)
     sess = _open_paired(be, numStates, saliency, quiescentState, groupSize, nullSeed)
 
     # group 1 and group 2 of a part are jobs 2k and 2k + 1; the second group follows the first one's row ranges
@@ -511,22 +519,33 @@ def run_paired_groups(files1, files2, numStates, saliency, outputDir, fileTag, q
             fi, lo, hi = my_parts[k]
             if rA != rB:
                 raise ValueError("paired inputs differ in length: {} vs {}".format(files1[fi], files2[fi]))
-            # global bin index of the part's first row (keys the null shuffle): from the plan; a single rank reading whole
-            # files learns it once every part has been parsed (below)
+            # global bin index of the part's first row (keys the null shuffle): from the plan when the row counts are known
+            # beforehand; otherwise it is set once every part has been parsed (below)
             row0 = int(sum(rows[:fi])) + lo if rows is not None else None
             pids[k] = sess.add_staged(XA, nA, XB, nB, row0)
-    if rows is None:
+    if mode == "whole":                                # single rank: row counts and first-row indices come from the parse
         seen = 0
         for k in range(len(my_parts)):
             sess.set_row0(pids[k], seen)
             seen += len(locs[k])
-    if rows is None:                                   # single rank: row counts come from the parse
         rows = [len(l) for l in locs]
         my_parts = [(fi, 0, rows[fi]) for fi in range(len(files1))]
-    plans = plan_partition(rows, d.world) if d.world > 1 else [my_parts]
-    if NA is None:
+    if d.world > 1:
+        NA, NB = d.max_ints([NA or 0, NB or 0])
+    if mode == "assigned":
+        rows = _exchange_rows(d, my_parts, locs, len(files1))
+        tm.lap("parse + upload + expected counts (each file once, on one rank)")
+        plans = plan_partition(rows, d.world)
+        starts = np.concatenate([[0], np.cumsum(rows)])
+        mine = {fi: (pids[k], locs[k]) for k, (fi, _lo, _hi) in enumerate(my_parts)}
+        pids, locs = _redistribute(d, sess, plans, owner, mine, starts, (NA, NB))
+        my_parts = plans[d.rank]
+        tm.lap("hand border pieces to their owners")
+    else:
+        plans = plan_partition(rows, d.world) if d.world > 1 else [my_parts]
+        tm.lap("parse + upload + expected counts")
+    if not NA:
         NA, NB = _columns_of(files1[0]), _columns_of(files2[0])
-    tm.lap("parse + upload + expected counts")
     sess.ensure_acc(NA + NB)
     sess.all_reduce(d)
     q = sess.finish(int(sum(rows)), NA + NB)

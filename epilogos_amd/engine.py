@@ -171,15 +171,20 @@ def hist_s2_from_binhist_pair(HA, HB, S, counts=None):
     return counts
 
 
-def hist_s3(X, N, S, counts=None, use_workspace=True):
+def hist_s3_ws_bytes(R, N, S):
+    return max(int(_abi.call("epg_ws_bytes", 3, R, N, S)), 256)
+
+
+def hist_s3(X, N, S, counts=None, use_workspace=True, ws=None):
     """counts int32 [N*N*S*S] += biosample-pair state co-occurrences.  With a workspace (room for the transposed matrix)
-    the matrix-core kernel runs; without one the ABI falls back to the LDS-counter kernel (same integers)."""
+    the matrix-core kernel runs; without one the ABI falls back to the LDS-counter kernel (same integers).  `ws`: a
+    caller-owned workspace of at least hist_s3_ws_bytes(R, N, S) bytes (a session reuses one for all its parts)."""
     R, ldx = _check_states(X, N)
     if counts is None:
         counts = zeros_counts(N * N * S * S, dtype=torch.int32, device=X.device)
     if use_workspace:
-        nbytes = _abi.call("epg_ws_bytes", 3, R, N, S)
-        ws = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=X.device)
+        if ws is None:
+            ws = torch.empty(hist_s3_ws_bytes(R, N, S), dtype=torch.uint8, device=X.device)
         _abi.call("epg_hist_s3", _ptr(X), R, N, ldx, S, _ptr(counts), _ptr(ws), ws.numel(), _stream())
     else:
         _abi.call("epg_hist_s3", _ptr(X), R, N, ldx, S, _ptr(counts), None, 0, _stream())
@@ -267,10 +272,12 @@ def score_s2_from_binhist(H, N, S, q, perms=None, want32=True, want64=False, out
     return o32, o64
 
 
-def score_s3(X, N, S, q, want32=True, want64=False):
+def score_s3(X, N, S, q, want32=True, want64=False, ws=None):
+    """`ws`: caller-owned workspace of at least epg_ws_bytes(3, R, N, S) bytes (tables + transposed matrix + cells)."""
     R, ldx = _check_states(X, N)
     o32, o64 = _outs(R, S, X.device, want32, want64)
-    ws = _ws(3, R, N, S, X.device)
+    if ws is None:
+        ws = _ws(3, R, N, S, X.device)
     _abi.call("epg_score_s3", _ptr(X), R, N, ldx, S, _ptr(q), _ptr(o64), _ptr(o32), _ptr(ws), ws.numel(), _stream())
     return o32, o64
 
@@ -363,17 +370,16 @@ class PinnedPool:
 
 def upload_states(pinned, R, ldx, copy_stream, device="cuda"):
     """Asynchronous H2D copy of a staged [R, ldx] int8 matrix on `copy_stream`.  Returns (X, event): the current stream
-    must wait for the event before reading X; the staging buffer may be reused once the event has completed."""
-    X = torch.empty((R, ldx), dtype=torch.int8, device=device)
-    if R == 0:
-        ev = torch.cuda.Event()
-        ev.record(copy_stream)
-        return X, ev
+    must wait for the event before reading X; the staging buffer may be reused once the event has completed.  X is allocated
+    on the copy stream (the caching allocator then knows the copy may start at once) and recorded for the current stream,
+    which is where the kernels that read it run."""
     with torch.cuda.stream(copy_stream):
-        X.copy_(pinned[:R * ldx].view(R, ldx), non_blocking=True)
+        X = torch.empty((R, ldx), dtype=torch.int8, device=device)
+        if R:
+            X.copy_(pinned[:R * ldx].view(R, ldx), non_blocking=True)
         ev = torch.cuda.Event()
         ev.record(copy_stream)
-    X.record_stream(copy_stream)
+    X.record_stream(torch.cuda.current_stream())
     return X, ev
 
 

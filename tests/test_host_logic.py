@@ -179,6 +179,15 @@ def _decompressed(path):
         return fh.read()
 
 
+def _io_passes(log):
+    """{input path: [(operation, lo, hi)]} from an EPILOGOS_IO_LOG file: every entry is one pass over the whole file."""
+    passes = {}
+    for line in Path(log).read_text().splitlines():
+        _pid, op, path, lo, hi = line.split("\t")
+        passes.setdefault(path, []).append((op, int(lo), int(hi)))
+    return passes
+
+
 def test_two_rank_gloo_matches_single_process(tmp_path, golden_real):
     """world_size 2 over gloo on CPU: partition + all-reduce + per-rank gzip members == the single-process output."""
     g = golden_real
@@ -191,13 +200,18 @@ def test_two_rank_gloo_matches_single_process(tmp_path, golden_real):
     for world in (1, 2):
         out = tmp_path / ("out%d" % world)
         out.mkdir()
-        env = dict(os.environ, PYTHONPATH=str(ROOT), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29400 + os.getpid() % 500))
+        env = dict(os.environ, PYTHONPATH=str(ROOT), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29400 + os.getpid() % 500),
+                   EPILOGOS_IO_LOG=str(tmp_path / ("io%d.log" % world)))
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
                "--master-addr", "127.0.0.1", "--master-port", env["MASTER_PORT"],
                str(ROOT / "tests" / "gloo_worker.py"), str(ind), str(out)]
         res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
         assert res.returncode == 0, res.stdout + res.stderr
         outs[world] = out
+        # every input file is inflated and parsed exactly ONCE in total, whole, whatever the number of ranks (round 2: every
+        # rank made a counting pass over every file before the first byte was parsed)
+        assert _io_passes(tmp_path / ("io%d.log" % world)) == {str(ind / "matrix_chr1.txt"): [("read", 0, -1)],
+                                                               str(ind / "matrix_chr2.txt"): [("read", 0, -1)]}
     for name in ("scores_t_s1_matrix_chr1.txt.gz", "scores_t_s1_matrix_chr2.txt.gz"):
         assert _decompressed(outs[1] / name) == _decompressed(outs[2] / name)
     assert np.array_equal(np.load(outs[1] / "exp_freq_t_s1.npy"), np.load(outs[2] / "exp_freq_t_s1.npy"))
@@ -222,12 +236,14 @@ def test_two_rank_gloo_paired_matches_single_process(tmp_path, golden_pair):
         out = tmp_path / ("out%d" % world)
         out.mkdir()
         port = str(free_port())
-        env = dict(os.environ, PYTHONPATH=str(ROOT), MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
+        env = dict(os.environ, PYTHONPATH=str(ROOT), MASTER_ADDR="127.0.0.1", MASTER_PORT=port, EPILOGOS_IO_LOG=str(tmp_path / ("io%d.log" % world)))
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
                "--master-addr", "127.0.0.1", "--master-port", port, str(ROOT / "tests" / "gloo_worker.py"), str(ind), str(out)]
         res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
         assert res.returncode == 0, res.stdout + res.stderr
         outs[world] = out
+        passes = _io_passes(tmp_path / ("io%d.log" % world))
+        assert len(passes) == 4 and all(v == [("read", 0, -1)] for v in passes.values()), passes
     for stem in ("matrix_chr1", "matrix_chr2"):
         assert _decompressed(outs[1] / ("pairwiseDelta_t_s1_%s.txt.gz" % stem)) == _decompressed(outs[2] / ("pairwiseDelta_t_s1_%s.txt.gz" % stem))
         for kind, key in (("temp_nullDistances", "nullDistances"), ("temp_quiescence", "quiescenceArr")):
@@ -376,6 +392,52 @@ def test_two_rank_gloo_prefix_stems(tmp_path, golden_real):
         z2 = np.load(outs[2] / ("temp_scores_t_s1_%s.npz" % stem), allow_pickle=True)
         assert np.array_equal(z1["scoreArr"], z2["scoreArr"]) and np.array_equal(z1["locationArr"], z2["locationArr"])
     assert not list(outs[2].glob(".part_*"))
+
+
+def test_three_rank_gloo_uneven_files_text_then_cache(tmp_path, golden_real):
+    """Four files of very different sizes over three ranks: the long second file is parsed by the middle rank, whose bin
+    range covers only its middle -- the head goes to rank 0, the tail to rank 2 (driver._redistribute); outputs equal the
+    single-process ones byte for byte and every file is read once.  A second run with the --cache-dir side-cars takes the
+    "ranges" route: no pass over any text file, each rank memory-maps its own row ranges."""
+    x = golden_real["x"]
+    ind = tmp_path / "in"
+    ind.mkdir()
+    cuts = [0, 90, 1400, 1460, x.shape[0]]
+    for k in range(4):
+        write_tsv(ind / ("m_chr%d.txt" % (k + 1)), x[cuts[k]:cuts[k + 1]], chrom="chr%d" % (k + 1))
+    cache = tmp_path / "cache"
+    outs = {}
+    for tag, world, use_cache in (("one", 1, False), ("three", 3, False), ("fill", 1, True), ("cached", 3, True)):
+        out = tmp_path / ("out_" + tag)
+        out.mkdir()
+        port = str(free_port())
+        env = dict(os.environ, PYTHONPATH=str(ROOT), MASTER_ADDR="127.0.0.1", MASTER_PORT=port, EPILOGOS_IO_LOG=str(tmp_path / (tag + ".log")))
+        env.pop("EPILOGOS_CACHE_DIR", None)
+        if use_cache:
+            env["EPILOGOS_CACHE_DIR"] = str(cache)
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+               "--master-addr", "127.0.0.1", "--master-port", port, str(ROOT / "tests" / "gloo_worker.py"), str(ind), str(out)]
+        res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+        assert res.returncode == 0, res.stdout + res.stderr
+        outs[tag] = out
+    for tag in ("one", "three", "fill"):
+        passes = _io_passes(tmp_path / (tag + ".log"))
+        assert sorted(passes) == sorted(str(ind / ("m_chr%d.txt" % k)) for k in (1, 2, 3, 4)), (tag, passes)
+        assert all(v == [("read", 0, -1)] for v in passes.values()), (tag, passes)
+    assert not (tmp_path / "cached.log").exists()                # nothing was inflated or parsed: the cache served row ranges
+    for k in (1, 2, 3, 4):
+        name = "scores_t_s1_m_chr%d.txt.gz" % k
+        want = _decompressed(outs["one"] / name)
+        assert len(want.splitlines()) == cuts[k] - cuts[k - 1]
+        for tag in ("three", "fill", "cached"):
+            assert _decompressed(outs[tag] / name) == want, (tag, name)
+        z1 = np.load(outs["one"] / ("temp_scores_t_s1_m_chr%d.npz" % k), allow_pickle=True)
+        for tag in ("three", "cached"):
+            z = np.load(outs[tag] / ("temp_scores_t_s1_m_chr%d.npz" % k), allow_pickle=True)
+            assert np.array_equal(z1["scoreArr"], z["scoreArr"]) and np.array_equal(z1["locationArr"], z["locationArr"])
+    for tag in ("three", "cached"):
+        assert np.array_equal(np.load(outs["one"] / "exp_freq_t_s1.npy"), np.load(outs[tag] / "exp_freq_t_s1.npy"))
+        assert not list(outs[tag].glob(".part_*"))
 
 
 def test_cli_rejects_states_outside_the_model(tmp_path, golden_real, fake_backend, state_info):
