@@ -87,7 +87,7 @@ class HipBackend:
         qd = q.reshape(-1) if self.torch.is_tensor(q) else \
             self.torch.from_numpy(np.ascontiguousarray(q, dtype=np.float32).reshape(-1)).to(self.device)
         if saliency == 1:
-            o32, _ = eng.score_s1(X, N, S, qd)
+            o32 = self._score_s1_host_table(eng.bin_hist(X, N, S, want_counts=False)[0], N, S, q)
         elif saliency == 2:
             o32, _ = eng.score_s2(X, N, S, qd, perms=perms)
         elif saliency == 3:
@@ -95,6 +95,15 @@ class HipBackend:
         else:
             raise ValueError("Please ensure that saliency metric is either 1, 2, or 3")
         return o32.cpu().numpy()
+
+    def _score_s1_host_table(self, H, N, S, q):
+        """S1 scores from histograms through the table the host builds with the reference's arithmetic (scores.s1ScoreTable):
+        float32 values identical to the reference's, hence identical text."""
+        from .scores import s1ScoreTable
+        qh = q.cpu().numpy() if self.torch.is_tensor(q) else np.asarray(q, dtype=np.float32)
+        _t64, t32 = s1ScoreTable(qh.reshape(-1), N)
+        o32, _ = self.engine.score_s1_from_binhist_table(H, N, S, T32=self.torch.from_numpy(t32).to(self.device))
+        return o32
 
     # ---- paired extras
     def pair_finish(self, a, b):
@@ -120,8 +129,7 @@ class HipBackend:
         HA, HB = eng.null_hist(self.to_device(xa), NA, self.to_device(xb), NB, S, ga, gb, seed, row0)
         qd = self.torch.from_numpy(np.ascontiguousarray(q, dtype=np.float32).reshape(-1)).to(self.device)
         if saliency == 1:
-            na, _ = eng.score_s1_from_binhist(HA, ga, S, qd)
-            nb, _ = eng.score_s1_from_binhist(HB, gb, S, qd)
+            na, nb = self._score_s1_host_table(HA, ga, S, q), self._score_s1_host_table(HB, gb, S, q)
         elif saliency == 2:
             # quirk Q9: the null halves keep the ORIGINAL groups' permutation counts (scores.py:397-398,418-421)
             na, _ = eng.score_s2_from_binhist(HA, max(ga, NA), S, qd, perms=NA * (NA - 1))
@@ -157,6 +165,7 @@ class _HipSession:
         self.n_uploads = 0
         self.upload_bytes = 0
         self._releaser = None
+        self._t1 = {}                                    # S1 score tables by group width
         self._ws3 = None                                 # S3 expected pass: ONE workspace for all parts of the session
 
     def alloc(self, ticket):
@@ -215,6 +224,16 @@ class _HipSession:
 
     def all_reduce(self, d):
         d.all_reduce_tensor(self.acc)                    # RCCL over xGMI: the tensor never leaves HBM
+
+    def _score_s1(self, H, N):
+        """S1 score pass of the command line: the lookup table comes from the host (scores.s1ScoreTable: numpy's log2 on the
+        exp_freq this session normalised), so the float32 scores are the reference's bit for bit; one table per group width."""
+        if N not in self._t1:
+            from .scores import s1ScoreTable
+            _t64, t32 = s1ScoreTable(self.q.cpu().numpy(), N)
+            self._t1[N] = self.torch.from_numpy(t32).to(self.device)
+        o32, _ = self.eng.score_s1_from_binhist_table(H, N, self.S, T32=self._t1[N])
+        return o32
 
     def finish_device(self, total_rows, N):
         """Count check (the reference dies on a state outside the model, expected.py:113; here such a byte is counted
@@ -293,7 +312,7 @@ class _HipSingleSession(_HipSession):
         if not keep:
             self.parts[pid] = None                       # the part's device data is released with its scores
         if self.sal == 1:
-            o32, _ = eng.score_s1_from_binhist(D, N, S, self.q)
+            o32 = self._score_s1(D, N)
         elif self.sal == 2:
             o32, _ = eng.score_s2_from_binhist(D, N, S, self.q)
         else:                                            # one score workspace (table, transposed matrix, cells) for all parts
@@ -378,10 +397,8 @@ class _HipPairedSession(_HipSession):
         # the null groups' histograms straight from the real groups' (multivariate hypergeometric, no pass over X)
         HnA, HnB = eng.null_hist_from_binhist(HA, HB, NA + NB, S, ga, gb, self.seed, row0)
         if self.sal == 1:
-            sA, _ = eng.score_s1_from_binhist(HA, NA, S, q)
-            sB, _ = eng.score_s1_from_binhist(HB, NB, S, q)
-            nA, _ = eng.score_s1_from_binhist(HnA, ga, S, q)
-            nB, _ = eng.score_s1_from_binhist(HnB, gb, S, q)
+            sA, sB = self._score_s1(HA, NA), self._score_s1(HB, NB)
+            nA, nB = self._score_s1(HnA, ga), self._score_s1(HnB, gb)
         else:                                            # quirk Q9: null halves keep the original groups' permutation counts
             sA, _ = eng.score_s2_from_binhist(HA, NA, S, q, perms=NA * (NA - 1))
             sB, _ = eng.score_s2_from_binhist(HB, NB, S, q, perms=NB * (NB - 1))

@@ -35,6 +35,7 @@ int score_s1_from_hist_impl(const uint16_t*, int64_t, int32_t, int32_t, const fl
 int normalise_i64_impl(const int64_t*, int64_t, float*, void*, int64_t, hipStream_t);
 int normalise_i32_impl(const int32_t*, int64_t, float*, void*, int64_t, hipStream_t);
 int hist_s2_from_binhist_impl(const uint16_t*, const uint16_t*, int64_t, int32_t, int64_t*, hipStream_t);
+int score_s1_from_hist_table_impl(const uint16_t*, int64_t, int32_t, int32_t, const double*, const float*, double*, float*, hipStream_t);
 int combine_score_s1_impl(int64_t*, int32_t, const uint16_t*, int64_t, int32_t, int32_t, float*, double*, float*, void*, int64_t, hipStream_t);
 int64_t s2_table_bytes(int, int);
 int score_s2_from_hist_impl(const uint16_t*, int64_t, int32_t, int32_t, int64_t, const float*, double*, float*, void*, int64_t, hipStream_t);
@@ -138,6 +139,11 @@ int epg_score_s1(const int8_t* X, int64_t R, int32_t N, int64_t ldx, int32_t S, 
 int epg_score_s1_from_binhist(const uint16_t* H, int64_t R, int32_t N, int32_t S, const float* q, double* out64, float* out32,
                               void* ws, int64_t ws_bytes, void* stream) {
     return score_s1_from_hist_impl(H, R, N, S, q, out64, out32, ws, ws_bytes, (hipStream_t)stream);
+}
+
+int epg_score_s1_from_binhist_table(const uint16_t* H, int64_t R, int32_t N, int32_t S, const double* T64, const float* T32,
+                                    double* out64, float* out32, void* stream) {
+    return score_s1_from_hist_table_impl(H, R, N, S, T64, T32, out64, out32, (hipStream_t)stream);
 }
 
 int epg_score_s2_from_binhist(const uint16_t* H, int64_t R, int32_t N, int32_t S, int64_t perms, const float* q, double* out64,

@@ -428,6 +428,22 @@ int score_s1_from_hist_impl(const uint16_t* H, int64_t R, int32_t N, int32_t S, 
     return launch_score_s1_from_hist(H, R, N, S, T64, T32, out64, out32, st);
 }
 
+// The same score pass with the lookup table supplied by the caller (device pointers, [N + 1, S] row-major; either may be NULL
+// together with its output): the command line builds T[c, s] = kl(c / N, q[s]) on the host with numpy's log2 -- the
+// reference's own arithmetic (scores.py:343,550) -- so that scores_*.txt.gz equals the reference's byte for byte; the device
+// table above differs from it in the last bit of a few float64 logarithms, which moves ~0.1 % of the float32 stores.
+int score_s1_from_hist_table_impl(const uint16_t* H, int64_t R, int32_t N, int32_t S, const double* T64, const float* T32,
+                                  double* out64, float* out32, hipStream_t st) {
+    if (R < 0 || N < 1 || S < 1) return fail(EPG_ERR_INVALID_ARG, "score_s1: bad shape");
+    if (R == 0) return EPG_OK;
+    if (!H || (out64 && !T64) || (out32 && !T32)) return fail(EPG_ERR_INVALID_ARG, "score_s1_from_binhist_table: NULL argument");
+    if ((T64 && (reinterpret_cast<uintptr_t>(T64) & 7)) || (T32 && (reinterpret_cast<uintptr_t>(T32) & 3)))
+        return fail(EPG_ERR_INVALID_ARG, "score_s1_from_binhist_table: misaligned table");
+    int rc = check_score_from_hist_args(H, out64, out32);
+    if (rc) return rc;
+    return launch_score_s1_from_hist(H, R, N, S, T64, T32, out64, out32, st);
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // STEP 2 and the S1 table of STEP 3 in ONE launch (a whole S1 job on a 1.9 M-bin shard is ~0.35 ms of kernel time: a memset,
 // two normalise kernels and the table kernel, each with its ~1.7 us boundary and its host call, were a measurable part of

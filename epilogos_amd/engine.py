@@ -237,6 +237,18 @@ def score_s1_from_binhist(H, N, S, q, want32=True, want64=False, out32=None, out
     return o32, o64
 
 
+def score_s1_from_binhist_table(H, N, S, T64=None, T32=None, out32=None, out64=None):
+    """S1 scores of cached histograms from a caller-built table T[c, s], c = 0..N (device tensors [N + 1, S]; T32 -> float32
+    scores, T64 -> float64 scores).  scores.s1ScoreTable builds the pair on the host with the reference's arithmetic."""
+    R = H.shape[0]
+    for T, dt in ((T64, torch.float64), (T32, torch.float32)):
+        if T is not None and (T.dtype != dt or T.numel() != (N + 1) * S or not T.is_contiguous()):
+            raise ValueError("S1 table must be a contiguous [N + 1, S] tensor of its output's dtype")
+    o32, o64 = _outs(R, S, H.device, T32 is not None, T64 is not None, out32, out64)
+    _abi.call("epg_score_s1_from_binhist_table", _ptr(H), R, N, S, _ptr(T64), _ptr(T32), _ptr(o64), _ptr(o32), _stream())
+    return o32, o64
+
+
 def combine_score_s1(counts, H, N, S, q=None, want32=True, want64=False, out32=None, out64=None, ws=None, rezero=False):
     """STEP 2 + STEP 3 of an S1 job in one ABI call: q = normalise(counts) (the all-reduced int64[S] vector), then the
     scores of the cached histograms H.  Returns (q, out32, out64)."""

@@ -62,18 +62,22 @@ def readNull(nullFile, quiescenceFile):
     return (z["chrName"][0], z["nullDistances"]), (zq["chrName"][0], zq["quiescenceArr"])
 
 
-def fitOnSubSample(distanceArrNull, samplingSize):
-    """One gennorm fit on a random sub-sample and its negative log-likelihood on all the data (reference :245-270)."""
-    if len(distanceArrNull) <= samplingSize:
-        sampleData = distanceArrNull
+def fitOnSubSample(nullDistances, samplingSize, rng=None):
+    """One trial of the null fit (reference roiAndVisualPairwise.py:245-270): generalised-normal parameters fitted to at most
+    `samplingSize` null distances drawn without replacement, and the negative log-likelihood of ALL null distances under
+    them.  Plain arrays in their own dtype (the float32 the score stage stored: scipy's optimiser sees what the reference's
+    sees), (beta, loc, scale) and a float out; every trial draws from fresh OS entropy unless a
+    numpy Generator is passed (the reference reseeds the global generator per call, which forked workers need)."""
+    values = np.asarray(nullDistances)
+    if values.size > samplingSize:
+        rng = np.random.default_rng() if rng is None else rng
+        fitted_on = values[rng.choice(values.size, size=samplingSize, replace=False)]
     else:
-        np.random.seed()
-        sampleData = pd.Series(np.random.choice(distanceArrNull, size=samplingSize, replace=False))
+        fitted_on = values
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
-        params = st.gennorm.fit(sampleData)
-        nnlf = st.gennorm.nnlf(params, pd.Series(distanceArrNull))
-    return params, nnlf
+        params = st.gennorm.fit(fitted_on)
+        return params, st.gennorm.nnlf(params, values)
 
 
 _FIT_DATA = None                                     # the null distances of the pool's parent: workers inherit them through fork

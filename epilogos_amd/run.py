@@ -1,7 +1,9 @@
 """`epilogos` command line for the MI355X engine: the option surface of the reference's epilogos/run.py
 (click options :18-73, checkFlags :328-375, checkArguments :378-451, fileTag/paths :158-165) for STEP 1-3.
 The per-chromosome SLURM submission (run.py:454-585) is replaced by a bin-range partition across the GPUs of the
-node (one process per GPU under torch.distributed.run; a single process when WORLD_SIZE is unset).  Single mode
+node: `--gpus N` starts one process per GPU (a child `python -m torch.distributed.run`, started before this process
+touches a GPU) the way the reference's one command fans out over SLURM by itself; a process that finds itself under
+torch.distributed.run (WORLD_SIZE set) joins the group.  Console script: `epilogos` (pyproject.toml -> run:cli).  Single mode
 also runs STEP 4 (regionsOfInterest_*.txt, epilogos_amd/roiSingle.py); paired mode runs the STEP 4 of
 epilogos_amd/roiAndVisualPairwise.py (pairwiseMetrics, regionsOfInterest, significantLoci; no figures)."""
 import os
@@ -97,11 +99,13 @@ def checkArguments(mode, saliency, inputDirPath, inputDirPath2, outputDirPath, n
 @click.option("--score-mem", "scoreMem", type=int, default=40000, help="SLURM-only; ignored")
 @click.option("--roi-mem", "roiMem", type=int, default=-1, help="SLURM-only; ignored")
 @click.option("--null-seed", "nullSeed", type=int, default=None, help="Seed for the paired-mode null shuffles (default: random)")
+@click.option("--gpus", "gpus", type=int, default=1, show_default=True,
+              help="GPUs of this node to split the genome over (0 = all visible); replaces the SLURM fan-out of the reference")
 @click.option("--cache-dir", "cacheDir", type=str, default=None,
               help="Keep parsed input matrices (int8 + coordinates) here; later runs on the same files skip the text parse")
 def main(mode, commandLineBool, inputDirectory, inputDirectory1, inputDirectory2, outputDirectory, stateInfo, saliency,
          numProcesses, exitBool, diagnosticBool, numTrials, samplingSize, quiescentState, groupSize, version, partition,
-         pvalBool, roiWidth, fileTag, expFreqMem, expCombMem, scoreMem, roiMem, nullSeed, cacheDir):
+         pvalBool, roiWidth, fileTag, expFreqMem, expCombMem, scoreMem, roiMem, nullSeed, gpus, cacheDir):
     """Information-theoretic navigation of multi-tissue functional genomic annotations -- MI355X scoring engine."""
     if version:
         print("Version:", __version__)
@@ -140,8 +144,19 @@ def main(mode, commandLineBool, inputDirectory, inputDirectory1, inputDirectory2
                    else "{}_{}_s{}".format(inputDirPath.name, inputDirPath2.name, saliency))
     storedExpPath = outputDirPath / "exp_freq_{}.npy".format(fileTag)
 
+    # --gpus N from a plain start: fan out into one process per GPU (the reference submits its own SLURM jobs,
+    # run.py:190-279,454-505) -- as a CHILD process, before this one has imported torch or touched a GPU
+    if gpus < 0:
+        print("ERROR: Number of GPUs must be positive or zero (0 means use all visible GPUs)"); sys.exit()
+    if "WORLD_SIZE" not in os.environ and gpus != 1:
+        if gpus == 0:
+            gpus = _visible_gpus()
+        if gpus > 1:
+            sys.exit(_launch(gpus, sys.argv[1:] if _ARGV is None else _ARGV))
+
     # one process per GPU when launched under torch.distributed.run
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    under_launcher = "WORLD_SIZE" in os.environ and "RANK" in os.environ
     import torch
     device = None
     # EPILOGOS_DIST_BACKEND=gloo lets several ranks share one GPU (testing the multi-rank path on a 1-GPU box)
@@ -150,10 +165,14 @@ def main(mode, commandLineBool, inputDirectory, inputDirectory1, inputDirectory2
         local = int(os.environ.get("LOCAL_RANK", "0"))
         torch.cuda.set_device(local % torch.cuda.device_count() if dist_backend else local)
         device = torch.device("cuda", torch.cuda.current_device())
-    if world > 1:
+    if world > 1 or under_launcher:                      # also a group of one: the collective path is the same code
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend=dist_backend or ("nccl" if device is not None else "gloo"))
+        backend = dist_backend or ("nccl" if device is not None else "gloo")
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=device)
+        else:
+            dist.init_process_group(backend=backend)
     rank = int(os.environ.get("RANK", "0"))
     say = print if rank == 0 else (lambda *a, **k: None)
     if os.environ.get("EPILOGOS_TIMING") and rank == 0:
@@ -211,14 +230,63 @@ def main(mode, commandLineBool, inputDirectory, inputDirectory1, inputDirectory2
     if os.environ.get("EPILOGOS_TIMING") and rank == 0:
         import time
         print("    [timing] %-34s %7.2f s" % ("end of main (since process start)", time.time() - _T_START), flush=True)
-    if world > 1:
+    if world > 1 or under_launcher:
         import torch.distributed as dist
         dist.destroy_process_group()
 
 
-if __name__ == "__main__":
+_ARGV = None            # the argument list cli() was called with, when it is not sys.argv[1:]
+
+
+def _visible_gpus():
+    """GPUs this process could use, without initialising any (torch.cuda.device_count() does not, on ROCm)."""
+    import torch
+    return max(int(torch.cuda.device_count()), 1)
+
+
+def _strip_gpus(argv):
+    """The argument list without --gpus (the children learn their number from WORLD_SIZE)."""
+    out, skip = [], False
+    for a in argv:
+        if skip:
+            skip = False
+        elif a == "--gpus":
+            skip = True
+        elif not a.startswith("--gpus="):
+            out.append(a)
+    return out
+
+
+def _launch_command(gpus, argv, port):
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus),
+            "--master-addr", "127.0.0.1", "--master-port", str(port), "-m", "epilogos_amd.run"] + _strip_gpus(argv)
+
+
+def _launch(gpus, argv):
+    """One process per GPU under torch.distributed.run, as a child of this (GPU-free) process; its exit code is ours."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: what RCCL needs on this driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or gpus) // gpus)))
+    root = str(Path(__file__).resolve().parents[1])
+    env["PYTHONPATH"] = root + (os.pathsep + env["PYTHONPATH"] if env.get("PYTHONPATH") else "")
+    cmd = _launch_command(gpus, argv, port)
+    if os.environ.get("EPILOGOS_LAUNCH_DRYRUN"):
+        print(" ".join(cmd))
+        return 0
+    return subprocess.call(cmd, env=env)
+
+
+def cli(argv=None):
+    """Entry point of the `epilogos` console script and of `python -m epilogos_amd.run`."""
+    global _ARGV
+    _ARGV = argv
     try:
-        main(standalone_mode=False)
+        main(args=argv, standalone_mode=False)
     except click.exceptions.Abort:
         print("Aborted!", file=sys.stderr)
         _code = 1
@@ -242,3 +310,7 @@ if __name__ == "__main__":
     if os.environ.get("EPILOGOS_FAST_EXIT", "1") != "0":
         os._exit(_code)
     sys.exit(_code)
+
+
+if __name__ == "__main__":
+    cli()

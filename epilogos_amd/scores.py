@@ -13,6 +13,25 @@ from . import _io
 from . import backend as _backend
 from .helpers import countRows, fileStem, readStates, readTable, strToBool
 
+def klScoreND(obs, exp):
+    """obs * log2(obs / exp) with the reference's masked-array semantics (scores.py:539-550): the quotient is masked where
+    exp == 0 or it is not finite and filled with 0; the logarithm is masked where its argument is <= 0 and filled with 0."""
+    obs = np.asarray(obs)
+    quotient = np.ma.divide(obs, exp).filled(0)
+    return obs * np.ma.log2(quotient).filled(0)
+
+
+def s1ScoreTable(expFreqArr, numCols):
+    """The S1 score of every possible count: T[c, s] = klScoreND(c / numCols, expFreqArr[s]) for c = 0 .. numCols
+    (scores.py:317 with rowObsS1's `count / dataArr.shape[1]`, :327-344) -- float64 [numCols + 1, S] and its float32 store.
+    Evaluated with numpy on the host, i.e. by the very expression and the very log2 the reference runs per bin, so the
+    GPU score pass that gathers from it (epg_score_s1_from_binhist_table) returns the reference's float32 values bit for
+    bit; 834 x 18 entries for the EpiMap matrix."""
+    obs = (np.arange(numCols + 1, dtype=np.int64) / numCols)[:, None]            # int64 / int: numpy's float64 true division
+    t64 = np.ascontiguousarray(klScoreND(obs, np.asarray(expFreqArr, dtype=np.float32)[None, :]), dtype=np.float64)
+    return t64, t64.astype(np.float32)
+
+
 NULL_SEED = None   # paired nulls are unseeded in the reference (helpers.py:183); set an int for reproducible runs
 
 

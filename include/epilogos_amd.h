@@ -105,6 +105,13 @@ int epg_score_s1_from_binhist(const uint16_t* H, int64_t R, int32_t N, int32_t S
 int epg_combine_score_s1(int64_t* counts, int32_t rezero, const uint16_t* H, int64_t R, int32_t N, int32_t S, float* q,
                          double* out64, float* out32, void* ws, int64_t ws_bytes, void* stream);
 
+/* The S1 score pass from cached histograms with the lookup table T[c, s] = kl(c / N, q[s]), c = 0..N, built by the CALLER
+ * (device pointers to [N + 1, S] row-major arrays; T64 feeds out64, T32 feeds out32, either pair may be NULL).  The command
+ * line builds the table on the host with the reference's own numpy expression (scores.py:343 rowObsS1, :550 klScoreND), so
+ * the float32 scores -- and scores_*.txt.gz -- equal the reference's bit for bit. */
+int epg_score_s1_from_binhist_table(const uint16_t* H, int64_t R, int32_t N, int32_t S, const double* T64, const float* T32,
+                                    double* out64, float* out32, void* stream);
+
 /* S2: p[i,j] = (h_i*h_j - [i==j]*h_i) / perms, score[b, j] = sum_i kl(p[i,j], q[i,j]) in ascending i
  *     -- scores.py:347-452 s2Score/rowObsS2.  perms = N*(N-1) of the ORIGINAL group (scores.py:371,397-398). */
 int epg_score_s2(const int8_t* X, int64_t R, int32_t N, int64_t ldx, int32_t S, int64_t perms, const float* q,

@@ -173,3 +173,14 @@ def test_hip_on_full_chr1(g, tmp_path):
     assert len(mine) == len(theirs) and hashlib.sha256(b"\n".join(theirs)).digest() == g["text_sha256"].tobytes()
     same = sum(a == b for a, b in zip(mine, theirs))
     assert same >= 0.999 * len(theirs)
+    # the command line's route: the score table comes from the host (scores.s1ScoreTable, numpy's log2 like the reference):
+    # every float32 equals the reference's and the text IS the reference's file, all 1 246 253 lines
+    from epilogos_amd.scores import s1ScoreTable
+    t64, t32 = s1ScoreTable(g["exp"], N)
+    h32, h64 = engine.score_s1_from_binhist_table(H, N, S, T64=torch.from_numpy(t64).cuda(), T32=torch.from_numpy(t32).cuda())
+    assert np.array_equal(h64.cpu().numpy(), ref64) and np.array_equal(h32.cpu().numpy(), ref32)
+    assert np.array_equal(h32.cpu().numpy()[::997], g["rows_997"])
+    assert hashlib.sha256(_text(tmp_path, loc, h32.cpu().numpy())).digest() == g["text_sha256"].tobytes()
+    from epilogos_amd import backend
+    sc = backend.HipBackend().scores(x, S, 1, g["exp"])                                 # the stage driver's call (scores.py)
+    assert hashlib.sha256(_text(tmp_path, loc, sc)).digest() == g["text_sha256"].tobytes()

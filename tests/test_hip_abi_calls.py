@@ -133,6 +133,19 @@ def test_combine_score_s1_and_pair_hist_direct(abi):
     with pytest.raises(abi.EpilogosHipError) as e:
         abi.call("epg_combine_score_s1", _p(counts), 0, _p(HA), R, NA, S, _p(q), None, _p(o32), _p(ws), 16, st)
     assert e.value.code == -4
+    # --- the same score pass with a caller-built table (the command line's: numpy on the host): the oracle's bits
+    from epilogos_amd.scores import s1ScoreTable
+    qh = q_ref.cpu().numpy()
+    t64, t32 = s1ScoreTable(qh, NA)
+    T64, T32 = torch.from_numpy(t64).cuda(), torch.from_numpy(t32).cuda()
+    abi.call("epg_score_s1_from_binhist_table", _p(HA), R, NA, S, _p(T64), _p(T32), _p(o64), _p(o32), st)
+    ref = onp.score_s1(xa, qh, S)
+    assert np.array_equal(o64.cpu().numpy(), ref) and np.array_equal(o32.cpu().numpy(), ref.astype(np.float32))
+    o32.zero_()
+    abi.call("epg_score_s1_from_binhist_table", _p(HA), R, NA, S, None, _p(T32), None, _p(o32), st)
+    assert np.array_equal(o32.cpu().numpy(), ref.astype(np.float32))
+    with pytest.raises(abi.EpilogosHipError):
+        abi.call("epg_score_s1_from_binhist_table", _p(HA), R, NA, S, None, _p(T32), _p(o64), _p(o32), st)   # out64 without T64
     # --- S2 counts of [A|B] from the two groups' histograms
     c2 = torch.zeros(S * S, dtype=torch.int64, device="cuda")
     abi.call("epg_hist_s2_from_binhist_pair", _p(HA), _p(HB), R, S, _p(c2), st)

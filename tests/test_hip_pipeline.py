@@ -163,6 +163,152 @@ def test_two_ranks_on_one_gpu_match_one_rank(tmp_path, golden_real, sal):
     np.testing.assert_allclose(got, g["s%d_f32" % sal][:1300], atol=1.01e-5 if sal == 2 else 2e-5)
 
 
+def _cli_inputs(tmp_path, g, S_=S):
+    from tests.conftest import load_golden
+    ind = tmp_path / "in"
+    ind.mkdir()
+    write_tsv(ind / "matrix_chr1.txt.gz", g["x"][:1300], chrom="chr1", start0=int(g["start0"]))
+    write_tsv(ind / "matrix_chr2.txt.gz", g["x"][1300:], chrom="chr2")
+    meta = tmp_path / "metadata.tsv"
+    names = load_golden("roi.npz")["state_names"]
+    meta.write_text("zero_index\tone_index\tshort_name\n" + "".join("%d\t%d\t%s\n" % (i, i + 1, names[i]) for i in range(S_)))
+    return ind, meta
+
+
+def test_cli_one_rank_group_over_rccl(tmp_path, golden_real):
+    """The command line under torch.distributed.run with ONE rank and the default backend (nccl = RCCL): the process group,
+    _Dist.comm_device, the device-side all-reduce of the count tensor (S1: int64[18]; S3: int32[N, N, S, S]) and
+    destroy_process_group run on RCCL; the files equal those of a plain start."""
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parents[1]
+    ind, meta = _cli_inputs(tmp_path, golden_real)
+    for sal in (1, 3):
+        outs = {}
+        for how in ("plain", "rccl"):
+            out = tmp_path / ("out_%s_%d" % (how, sal))
+            port = str(free_port())
+            env = dict(os.environ, PYTHONPATH=str(root), MASTER_ADDR="127.0.0.1", MASTER_PORT=port, EPILOGOS_TIMING="1")
+            env.pop("EPILOGOS_DIST_BACKEND", None)
+            tail = ["-m", "epilogos_amd.run", "-l", "-i", str(ind), "-j", str(meta), "-o", str(out), "-s", str(sal), "-f", "t"]
+            cmd = [sys.executable] + (tail if how == "plain" else
+                                      ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                                       "--master-port", port] + tail)
+            res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=str(root))
+            assert res.returncode == 0, res.stdout + res.stderr
+            outs[how] = out
+        for name in ("scores_t_matrix_chr1.txt.gz", "scores_t_matrix_chr2.txt.gz"):
+            with gzip.open(outs["plain"] / name, "rb") as a, gzip.open(outs["rccl"] / name, "rb") as b:
+                assert a.read() == b.read()
+        assert (outs["plain"] / "regionsOfInterest_t.txt").read_bytes() == (outs["rccl"] / "regionsOfInterest_t.txt").read_bytes()
+
+
+def test_s3_count_tensor_of_833_biosamples_through_rccl(tmp_path):
+    """The 899 MB int32[833, 833, 18, 18] count tensor of BASELINE config 4 goes through dist.all_reduce on RCCL (a group of
+    one rank: what this box can hold) inside the command line's session, and the scores still equal the oracle's."""
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parents[1]
+    code = """
+import os, sys, numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+from epilogos_amd import backend, driver
+from tests.conftest import synth_states
+torch.cuda.set_device(0)
+dist.init_process_group(backend="nccl", device_id=torch.device("cuda", 0))
+d = driver._Dist()
+assert d.comm_device is not None and d.world == 1
+S, N, R = 18, 833, 600
+x = synth_states(R, N, seed=11)
+be = backend.HipBackend()
+sess = be.open_single(S, 3)
+pid = sess.add_device(be.to_device(x), N)
+assert sess.acc.numel() == N * N * S * S and sess.acc.dtype == torch.int32
+before = sess.acc.clone()
+sess.all_reduce(d)                                   # RCCL, 899 MB, in place
+assert torch.equal(before, sess.acc)
+q = sess.finish(R, N)
+sc = sess.scores(pid)
+from oracle import oracle_np as onp
+qo = onp.normalise(onp.expected_s3(x, S))
+assert np.array_equal(q, qo)
+ref = onp.score_s3_f64(x[:24], qo, S)
+np.testing.assert_allclose(sc[:24], ref, rtol=3e-6, atol=1e-6)
+print("S3_RCCL_OK", float(sc.sum()))
+dist.destroy_process_group()
+""" % str(root)
+    port = str(free_port())
+    env = dict(os.environ, PYTHONPATH=str(root), MASTER_ADDR="127.0.0.1", MASTER_PORT=port, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    res = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900, cwd=str(root))
+    assert res.returncode == 0 and "S3_RCCL_OK" in res.stdout, res.stdout + res.stderr
+
+
+def test_gpus_flag_starts_one_process_per_rank(tmp_path, golden_real):
+    """`--gpus 2` from a plain start: the command line itself starts torch.distributed.run as a child (before it touches a
+    GPU) and returns its exit code.  On a one-GPU box the two ranks share cuda:0 over gloo (EPILOGOS_DIST_BACKEND); the
+    text inputs take the parse-once route (each file on one rank, border pieces handed over) and the outputs equal the
+    single-process ones."""
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parents[1]
+    ind, meta = _cli_inputs(tmp_path, golden_real)
+    outs = {}
+    for gpus in (1, 2):
+        out = tmp_path / ("out%d" % gpus)
+        env = dict(os.environ, PYTHONPATH=str(root), EPILOGOS_DIST_BACKEND="gloo", EPILOGOS_IO_LOG=str(tmp_path / ("io%d.log" % gpus)))
+        for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+            env.pop(k, None)
+        cmd = [sys.executable, "-m", "epilogos_amd.run", "-l", "-i", str(ind), "-j", str(meta), "-o", str(out), "-s", "1", "-f", "t",
+               "--gpus", str(gpus)]
+        res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=str(root))
+        assert res.returncode == 0, res.stdout + res.stderr
+        assert ("GPUs = %d" % gpus) in res.stdout
+        outs[gpus] = out
+        reads = [l.split("\t") for l in (tmp_path / ("io%d.log" % gpus)).read_text().splitlines()]
+        assert sorted(r[2] for r in reads) == sorted(str(p) for p in ind.glob("*"))     # each file once, whatever the rank count
+    for name in ("scores_t_matrix_chr1.txt.gz", "scores_t_matrix_chr2.txt.gz"):
+        with gzip.open(outs[1] / name, "rb") as a, gzip.open(outs[2] / name, "rb") as b:
+            assert a.read() == b.read()
+    assert (outs[1] / "regionsOfInterest_t.txt").read_bytes() == (outs[2] / "regionsOfInterest_t.txt").read_bytes()
+    # a failing child's exit code is the parent's
+    bad = subprocess.run([sys.executable, "-m", "epilogos_amd.run", "-l", "-i", str(tmp_path / "nowhere"), "-j", str(meta), "-o",
+                          str(tmp_path / "o"), "--gpus", "2"], env=env, capture_output=True, text=True, timeout=600, cwd=str(root))
+    assert bad.returncode != 0
+
+
+def test_bench_one_rank_group_and_graph_replay(tmp_path):
+    """bench.py --pg --graph on one GPU: the step (K1, RCCL all-reduce of a one-rank group, combine, score) is captured in a
+    hipGraph and replayed; the line reports the all-reduce by itself and says how the step was launched."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parents[1]
+    env = dict(os.environ, PYTHONPATH=str(root))
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    base = [sys.executable, str(root / "bench.py"), "--steps", "5", "--warmup", "2", "--bins", "400000", "--no-cpu-baseline", "--configs", "none"]
+    lines = {}
+    for tag, extra in (("plain", []), ("pg", ["--pg"]), ("graph", ["--pg", "--graph"])):
+        res = subprocess.run(base + extra, env=env, capture_output=True, text=True, timeout=900, cwd=str(root))
+        assert res.returncode == 0, res.stdout + res.stderr
+        lines[tag] = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][-1])
+    assert lines["plain"]["allreduce_probe"] is None
+    for tag in ("pg", "graph"):
+        p = lines[tag]["allreduce_probe"]
+        assert p["world"] == 1 and p["backend"] == "nccl" and p["device_us_per_call_back_to_back"] > 0 and p["host_us_per_call"] > 0
+    assert lines["graph"]["config"]["step_launch"] == "hipGraph replay"
+    for l in lines.values():
+        assert l["kernels_ms"]["k_bin_hist"] > 0 and l["value"] > 0
+
+
 def test_driver_uploads_each_part_once_and_rejects_bad_states(tmp_path, golden_real, capsys, monkeypatch):
     """The genome driver on the HIP backend: every part crosses PCIe once (its histograms / matrix stay resident between
     the count pass and the score pass), outputs equal the stage drivers', and a state outside the model stops the run."""

@@ -456,3 +456,32 @@ def test_cli_rejects_states_outside_the_model(tmp_path, golden_real, fake_backen
         assert res.exit_code != 0
         assert isinstance(res.exception, ValueError) and "outside the 18-state model" in str(res.exception)
         assert not list(out.glob("scores_*"))
+
+
+def test_gpus_launcher_command(tmp_path, state_info, capsys, monkeypatch):
+    """`--gpus N` (reference: the SLURM fan-out of run.py:190-279): the child command is torch.distributed.run with one process
+    per GPU on 127.0.0.1 and this module as its program, --gpus itself stripped; a process already under the launcher
+    (WORLD_SIZE set) never launches again."""
+    from epilogos_amd import run
+    argv = ["-l", "-i", "in", "--gpus", "4", "-j", "meta.tsv", "-o", "out", "--gpus=4", "-s", "2"]
+    assert run._strip_gpus(argv) == ["-l", "-i", "in", "-j", "meta.tsv", "-o", "out", "-s", "2"]
+    cmd = run._launch_command(4, argv, 29511)
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node" in cmd and cmd[cmd.index("--nproc-per-node") + 1] == "4"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29511"
+    k = cmd.index("epilogos_amd.run")
+    assert cmd[k - 1] == "-m" and cmd[k + 1:] == run._strip_gpus(argv)
+    # dry run through the real option parser: the launch happens after the arguments have been checked, before torch is imported
+    ind = tmp_path / "in"
+    ind.mkdir()
+    (ind / "m_chr1.txt").write_text("chr1\t0\t200\t1\t2\n")
+    monkeypatch.setenv("EPILOGOS_LAUNCH_DRYRUN", "1")
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    args = ["-l", "-i", str(ind), "-j", str(state_info), "-o", str(tmp_path / "out"), "--gpus", "3"]
+    monkeypatch.setattr(run, "_ARGV", args)
+    with pytest.raises(SystemExit) as e:
+        run.main(args=args, standalone_mode=False)
+    assert e.value.code == 0
+    printed = capsys.readouterr().out
+    assert "torch.distributed.run" in printed and "--nproc-per-node 3" in printed and "--gpus" not in printed
+    with pytest.raises(SystemExit):
+        run.main(args=args[:-1] + ["-2"], standalone_mode=False)
