@@ -256,7 +256,13 @@ static int grid_for_tiles(long R) {
     const long nsuper = (R + 31) >> 5;
     long blocks = (nsuper + 3) / 4;
     const long cap = (long)num_cus() * g_blocks_per_cu;
-    if (blocks > cap) blocks = cap;
+    if (blocks > cap) {
+        // persistent grid: a wave walks super-tiles st, st + waves, ...; with the full grid the waves of a 1.9 M-bin shard (an
+        // eighth of the genome) get 14 or 15 of them -- the launch ends with 5 % of its time spent by the waves that got 15.
+        // Take the fewest iterations the full grid allows, then the fewest blocks that still cover the tiles in that many.
+        const long iters = (nsuper + cap * 4 - 1) / (cap * 4);
+        blocks = (nsuper + iters * 4 - 1) / (iters * 4);
+    }
     if (blocks < 1) blocks = 1;
     return (int)blocks;
 }

@@ -294,6 +294,11 @@ int64_t s3_lanes_ws_bytes(int64_t R, int N, int S);
 int score_s3_lanes(const int8_t* X8, int64_t R, int32_t N, int64_t ldx, int32_t S, const float* q, double* out64, float* out32, void* ws,
                    int64_t ws_bytes, hipStream_t st);
 
+bool s3_sparse_ok(int N, int S);
+int64_t s3_sparse_ws_bytes(int64_t R, int N, int S);
+int score_s3_sparse(const int8_t* X8, int64_t R, int32_t N, int64_t ldx, int32_t S, const float* q, double* out64, float* out32, void* ws,
+                    int64_t ws_bytes, hipStream_t st, bool forced);
+
 static int s3_nceil(int N) { return (N + S3S_ACH - 1) / S3S_ACH * S3S_ACH; }
 int64_t s3_table_bytes(int N, int S) { return align_up((int64_t)s3_nceil(N) * N * S * S * 4, 256); }
 int64_t s3_ws_bytes(int64_t R, int N, int S) {
@@ -301,6 +306,7 @@ int64_t s3_ws_bytes(int64_t R, int N, int S) {
     // precomputed fp4 one-hot operand for the default kernel)
     int64_t score = s3_table_bytes(N, S) + s3_mfma_ws_bytes(R, N) + align_up(R * S * 8, 256);
     if (s3_lanes_ok(N, S) && s3_lanes_ws_bytes(R, N, S) > score) score = s3_lanes_ws_bytes(R, N, S);
+    if (s3_sparse_ok(N, S) && s3_sparse_ws_bytes(R, N, S) > score) score = s3_sparse_ws_bytes(R, N, S);
     const int64_t expected = s3_gemm_ws_bytes(R, N, S);
     return score > expected ? score : expected;
 }
@@ -342,8 +348,18 @@ int score_s3_impl(const int8_t* X8, int64_t R, int32_t N, int64_t ldx, int32_t S
     if (!X8 || !q || !ws) return fail(EPG_ERR_INVALID_ARG, "score_s3: NULL argument");
     // default: the biosample-lane kernel (epg_s3_lanes.hip, S <= 21) when the workspace holds its table;
     // EPG_S3_SCORE=bins selects k_s3_score below (A/B measurements; the path for S > 21)
-    const char* env = getenv("EPG_S3_SCORE");      // read per call: the tests run both kernels in one process
+    const char* env = getenv("EPG_S3_SCORE");      // read per call: the tests run the kernels in one process
     const bool force_bins = env && env[0] == 'b';
+    // EPG_S3_SCORE=sparse: the modal-state kernel (epg_s3_sparse.hip) -- the same integers as the dense kernel from ~1/3 of
+    // its gathers, and SLOWER on this chip (56 against 39 ms per 500 K bins at N = 833: a SIMD pays ~3.7 cycles per wave
+    // instruction of any kind, and steering a gather to a data-dependent accumulator register costs more instructions than
+    // the gathers it saves; epg_s3_sparse.hip, tools/ubench/gpr_idx.hip).  Kept selectable; not the default.
+    // It returns 1 for a matrix it cannot take (bytes that are not states): the dense kernel runs then.
+    const bool force_sparse = env && env[0] == 's';
+    if (force_sparse && s3_sparse_ok(N, S) && ws_bytes >= s3_sparse_ws_bytes(R, N, S) - (out64 ? align_up(R * S * 8, 256) : 0)) {
+        const int rc = score_s3_sparse(X8, R, N, ldx, S, q, out64, out32, ws, ws_bytes, st, true);
+        if (rc != 1) return rc;
+    }
     if (!force_bins && s3_lanes_ok(N, S) && ws_bytes >= s3_lanes_ws_bytes(R, N, S) - (out64 ? align_up(R * S * 8, 256) : 0))
         return score_s3_lanes(X8, R, N, ldx, S, q, out64, out32, ws, ws_bytes, st);
     const int64_t tb = s3_table_bytes(N, S), xtb = s3_mfma_ws_bytes(R, N);

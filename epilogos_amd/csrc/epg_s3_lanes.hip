@@ -14,7 +14,7 @@
 //    number SI >= S + 1 of dwords per (x_b, b) the bank of lane l is (SI * l + x_a) mod 32: a bijection of l, whatever the
 //    states are.  Every gather is conflict free by construction (PMC: SQ_LDS_BANK_CONFLICT is 2 % of
 //    SQ_LDS_IDX_ACTIVE, the epilogue's same-address adds; 45 % in k_s3_score).
-//  * the table is stored as 32-bit FIXED POINT in units of max|T| * N / 2^31: the N terms of one (bin, b) add up in a plain
+//  * the table is stored as 32-bit FIXED POINT in units of max|T| * N / 2^30 (2^31 in round 2; see k_s3_tq_unit): the N terms of one (bin, b) add up in a plain
 //    int32 without overflow, integer adds are exact and commute (bit-identical scores for any launch geometry, like the
 //    64-bit cells they are added to), and the only error is the rounding of a table entry, <= unit / 2 ~ 7e-12 absolute at
 //    N = 833 against terms of 1e-6 .. 3e-5, where the float32 partial sums of k_s3_score gave 1e-7 of a score.  (16-bit
@@ -82,10 +82,12 @@ __global__ __launch_bounds__(256) void k_s3_tq_max(const float* __restrict__ q, 
     if ((threadIdx.x & 63) == 0 && m) atomicMax(maxbits, m);
 }
 
-// scal[0] = unit (score per fixed-point step), scal[1] = 1 / unit
+// scal[0] = unit (score per fixed-point step), scal[1] = 1 / unit.  max|T| N / 2^30 -- the unit of the modal-state kernel
+// (epg_s3_sparse.hip), whose table holds DIFFERENCES of two entries: with one unit the two kernels add up the same
+// integers and return the same bits
 __global__ void k_s3_tq_unit(const u32* __restrict__ maxbits, int N, double* __restrict__ scal) {
     const double mx = (double)__uint_as_float(*maxbits);
-    const double unit = mx * (double)N / 2147483648.0;
+    const double unit = mx * (double)N / 1073741824.0;
     scal[0] = unit;
     scal[1] = unit > 0.0 ? 1.0 / unit : 0.0;
 }

@@ -77,3 +77,39 @@ def test_s3_expected_kernels_random_shapes(monkeypatch):
         assert torch.equal(red2, 2 * full), (N, S, R, dirty)
         if not dirty and N * N * S * S * R < 4e8:                  # oracle-sized and clean: the reference's own counts
             assert np.array_equal(full.cpu().numpy().reshape(N, N, S, S), onp.expected_s3(x, S)), (N, S, R)
+
+
+def test_s3_modal_state_kernel_returns_the_dense_kernels_bits(monkeypatch):
+    """EPG_S3_SCORE=sparse (epg_s3_sparse.hip: per-biosample base table + gathers only for biosamples off the modal state,
+    accumulators addressed through the VGPR index mode) against the dense biosample-lane kernel: the same fixed-point unit,
+    so float64 and float32 scores are IDENTICAL -- chunks of 32 biosamples with ragged ends, slices of 1440 bins with ragged
+    ends, 2 to 19 states (every slab size of its three-buffer ring, incl. the third buffer's offset bias), a q with zeros, and
+    a matrix with bytes that are not states (handed to the dense kernel).  scores.py:455-506."""
+    from epilogos_amd import engine
+    engine.require_gpu()
+    rng = np.random.default_rng(3)
+    shapes = [(18, 33, 200), (18, 64, 1440), (18, 65, 1441), (18, 129, 4000), (15, 40, 300), (19, 97, 2500), (2, 5, 77), (7, 31, 129),
+              (18, 200, 2881), (11, 32, 128), (16, 70, 1500), (17, 50, 500), (3, 9, 50), (10, 100, 3000), (13, 35, 97)]
+    for n, (S, N, R) in enumerate(shapes):
+        p = rng.dirichlet(np.full(S, 0.3))
+        p[int(rng.integers(0, S))] += 2.0
+        p /= p.sum()
+        x = rng.choice(S, size=(R, N), p=p).astype(np.int8)
+        if n % 4 == 3:
+            x[rng.integers(0, R), rng.integers(0, N)] = -1
+            x[rng.integers(0, R), rng.integers(0, N)] = 31
+        q = rng.random((N, N, S, S)).astype(np.float32) ** 3
+        q[rng.random(q.shape) < 0.05] = 0.0
+        q /= q.sum()
+        X = engine.states_to_device(x)
+        qd = torch.from_numpy(q.reshape(-1)).cuda()
+        monkeypatch.setenv("EPG_S3_SCORE", "lanes")
+        d32, d64 = engine.score_s3(X, N, S, qd, want32=True, want64=True)
+        monkeypatch.setenv("EPG_S3_SCORE", "sparse")
+        s32, s64 = engine.score_s3(X, N, S, qd, want32=True, want64=True)
+        s32b, _ = engine.score_s3(X, N, S, qd, want32=True, want64=False)
+        monkeypatch.delenv("EPG_S3_SCORE")
+        assert torch.equal(d64, s64) and torch.equal(d32, s32) and torch.equal(s32, s32b), (S, N, R)
+        assert bool(torch.isfinite(s64).all())
+        if R * N * N < 3e6 and n % 4 != 3:
+            np.testing.assert_allclose(s64.cpu().numpy(), onp.score_s3_f64(x, q, S), rtol=2e-6, atol=1e-9, err_msg=str((S, N, R)))
