@@ -32,17 +32,46 @@ if stats.exists():
     lines.append("")
 trace = src / "stats" / "p_kernel_trace.csv"
 if trace.exists() and bench:
-    # engine.place_hist times the same kernel on candidate blocks before the steps (slow candidates included), so the table
-    # above mixes those probe launches in; the bench's own launches are the LAST warmup + steps dispatches with the H store
-    k1 = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) for r in csv.DictReader(open(trace))
-          if "k_bin_hist" in r["Kernel_Name"]]
-    k1.sort()
-    steps = 20
-    if len(k1) >= steps:
-        d = [x[1] for x in k1[-steps:]]
-        lines += ["k_bin_hist over the LAST %d dispatches of the trace (the timed steps; the rows above include the %d launches of "
-                  "the placement probe and the warm-up): avg %.0f ns, min %d, max %d -- bench line (HIP events, un-profiled run): %.0f ns"
-                  % (steps, len(k1) - steps, sum(d) / len(d), min(d), max(d), bench["kernels_ms"]["k_bin_hist"] * 1e6), ""]
+    # bench.py launches k_bin_hist for its own steps FIRST (one untimed job, the warm-up, the timed steps); the placement
+    # experiment and the S2 / paired configs launch it again afterwards, so the timed steps are dispatches 1 + warmup ..
+    # 1 + warmup + steps of the kernel's full-width instantiation
+    tr = list(csv.DictReader(open(trace)))
+    k1 = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) for r in tr
+                if "k_bin_hist<18, 7" in r["Kernel_Name"])
+    steps, warm = bench["steps"], bench["warmup"]
+    if len(k1) >= 1 + warm + steps:
+        d = [x[1] for x in k1[1 + warm:1 + warm + steps]]
+        lines += ["k_bin_hist over the %d timed dispatches of the trace (dispatches %d..%d of the kernel; later ones belong to the "
+                  "placement experiment and the S2 config): avg %.0f ns, min %d, max %d -- bench line (HIP events, un-profiled run): %.0f ns"
+                  % (steps, 1 + warm, warm + steps, sum(d) / len(d), min(d), max(d), bench["kernels_ms"]["k_bin_hist"] * 1e6), ""]
+    # the configs of the same run: kernel time of every phase from the trace next to the bench line's event times
+    cfg = bench.get("configs") or {}
+    def tsum(pred, last):
+        rows = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) for r in tr if pred(r["Kernel_Name"]))
+        return rows[-last:] if last else rows
+    if "s3" in cfg and "phases_ms" in cfg["s3"]:
+        reps = cfg["s3"]["reps"]
+        sy = [d for _, d in tsum(lambda n: "k_s3_syrk_fp4" in n, 0) if d > 1e6][-reps:]
+        sc = [d for _, d in tsum(lambda n: "k_s3_score_bl" in n, reps)]
+        if sy and sc:
+            lines += ["config s3 (%d bins): `k_s3_syrk_fp4` %.2f ms per launch (one per 1 M-bin chunk of the operand) and `k_s3_score_bl` %.2f ms per call in the trace (last %d); bench "
+                      "line phases (events, incl. operand build / reconstruction resp. table build / transpose): expected %.2f ms, scores %.2f ms"
+                      % (cfg["s3"]["bins_total"], sum(sy) / len(sy) / 1e6, sum(sc) / len(sc) / 1e6, reps, cfg["s3"]["phases_ms"]["expected"],
+                         cfg["s3"]["phases_ms"]["scores"]), ""]
+    if "s2" in cfg and "kernels_ms" in cfg["s2"]:
+        a = [d for _, d in tsum(lambda n: "k_s2_hist_wave" in n, 3)]
+        b = [d for _, d in tsum(lambda n: "k_score_s2_bin" in n, 3)]
+        if a and b:
+            lines += ["config s2: `k_s2_hist_wave` %.4f ms, `k_score_s2_bin` %.4f ms in the trace (last 3 calls); bench line kernels_ms: %s"
+                      % (sum(a) / len(a) / 1e6, sum(b) / len(b) / 1e6, json.dumps(cfg["s2"]["kernels_ms"])), ""]
+    if "paired" in cfg and "phases_ms" in cfg["paired"]:
+        names = ("k_null_hist_h", "k_score_s1_from_hist", "k_pair_finish", "k_pair_metrics", "k_quiescent_h")
+        parts = []
+        for nm in names:
+            v = [d for _, d in tsum(lambda n, nm=nm: nm in n, 0)]
+            if v:
+                parts.append("`%s` %d calls, avg %.3f ms" % (nm, len(v), sum(v) / len(v) / 1e6))
+        lines += ["config paired: " + "; ".join(parts) + " -- bench line phases: %s" % json.dumps(cfg["paired"]["phases_ms"]), ""]
 stats_all = src / "stats_all" / "p_kernel_stats.csv"
 if stats_all.exists():
     rows = list(csv.DictReader(open(stats_all)))
@@ -72,10 +101,10 @@ for cname in ("fetch", "write"):
     for r in rows_c:
         agg[(r["Kernel_Name"].split("(")[0], r["Counter_Name"])].append(float(r["Counter_Value"]))
     for key in list(agg):
-        # k_bin_hist: the placement probe launches it too (some of them without the histogram store); the bench's own
-        # launches are the last warmup + steps = 4 dispatches of a PMC pass (`--steps 3 --warmup 1`)
-        if "k_bin_hist" in key[0]:
-            agg[key] = agg[key][-4:]
+        # k_bin_hist: the placement experiment and the S2 config launch it too (some without the histogram store); the bench's
+        # own warm-up + steps are dispatches 1..4 of a PMC pass (`--steps 3 --warmup 1`)
+        if "k_bin_hist<18, 7" in key[0]:
+            agg[key] = agg[key][1:5]
     lines += ["## PMC pass `%s`" % cname, "", "| kernel | counter | mean per launch | bytes (KB x1024%s) |" % (", x2 gfx950 read correction" if cname == "fetch" else ""), "|---|---|---|---|"]
     for (k, c), v in sorted(agg.items()):
         m = sum(v) / len(v)
@@ -85,7 +114,7 @@ for cname in ("fetch", "write"):
     lines.append("")
 if bench and traffic:
     R, N = bench["config"]["bins_per_gpu"], bench["config"]["biosamples"]
-    k = [x for x in traffic if "k_bin_hist" in x]
+    k = [x for x in traffic if "k_bin_hist<18, 7" in x] or [x for x in traffic if "k_bin_hist" in x]
     if k:
         t = traffic[k[0]]
         total = t.get("FETCH_SIZE", 0) + t.get("WRITE_SIZE", 0)
