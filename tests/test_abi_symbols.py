@@ -81,3 +81,16 @@ def test_io_library_exports_its_header():
     assert len(names) >= 9
     for n in names:
         assert hasattr(lib, n), n
+
+
+def test_console_script_of_pyproject_resolves():
+    """pyproject.toml declares the reference's `epilogos` command (setup.py:28-33) as epilogos_amd.run:cli."""
+    import importlib
+    from pathlib import Path
+
+    import tomli
+    meta = tomli.loads((Path(__file__).resolve().parents[1] / "pyproject.toml").read_text())
+    target = meta["project"]["scripts"]["epilogos"]
+    mod, fn = target.split(":")
+    assert callable(getattr(importlib.import_module(mod), fn))
+    assert meta["tool"]["setuptools"]["dynamic"]["version"]["attr"] == "epilogos_amd.__version__"
