@@ -282,6 +282,49 @@ def test_gpus_flag_starts_one_process_per_rank(tmp_path, golden_real):
     assert bad.returncode != 0
 
 
+@pytest.mark.parametrize("sal", [1, 2])
+def test_paired_two_ranks_on_one_gpu_match_one_rank(tmp_path, golden_pair, sal):
+    """Paired mode over two ranks (gloo transport, both on cuda:0), text inputs: each of the four files is parsed by one rank,
+    the border pieces' histograms change hands (backend._HipPairedSession.export_rows / import_rows), the null shuffle is keyed
+    by the global bin index -- pairwiseDelta, the STEP 4 files and exp_freq equal the single-rank run's."""
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+    from tests.conftest import load_golden
+    root = Path(__file__).resolve().parents[1]
+    g = golden_pair
+    a, b = tmp_path / "male", tmp_path / "female"
+    a.mkdir(); b.mkdir()
+    for name, lo, hi in (("matrix_chr1.txt.gz", 0, 1300), ("matrix_chr2.txt.gz", 1300, 2048)):
+        write_tsv(a / name, g["xa"][lo:hi], chrom=name[7:-7])
+        write_tsv(b / name, g["xb"][lo:hi], chrom=name[7:-7])
+    meta = tmp_path / "metadata.tsv"
+    names = load_golden("roi.npz")["state_names"]
+    meta.write_text("zero_index\tone_index\tshort_name\n" + "".join("%d\t%d\t%s\n" % (i, i + 1, names[i]) for i in range(S)))
+    outs = {}
+    for gpus in (1, 2):
+        out = tmp_path / ("out%d" % gpus)
+        env = dict(os.environ, PYTHONPATH=str(root), EPILOGOS_DIST_BACKEND="gloo", EPILOGOS_IO_LOG=str(tmp_path / ("io%d.log" % gpus)))
+        for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+            env.pop(k, None)
+        cmd = [sys.executable, "-m", "epilogos_amd.run", "-l", "-m", "paired", "-a", str(a), "-b", str(b), "-j", str(meta), "-o", str(out),
+               "-s", str(sal), "-f", "t", "--null-seed", "77", "-w", "10", "--gpus", str(gpus)]
+        res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=str(root))
+        assert res.returncode == 0, res.stdout + res.stderr
+        outs[gpus] = out
+        reads = sorted(l.split("\t")[2] for l in (tmp_path / ("io%d.log" % gpus)).read_text().splitlines())
+        assert reads == sorted(str(p) for d in (a, b) for p in d.glob("*"))                 # four files, each parsed once
+    assert np.array_equal(np.load(outs[1] / "exp_freq_t.npy"), np.load(outs[2] / "exp_freq_t.npy")) if (outs[1] / "exp_freq_t.npy").exists() else True
+    for name in ("pairwiseDelta_t_matrix_chr1.txt.gz", "pairwiseDelta_t_matrix_chr2.txt.gz", "pairwiseMetrics_t.txt.gz"):
+        with gzip.open(outs[1] / name, "rb") as fa, gzip.open(outs[2] / name, "rb") as fb:
+            assert fa.read() == fb.read(), name
+    assert (outs[1] / "regionsOfInterest_t.txt").read_bytes() == (outs[2] / "regionsOfInterest_t.txt").read_bytes()
+    if sal == 1:
+        with gzip.open(outs[2] / "pairwiseDelta_t_matrix_chr1.txt.gz", "rb") as fh:
+            np.testing.assert_allclose(_text_to_array(fh.read()), g["s1_delta"][:1300], atol=1.01e-5)
+
+
 def test_bench_one_rank_group_and_graph_replay(tmp_path):
     """bench.py --pg --graph on one GPU: the step (K1, RCCL all-reduce of a one-rank group, combine, score) is captured in a
     hipGraph and replayed; the line reports the all-reduce by itself and says how the step was launched."""
