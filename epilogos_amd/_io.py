@@ -28,6 +28,8 @@ def load():
     lib.epgio_count_rows.argtypes = [C.c_char_p]
     lib.epgio_open_table.restype = p
     lib.epgio_open_table.argtypes = [C.c_char_p, i64, i64, i32]
+    lib.epgio_open_table_ex.restype = p
+    lib.epgio_open_table_ex.argtypes = [C.c_char_p, i64, i64, i32, i32]
     lib.epgio_table_rows.restype = i64
     lib.epgio_table_rows.argtypes = [p]
     lib.epgio_table_cols.restype = i32
@@ -62,6 +64,20 @@ def load():
 
 def _err():
     return load().epgio_last_error().decode(errors="replace")
+
+
+_state_limit = 31
+
+
+def set_state_limit(numStates):
+    """The state model the process works with.  Up to 31 states the parser stores file values outside 1..31 as "not a state"
+    (the fast kernels decode five bits of a byte); a larger model keeps 1..127 and runs the wide kernels (epg_wide.hip)."""
+    global _state_limit
+    _state_limit = 127 if int(numStates) > 31 else 31
+
+
+def state_limit():
+    return _state_limit
 
 
 def _log_io(op, path, lo=0, hi=-1):
@@ -140,7 +156,7 @@ def read_table(path, rows=None, threads=0, ldx=None, alloc=None, with_range=Fals
     lib = load()
     lo, hi = (0, -1) if rows is None else rows
     _log_io("read", path, lo, hi)
-    h = lib.epgio_open_table(str(path).encode(), lo, hi, threads)
+    h = lib.epgio_open_table_ex(str(path).encode(), lo, hi, threads, _state_limit)
     if not h:
         raise EpilogosIOError(_err())
     try:

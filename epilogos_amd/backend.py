@@ -126,7 +126,12 @@ class HipBackend:
         eng = self.engine
         NA, NB = xa.shape[1], xb.shape[1]
         ga, gb = (NA, NB) if groupSize == -1 else (groupSize, groupSize)
-        HA, HB = eng.null_hist(self.to_device(xa), NA, self.to_device(xb), NB, S, ga, gb, seed, row0)
+        if S > 31:                                       # the wide models: the matrix-scanning kernel decodes five bits
+            hA, _ = eng.bin_hist(self.to_device(xa), NA, S, want_counts=False)
+            hB, _ = eng.bin_hist(self.to_device(xb), NB, S, want_counts=False)
+            HA, HB = eng.null_hist_from_binhist(hA, hB, NA + NB, S, ga, gb, seed, row0)
+        else:
+            HA, HB = eng.null_hist(self.to_device(xa), NA, self.to_device(xb), NB, S, ga, gb, seed, row0)
         qd = self.torch.from_numpy(np.ascontiguousarray(q, dtype=np.float32).reshape(-1)).to(self.device)
         if saliency == 1:
             na, nb = self._score_s1_host_table(HA, ga, S, q), self._score_s1_host_table(HB, gb, S, q)

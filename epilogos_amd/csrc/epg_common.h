@@ -32,6 +32,15 @@ int num_cus();
 
 static inline int64_t align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
 
+// Rows a wave stages per turn in the kernels that keep whole rows of a wave's tile in LDS (four waves per block, 64 KB of LDS
+// without asking): 64 for the state models the kernels were built for, 32 / 16 / 8 when `row_bytes` (all staged arrays of a
+// row together) grows with a wide model.  A multiple of 8, so that a tile of uint16 or float32 rows starts 16-byte aligned.
+static inline int tile_rows(int64_t row_bytes) {
+    int tr = 64;
+    while (tr > 8 && 4 * tr * row_bytes > 65536) tr >>= 1;
+    return tr;
+}
+
 // (a & m) | (b & ~m): one v_bfi_b32
 __device__ __forceinline__ u32 bfi(u32 m, u32 a, u32 b) { return (a & m) | (b & ~m); }
 

@@ -247,9 +247,9 @@ bool slurp(const char* path, Text& t, int32_t threads = 0) {
 // byte) makes it return -1 and the scalar code parses -- and judges -- the row.  Loads are masked to the row (through its
 // '\n'), so nothing behind it is touched.  q = the tab in front of the first value, nl = the row's '\n'.
 __attribute__((target("avx512f,avx512bw,avx512vbmi2,bmi2,popcnt")))
-int parse_row_avx512(const char* q, const char* nl, int8_t* out, int cols, __m512i& vmin, __m512i& vmax) {
+int parse_row_avx512(const char* q, const char* nl, int8_t* out, int cols, __m512i& vmin, __m512i& vmax, int max0) {
     const __m512i c_tab = _mm512_set1_epi8('\t'), c_nl = _mm512_set1_epi8('\n'), c_cr = _mm512_set1_epi8('\r');
-    const __m512i c_0 = _mm512_set1_epi8('0'), c_9 = _mm512_set1_epi8(9), c_30 = _mm512_set1_epi8(30), c_1 = _mm512_set1_epi8(1);
+    const __m512i c_0 = _mm512_set1_epi8('0'), c_9 = _mm512_set1_epi8(9), c_30 = _mm512_set1_epi8((char)max0), c_1 = _mm512_set1_epi8(1);
     const __m512i c_ff = _mm512_set1_epi8((char)0xff);
     const __m512i lut10 = _mm512_broadcast_i32x4(_mm_setr_epi8(0, 10, 20, 30, 40, 50, 60, 70, 80, 90, 0, 0, 0, 0, 0, 0));
     int c = 0;
@@ -278,7 +278,7 @@ int parse_row_avx512(const char* q, const char* nl, int8_t* out, int cols, __m51
         vmin = _mm512_mask_min_epu8(vmin, tab, vmin, v);
         vmax = _mm512_mask_max_epu8(vmax, tab, vmax, v);
         __m512i o = _mm512_sub_epi8(v, c_1);                        // 0-based; 0 wraps to 255
-        o = _mm512_mask_mov_epi8(o, _mm512_cmpgt_epu8_mask(o, c_30), c_ff);   // outside 0..30: "not a state" (-1)
+        o = _mm512_mask_mov_epi8(o, _mm512_cmpgt_epu8_mask(o, c_30), c_ff);   // outside 0..max0: "not a state" (-1)
         const int cnt = (int)_mm_popcnt_u64(tab);
         if (c + cnt > cols) return -1;
         _mm512_mask_storeu_epi8(out + c, _bzhi_u64(~0ull, (unsigned)cnt), _mm512_maskz_compress_epi8(tab, o));
@@ -361,6 +361,11 @@ static double now_s() {
 }
 
 epgio_table* epgio_open_table(const char* path, int64_t row_lo, int64_t row_hi, int32_t threads) {
+    return epgio_open_table_ex(path, row_lo, row_hi, threads, 31);
+}
+
+epgio_table* epgio_open_table_ex(const char* path, int64_t row_lo, int64_t row_hi, int32_t threads, int32_t max_state) {
+    const int max0 = (max_state > 31 ? 127 : 31) - 1;        // largest 0-based state kept: two classes, like the kernels
     static const bool timing = getenv("EPGIO_TIMING") != nullptr;
     double t0 = now_s();
     auto lap = [&](const char* what) {
@@ -475,7 +480,7 @@ epgio_table* epgio_open_table(const char* path, int64_t row_lo, int64_t row_hi, 
                     int c = 0;
 #if defined(__x86_64__)
                     if (simd) {
-                        if (parse_row_avx512(q, nl, out, cols, vmin512[i].v, vmax512[i].v) == cols) return;
+                        if (parse_row_avx512(q, nl, out, cols, vmin512[i].v, vmax512[i].v, max0) == cols) return;
                         // anything unusual: the scalar code below parses the row again from its first value
                     }
 #endif
@@ -498,7 +503,7 @@ epgio_table* epgio_open_table(const char* path, int64_t row_lo, int64_t row_hi, 
                             lo = v < lo ? v : lo;
                             hi = v > hi ? v : hi;
                             --v;                                                        // file states are 1-based (helpers.py:155)
-                            out[c++] = (int8_t)(((unsigned)v > 30u) ? -1 : v);            // outside 0..30: "not a state" (see below)
+                            out[c++] = (int8_t)(((unsigned)v > (unsigned)max0) ? -1 : v);  // outside 0..max0: "not a state" (see below)
                         }
                         vlo[i] = lo; vhi[i] = hi;
                         if (c == cols && q < nl && *q == '\r') ++q;                    // CRLF line ends
@@ -518,10 +523,10 @@ epgio_table* epgio_open_table(const char* path, int64_t row_lo, int64_t row_hi, 
                         if (v < vlo[i]) vlo[i] = v;
                         if (v > vhi[i]) vhi[i] = v;
                         v -= 1;                             // file states are 1-based (helpers.py:155)
-                        // the kernels decode five bits and treat 31 as "not a state": anything outside 0..30 is stored as
-                        // -1 so that it cannot alias a state; the caller sees it in epgio_table_state_range and in the
+                        // the kernels of models up to 31 states decode five bits and treat 31 as "not a state": anything
+                        // outside 0..max0 (30, or 126 for the wide models) is stored as -1 so that it cannot alias a state; the caller sees it in epgio_table_state_range and in the
                         // count check (sum of counts != rows * columns)
-                        out[c++] = (int8_t)((v < 0 || v > 30) ? -1 : v);
+                        out[c++] = (int8_t)((v < 0 || v > max0) ? -1 : v);
                     }
                     if (c != cols || q != nl) { err[i] = 1; if (bad_row[i] < 0) bad_row[i] = r; }
                 });

@@ -139,16 +139,16 @@ __device__ __forceinline__ void nh_stage_in(char* lds, const char* src, int nbyt
 }
 
 __global__ __launch_bounds__(256) void k_null_hist_h(const u16* __restrict__ HA, const u16* __restrict__ HB, long R, int S, int n_cols,
-                                                      int ga, int gb, u64 seed, long row0, u16* __restrict__ OA, u16* __restrict__ OB) {
+                                                      int ga, int gb, u64 seed, long row0, u16* __restrict__ OA, u16* __restrict__ OB, int TR) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int rowb = 2 * S;
-    char* sa = smem + (size_t)wave * 2 * 64 * rowb;               // the wave's 64 rows of hA, later of the A group's counts
-    char* sb = sa + 64 * rowb;
-    const long ntiles = (R + 63) >> 6;
+    char* sa = smem + (size_t)wave * 2 * TR * rowb;               // the wave's TR (64) rows of hA, later of the A group's counts
+    char* sb = sa + TR * rowb;
+    const long ntiles = (R + TR - 1) / TR;
     for (long tile = (long)blockIdx.x * 4 + wave; tile < ntiles; tile += (long)gridDim.x * 4) {
-        const long r0 = tile * 64;
-        const int rows = (int)(R - r0 < 64 ? R - r0 : 64);
+        const long r0 = tile * TR;
+        const int rows = (int)(R - r0 < TR ? R - r0 : TR);
         nh_stage_in(sa, reinterpret_cast<const char*>(HA + r0 * S), rows * rowb, lane);
         nh_stage_in(sb, reinterpret_cast<const char*>(HB + r0 * S), rows * rowb, lane);
         __builtin_amdgcn_wave_barrier();
@@ -240,18 +240,19 @@ __global__ __launch_bounds__(256) void k_null_hist_h(const u16* __restrict__ HA,
 
 int null_hist_from_binhist_impl(const uint16_t* HA, const uint16_t* HB, int64_t R, int32_t S, int32_t n_cols, int32_t ga, int32_t gb,
                                 uint64_t seed, int64_t row0, uint16_t* OA, uint16_t* OB, hipStream_t st) {
-    if (R < 0 || S < 1 || S > 31 || n_cols < 1 || n_cols > 65535) return fail(EPG_ERR_INVALID_ARG, "null_hist_from_binhist: bad shape");
+    if (R < 0 || S < 1 || S > 127 || n_cols < 1 || n_cols > 65535) return fail(EPG_ERR_INVALID_ARG, "null_hist_from_binhist: bad shape");
     if (ga < 0 || gb < 0 || (long)ga + gb > n_cols)
         return fail(EPG_ERR_INVALID_ARG, "null_hist_from_binhist: group sizes %d + %d exceed the %d columns", ga, gb, n_cols);
     if (R == 0) return EPG_OK;
     if (!HA || !HB || !OA || !OB) return fail(EPG_ERR_INVALID_ARG, "null_hist_from_binhist: NULL argument");
     if ((reinterpret_cast<uintptr_t>(HA) | reinterpret_cast<uintptr_t>(HB) | reinterpret_cast<uintptr_t>(OA) | reinterpret_cast<uintptr_t>(OB)) & 15)
         return fail(EPG_ERR_INVALID_ARG, "null_hist_from_binhist: histogram arrays must be 16-byte aligned");
-    long blocks = ((R + 63) / 64 + 3) / 4;
+    const int TR = tile_rows(2 * 2 * S);
+    long blocks = ((R + TR - 1) / TR + 3) / 4;
     if (blocks > num_cus() * 8L) blocks = num_cus() * 8L;
-    const size_t shmem = (size_t)4 * 2 * 64 * 2 * S;
+    const size_t shmem = (size_t)4 * 2 * TR * 2 * S;
     hipLaunchKernelGGL(k_null_hist_h, dim3((unsigned)blocks), dim3(256), shmem, st, HA, HB, (long)R, S, n_cols, ga, gb, (u64)seed,
-                       (long)row0, OA, OB);
+                       (long)row0, OA, OB, TR);
     EPG_LAUNCH_CHECK("k_null_hist_h");
     return EPG_OK;
 }
@@ -283,8 +284,10 @@ int quiescent_from_binhist_impl(const uint16_t* HA, const uint16_t* HB, int64_t 
 
 int null_hist_impl(const int8_t* XA, int32_t NA, int64_t ldxa, const int8_t* XB, int32_t NB, int64_t ldxb, int64_t R, int32_t S,
                    int32_t ga, int32_t gb, uint64_t seed, int64_t row0, uint16_t* HA, uint16_t* HB, hipStream_t st) {
-    if (R < 0 || NA < 1 || NB < 1 || ldxa < NA || ldxb < NB || S < 1 || S > 31)
+    if (R < 0 || NA < 1 || NB < 1 || ldxa < NA || ldxb < NB || S < 1)
         return fail(EPG_ERR_INVALID_ARG, "null_hist: bad shape");
+    if (S > 31) return fail(EPG_ERR_UNSUPPORTED, "null_hist: the matrix-scanning kernel decodes five bits; for S=%d count the groups with "
+                                                 "epg_bin_hist and draw with epg_null_hist_from_binhist", S);
     if (ga < 0 || gb < 0 || (long)ga + gb > (long)NA + NB)
         return fail(EPG_ERR_INVALID_ARG, "null_hist: group sizes %d + %d exceed the %d columns", ga, gb, NA + NB);
     if (NA + NB > 65535) return fail(EPG_ERR_UNSUPPORTED, "null_hist: more than 65535 columns");

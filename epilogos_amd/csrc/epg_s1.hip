@@ -92,7 +92,7 @@ __global__ __launch_bounds__(256) void k_bin_hist(const char* __restrict__ X, lo
 // Used for the matrix's last row(s) when ldx < 16*ceil(N/16) (the fast kernel's last chunk would over-read).  Decodes
 // the low five bits of a byte like the fast kernel (see epg_count.h) so that both treat every byte value alike.
 __global__ __launch_bounds__(256) void k_bin_hist_safe(const char* __restrict__ X, long row_begin, long row_end, int N,
-                                                        long ldx, int S, u16* __restrict__ H, u64* __restrict__ counts) {
+                                                        long ldx, int S, u16* __restrict__ H, u64* __restrict__ counts, int mask = 31) {
     __shared__ u32 s_h[4][128];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (long row = row_begin + (long)blockIdx.x * 4 + wave; row < row_end; row += (long)gridDim.x * 4) {
@@ -100,7 +100,7 @@ __global__ __launch_bounds__(256) void k_bin_hist_safe(const char* __restrict__ 
         __builtin_amdgcn_wave_barrier();
         const char* rp = X + row * ldx;
         for (int n = lane; n < N; n += 64) {
-            const int v = (unsigned char)rp[n] & 31;
+            const int v = (unsigned char)rp[n] & mask;       // 31: the fast kernels' five-bit decode; 255: the wide models
             if (v < S) atomicAdd(&s_h[wave][v], 1u);
         }
         __builtin_amdgcn_wave_barrier();
@@ -311,13 +311,19 @@ static long fast_rows(long R, int N, long ldx) {
 int bin_hist_impl(const int8_t* X8, int64_t R, int32_t N, int64_t ldx, int32_t S, uint16_t* H, int64_t* counts,
                   hipStream_t st) {
     if (R < 0 || N < 1 || ldx < N || S < 1) return fail(EPG_ERR_INVALID_ARG, "bin_hist: bad shape R=%lld N=%d ldx=%lld S=%d", (long long)R, N, (long long)ldx, S);
-    if (S > 31) return fail(EPG_ERR_UNSUPPORTED, "bin_hist: S=%d > 31 not supported by this build", S);
+    if (S > 127) return fail(EPG_ERR_UNSUPPORTED, "bin_hist: S=%d > 127 (states are int8)", S);
     if (N > 65535) return fail(EPG_ERR_UNSUPPORTED, "bin_hist: N=%d > 65535 (uint16 per-bin counts)", N);
     if (R == 0) return EPG_OK;
     if (!X8) return fail(EPG_ERR_INVALID_ARG, "bin_hist: X is NULL");
     if (H && (reinterpret_cast<uintptr_t>(H) & 15)) return fail(EPG_ERR_INVALID_ARG, "bin_hist: H must be 16-byte aligned");
     const char* X = reinterpret_cast<const char*>(X8);
     u64* cnt = reinterpret_cast<u64*>(counts);
+    if (S > 31) {                                  // the wide models (epg_wide.hip): one wave per bin, the whole byte decoded
+        hipLaunchKernelGGL(k_bin_hist_safe, dim3((unsigned)((R + 3) / 4 < num_cus() * 32L ? (R + 3) / 4 : num_cus() * 32L)), dim3(256), 0, st, X, 0L,
+                           (long)R, N, ldx, S, H, cnt, 255);
+        EPG_LAUNCH_CHECK("k_bin_hist_safe");
+        return EPG_OK;
+    }
     const long Rf = fast_rows(R, N, ldx);
     if (Rf > 0) {
         // the reference's models have their own instantiation; any other size runs on the next larger counting core
@@ -460,8 +466,8 @@ int score_s1_from_hist_table_impl(const uint16_t* H, int64_t R, int32_t N, int32
 // ---------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_s1_combine(const u64* __restrict__ counts, int N, int S, float* __restrict__ q,
                                                      double* __restrict__ T64, float* __restrict__ T32) {
-    __shared__ long long s_c[32];
-    __shared__ double s_q[32];
+    __shared__ long long s_c[128];
+    __shared__ double s_q[128];
     const int t = threadIdx.x;
     if (t < S) s_c[t] = (long long)counts[t];
     __syncthreads();
@@ -488,7 +494,7 @@ static int normalise_impl(const IT* C, int64_t n, float* q, void* ws, int64_t ws
 int combine_score_s1_impl(int64_t* counts, int32_t rezero, const uint16_t* H, int64_t R, int32_t N, int32_t S, float* q,
                           double* out64, float* out32, void* ws, int64_t ws_bytes, hipStream_t st) {
     if (R < 0 || N < 1 || S < 1) return fail(EPG_ERR_INVALID_ARG, "combine_score_s1: bad shape R=%lld N=%d S=%d", (long long)R, N, S);
-    if (S > 31) return fail(EPG_ERR_UNSUPPORTED, "combine_score_s1: S=%d > 31 not supported by this build", S);
+    if (S > 127) return fail(EPG_ERR_UNSUPPORTED, "combine_score_s1: S=%d > 127 (states are int8)", S);
     if (!counts || !q || !ws || (R > 0 && !H)) return fail(EPG_ERR_INVALID_ARG, "combine_score_s1: NULL argument");
     if (ws_bytes < s1_table_bytes(N, S)) return fail(EPG_ERR_WORKSPACE, "combine_score_s1: workspace %lld < %lld bytes", (long long)ws_bytes, (long long)s1_table_bytes(N, S));
     int rc = check_score_from_hist_args(H, out64, out32);
@@ -508,7 +514,7 @@ int combine_score_s1_impl(int64_t* counts, int32_t rezero, const uint16_t* H, in
 int score_s1_impl(const int8_t* X8, int64_t R, int32_t N, int64_t ldx, int32_t S, const float* q, double* out64,
                   float* out32, void* ws, int64_t ws_bytes, hipStream_t st) {
     if (R < 0 || N < 1 || ldx < N || S < 1) return fail(EPG_ERR_INVALID_ARG, "score_s1: bad shape");
-    if (S > 31) return fail(EPG_ERR_UNSUPPORTED, "score_s1: S=%d > 31 not supported by this build", S);
+    if (S > 127) return fail(EPG_ERR_UNSUPPORTED, "score_s1: S=%d > 127 (states are int8)", S);
     if (R == 0) return EPG_OK;
     if (!X8 || !q || !ws) return fail(EPG_ERR_INVALID_ARG, "score_s1: NULL argument");
     if ((out32 && (reinterpret_cast<uintptr_t>(out32) & 15)) || (out64 && (reinterpret_cast<uintptr_t>(out64) & 15)))

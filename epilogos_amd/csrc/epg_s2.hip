@@ -591,17 +591,17 @@ __device__ __forceinline__ void load_staged(char* lds, const char* src, int nbyt
 // registers, no per-lane arrays (a float d[32] indexed by a runtime loop lives in scratch: 4.9 ms) -- writes delta over
 // its row of a, and the wave stores the 64 delta rows as whole lines.
 __global__ __launch_bounds__(256) void k_pair_finish(const float* __restrict__ a, const float* __restrict__ b, long R,
-                                                      int S, float* __restrict__ delta, float* __restrict__ dist) {
+                                                      int S, float* __restrict__ delta, float* __restrict__ dist, int TR) {
 #pragma clang fp contract(off)   // numpy squares, rounds, then adds: no fused multiply-add anywhere in here
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int rowb = S * 4;
-    char* sa = smem + (size_t)wave * 2 * 64 * rowb;
-    char* sb = sa + 64 * rowb;
-    const long ntiles = (R + 63) >> 6;
+    char* sa = smem + (size_t)wave * 2 * TR * rowb;        // TR rows per wave and turn: 64, fewer for the wide state models
+    char* sb = sa + TR * rowb;
+    const long ntiles = (R + TR - 1) / TR;
     for (long tile = (long)blockIdx.x * 4 + wave; tile < ntiles; tile += (long)gridDim.x * 4) {
-        const long row0 = tile * 64;
-        const int rows = (int)(R - row0 < 64 ? R - row0 : 64);
+        const long row0 = tile * TR;
+        const int rows = (int)(R - row0 < TR ? R - row0 : TR);
         load_staged(sa, reinterpret_cast<const char*>(a + row0 * S), rows * rowb, lane);
         load_staged(sb, reinterpret_cast<const char*>(b + row0 * S), rows * rowb, lane);
         __builtin_amdgcn_wave_barrier();
@@ -695,10 +695,14 @@ __global__ __launch_bounds__(256) void k_quiescent(const char* __restrict__ XA, 
 // ---------------------------------------------------------------------------------------------------------------
 // host-side dispatch
 // ---------------------------------------------------------------------------------------------------------------
+int wide_hist_s2_from_binhist(const uint16_t* H, const uint16_t* H2, int64_t R, int32_t S, int64_t* counts, hipStream_t st);
+int wide_score_s2_from_hist(const uint16_t* H, int64_t R, int32_t S, int64_t perms, const float* q, double* out64, float* out32, hipStream_t st);
+
 int hist_s2_from_binhist_impl(const uint16_t* H, const uint16_t* H2, int64_t R, int32_t S, int64_t* counts, hipStream_t st) {
-    if (R < 0 || S < 1 || S > 31) return fail(EPG_ERR_INVALID_ARG, "hist_s2: bad shape R=%lld S=%d", (long long)R, S);
+    if (R < 0 || S < 1 || S > 127) return fail(EPG_ERR_INVALID_ARG, "hist_s2: bad shape R=%lld S=%d", (long long)R, S);
     if (R == 0) return EPG_OK;
     if (!H || !counts) return fail(EPG_ERR_INVALID_ARG, "hist_s2: NULL argument");
+    if (S > 31) return wide_hist_s2_from_binhist(H, H2, R, S, counts, st);          // the wide models: epg_wide.hip
     const long nb = (R + S2H_BATCH - 1) / S2H_BATCH;
     if ((reinterpret_cast<uintptr_t>(H) & 15) || (reinterpret_cast<uintptr_t>(H2) & 15)) return fail(EPG_ERR_INVALID_ARG, "hist_s2: H must be 16-byte aligned");
     static const bool use_block = [] { const char* e = getenv("EPG_S2_HIST"); return e && e[0] == 'b'; }();   // A/B: round-1 kernel
@@ -726,9 +730,10 @@ int64_t s2_table_bytes(int maxc, int S) { return align_up((int64_t)(maxc + 1) * 
 
 int score_s2_from_hist_impl(const uint16_t* H, int64_t R, int32_t N, int32_t S, int64_t perms, const float* q,
                             double* out64, float* out32, void* ws, int64_t ws_bytes, hipStream_t st) {
-    if (R < 0 || N < 1 || S < 1 || S > 31 || perms < 1) return fail(EPG_ERR_INVALID_ARG, "score_s2: bad shape R=%lld N=%d S=%d perms=%lld", (long long)R, N, S, (long long)perms);
+    if (R < 0 || N < 1 || S < 1 || S > 127 || perms < 1) return fail(EPG_ERR_INVALID_ARG, "score_s2: bad shape R=%lld N=%d S=%d perms=%lld", (long long)R, N, S, (long long)perms);
     if (R == 0) return EPG_OK;
     if (!H || !q || !ws) return fail(EPG_ERR_INVALID_ARG, "score_s2: NULL argument");
+    if (S > 31) return wide_score_s2_from_hist(H, R, S, perms, q, out64, out32, st);   // the wide models: epg_wide.hip
     if (ws_bytes < s2_table_bytes(N, S)) return fail(EPG_ERR_WORKSPACE, "score_s2: workspace %lld < %lld bytes", (long long)ws_bytes, (long long)s2_table_bytes(N, S));
     double* LH = reinterpret_cast<double*>(ws);
     double* LPQ = reinterpret_cast<double*>(reinterpret_cast<char*>(ws) + align_up((int64_t)(N + 1) * 8, 256));
@@ -781,15 +786,15 @@ int score_s2_from_hist_impl(const uint16_t* H, int64_t R, int32_t N, int32_t S, 
 __device__ __forceinline__ float text_roundtrip_f5(float v) { return (float)(rint((double)v * 1e5) / 1e5); }
 
 __global__ __launch_bounds__(256) void k_pair_metrics(const float* __restrict__ delta, long R, int S, int roundtrip,
-                                                       float* __restrict__ dist, int* __restrict__ maxdiff) {
+                                                       float* __restrict__ dist, int* __restrict__ maxdiff, int TR) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int rowb = S * 4;
-    char* sd_ = smem + (size_t)wave * 64 * rowb;                     // the wave's 64 rows, fetched as whole lines
-    const long ntiles = (R + 63) >> 6;
+    char* sd_ = smem + (size_t)wave * TR * rowb;                     // the wave's 64 rows, fetched as whole lines
+    const long ntiles = (R + TR - 1) / TR;
     for (long tile = (long)blockIdx.x * 4 + wave; tile < ntiles; tile += (long)gridDim.x * 4) {
-        const long row0 = tile * 64;
-        const int rows = (int)(R - row0 < 64 ? R - row0 : 64);
+        const long row0 = tile * TR;
+        const int rows = (int)(R - row0 < TR ? R - row0 : TR);
         load_staged(sd_, reinterpret_cast<const char*>(delta + row0 * S), rows * rowb, lane);
         __builtin_amdgcn_wave_barrier();
         if (lane < rows) {
@@ -816,22 +821,24 @@ int pair_metrics_impl(const float* delta, int64_t R, int32_t S, int32_t roundtri
     if (R == 0) return EPG_OK;
     if (!delta || !dist || !maxdiff) return fail(EPG_ERR_INVALID_ARG, "pair_metrics: NULL argument");
     if (reinterpret_cast<uintptr_t>(delta) & 15) return fail(EPG_ERR_INVALID_ARG, "pair_metrics: delta must be 16-byte aligned");
-    long blocks = ((R + 63) / 64 + 3) / 4;
+    const int TR = tile_rows(S * 4);
+    long blocks = ((R + TR - 1) / TR + 3) / 4;
     if (blocks > num_cus() * 8L) blocks = num_cus() * 8L;
-    hipLaunchKernelGGL(k_pair_metrics, dim3((unsigned)blocks), dim3(256), (size_t)4 * 64 * S * 4, st, delta, (long)R, S, roundtrip, dist, maxdiff);
+    hipLaunchKernelGGL(k_pair_metrics, dim3((unsigned)blocks), dim3(256), (size_t)4 * TR * S * 4, st, delta, (long)R, S, roundtrip, dist, maxdiff, TR);
     EPG_LAUNCH_CHECK("k_pair_metrics");
     return EPG_OK;
 }
 
 int pair_finish_impl(const float* a, const float* b, int64_t R, int32_t S, float* delta, float* dist, hipStream_t st) {
-    if (R < 0 || S < 1 || S > 32) return fail(EPG_ERR_INVALID_ARG, "pair_finish: bad shape");
+    if (R < 0 || S < 1 || S > 127) return fail(EPG_ERR_INVALID_ARG, "pair_finish: bad shape");   // numpy's pairwise sum recurses above 128
     if (R == 0) return EPG_OK;
     if (!a || !b || !delta) return fail(EPG_ERR_INVALID_ARG, "pair_finish: NULL argument");
     if ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(delta)) & 15)
         return fail(EPG_ERR_INVALID_ARG, "pair_finish: a, b and delta must be 16-byte aligned");
-    long blocks = ((R + 63) / 64 + 3) / 4;
+    const int TR = tile_rows(2 * S * 4);
+    long blocks = ((R + TR - 1) / TR + 3) / 4;
     if (blocks > num_cus() * 8L) blocks = num_cus() * 8L;
-    hipLaunchKernelGGL(k_pair_finish, dim3((int)blocks), dim3(256), (size_t)4 * 2 * 64 * S * 4, st, a, b, (long)R, S, delta, dist);
+    hipLaunchKernelGGL(k_pair_finish, dim3((int)blocks), dim3(256), (size_t)4 * 2 * TR * S * 4, st, a, b, (long)R, S, delta, dist, TR);
     EPG_LAUNCH_CHECK("k_pair_finish");
     return EPG_OK;
 }

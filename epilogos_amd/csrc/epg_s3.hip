@@ -299,9 +299,14 @@ int64_t s3_sparse_ws_bytes(int64_t R, int N, int S);
 int score_s3_sparse(const int8_t* X8, int64_t R, int32_t N, int64_t ldx, int32_t S, const float* q, double* out64, float* out32, void* ws,
                     int64_t ws_bytes, hipStream_t st, bool forced);
 
+int wide_hist_s3(const int8_t* X, int64_t R, int32_t N, int64_t ldx, int32_t S, int32_t* counts, hipStream_t st);
+int wide_score_s3(const int8_t* X, int64_t R, int32_t N, int64_t ldx, int32_t S, const float* q, double* out64, float* out32, void* ws,
+                  int64_t ws_bytes, hipStream_t st);
+
 static int s3_nceil(int N) { return (N + S3S_ACH - 1) / S3S_ACH * S3S_ACH; }
 int64_t s3_table_bytes(int N, int S) { return align_up((int64_t)s3_nceil(N) * N * S * S * 4, 256); }
 int64_t s3_ws_bytes(int64_t R, int N, int S) {
+    if (S > 31) return align_up(R * S * 8, 256) + 256;       // the wide models (epg_wide.hip): the fixed-point cells, nothing else
     // score: table + transposed state matrix + float64 accumulator; expected: transposed state matrix (+ a chunk of the
     // precomputed fp4 one-hot operand for the default kernel)
     int64_t score = s3_table_bytes(N, S) + s3_mfma_ws_bytes(R, N) + align_up(R * S * 8, 256);
@@ -314,9 +319,10 @@ int64_t s3_ws_bytes(int64_t R, int N, int S) {
 int hist_s3_impl(const int8_t* X8, int64_t R, int32_t N, int64_t ldx, int32_t S, int32_t* counts, void* ws, int64_t ws_bytes,
                  hipStream_t st) {
     if (R < 0 || N < 2 || ldx < N || S < 1) return fail(EPG_ERR_INVALID_ARG, "hist_s3: bad shape R=%lld N=%d ldx=%lld S=%d", (long long)R, N, (long long)ldx, S);
-    if (S > 31) return fail(EPG_ERR_UNSUPPORTED, "hist_s3: S=%d > 31 not supported by this build", S);
+    if (S > 127) return fail(EPG_ERR_UNSUPPORTED, "hist_s3: S=%d > 127 (states are int8)", S);
     if (R == 0) return EPG_OK;
     if (!X8 || !counts) return fail(EPG_ERR_INVALID_ARG, "hist_s3: NULL argument");
+    if (S > 31) return wide_hist_s3(X8, R, N, ldx, S, counts, st);                      // the wide models: epg_wide.hip
     // matrix-core path when the caller gave room for the transposed matrix (S <= 30: padding rows use pattern 30);
     // EPG_S3_HIST=lds forces the LDS-atomic kernel (A/B measurements, and the fallback for S = 31 / no workspace)
     static const bool force_lds = [] { const char* e = getenv("EPG_S3_HIST"); return e && e[0] == 'l'; }();
@@ -343,9 +349,10 @@ int hist_s3_impl(const int8_t* X8, int64_t R, int32_t N, int64_t ldx, int32_t S,
 int score_s3_impl(const int8_t* X8, int64_t R, int32_t N, int64_t ldx, int32_t S, const float* q, double* out64, float* out32,
                   void* ws, int64_t ws_bytes, hipStream_t st) {
     if (R < 0 || N < 2 || ldx < N || S < 1) return fail(EPG_ERR_INVALID_ARG, "score_s3: bad shape");
-    if (S > 31) return fail(EPG_ERR_UNSUPPORTED, "score_s3: S=%d > 31 not supported by this build", S);
+    if (S > 127) return fail(EPG_ERR_UNSUPPORTED, "score_s3: S=%d > 127 (states are int8)", S);
     if (R == 0) return EPG_OK;
     if (!X8 || !q || !ws) return fail(EPG_ERR_INVALID_ARG, "score_s3: NULL argument");
+    if (S > 31) return wide_score_s3(X8, R, N, ldx, S, q, out64, out32, ws, ws_bytes, st);   // the wide models: epg_wide.hip
     // default: the biosample-lane kernel (epg_s3_lanes.hip, S <= 21) when the workspace holds its table;
     // EPG_S3_SCORE=bins selects k_s3_score below (A/B measurements; the path for S > 21)
     const char* env = getenv("EPG_S3_SCORE");      // read per call: the tests run the kernels in one process

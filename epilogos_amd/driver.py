@@ -393,6 +393,7 @@ def run_single_group(files, numStates, saliency, outputDir, fileTag, verbose=Fal
     keep_temp_scores writes the reference's temp_scores_{tag}_{stem}.npz (scores.py:166-169) for a STEP 4 run
     elsewhere; the command line skips them because its STEP 4 would delete them a moment later."""
     be = backend if backend is not None else _backend.get()
+    _io.set_state_limit(numStates)                     # above 31 states the parser keeps values up to 127 (wide kernels)
     d = _Dist()
     files = [Path(f) for f in files]
     outputDir = Path(outputDir)
@@ -487,6 +488,7 @@ def run_paired_groups(files1, files2, numStates, saliency, outputDir, fileTag, q
     also writes temp_nullDistances / temp_quiescence (the reference's, scores.py:246-255) and temp_pairMetrics (the
     side-car of this engine's STEP 4)."""
     be = backend if backend is not None else _backend.get()
+    _io.set_state_limit(numStates)
     d = _Dist()
     files1, files2 = [Path(f) for f in files1], [Path(f) for f in files2]
     outputDir = Path(outputDir)

@@ -8,11 +8,13 @@ from time import time
 
 import numpy as np
 
+from . import _io
 from . import backend as _backend
 from .helpers import countRows, fileStem, readStates, strToBool
 
 
 def main(file1, file2, numStates, saliency, outputDir, fileTag, numProcesses, verbose):
+    _io.set_state_limit(numStates)
     """file2 == "null" for single-group runs; numProcesses is accepted for CLI compatibility and ignored (the
     row-range fan-out of the reference's Pool is the GPU's grid)."""
     if verbose: tTotal = time()

@@ -44,7 +44,9 @@ def _cache_paths(path):
         return None
     import hashlib
     st = os.stat(path)
-    key = hashlib.sha1("{}|{}|{}".format(os.path.abspath(path), st.st_size, st.st_mtime_ns).encode()).hexdigest()[:20]
+    # (a cache parsed for a model of up to 31 states holds -1 for larger values: the wide models get their own)
+    wide = "|wide" if _io.state_limit() > 31 else ""
+    key = hashlib.sha1("{}|{}|{}{}".format(os.path.abspath(path), st.st_size, st.st_mtime_ns, wide).encode()).hexdigest()[:20]
     base = Path(root) / "{}_{}".format(Path(path).name.split(".")[0], key)
     return [Path(str(base) + ext) for ext in (".states.npy", ".locblob.npy", ".locoff.npy", ".range.npy")]
 

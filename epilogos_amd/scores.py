@@ -37,6 +37,7 @@ NULL_SEED = None   # paired nulls are unseeded in the reference (helpers.py:183)
 
 def main(file1, file2, numStates, saliency, outputDir, expFreqPath, fileTag, numProcesses, quiescentState, groupSize,
          verbose):
+    _io.set_state_limit(numStates)
     if verbose: tTotal = time()
     file1Path, file2Path, outputDirPath = Path(file1), Path(file2), Path(outputDir)
     filename = fileStem(file1Path)

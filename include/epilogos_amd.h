@@ -21,12 +21,14 @@
  *     (ldx >= N; the fast path wants X and ldx 16-byte aligned, any ldx >= N is accepted).  State bytes must be in
  *     0..31 or 0xFF (-1): a byte in [S, 31] or 0xFF is "not a state" and is counted nowhere (the expected pass detects
  *     it: sum(counts) != R*N); the S1/S2 kernels decode only the low five bits, so other byte values are outside the
- *     contract (libepilogos_io's parser stores every file value outside 1..31 as -1).
+ *     contract (libepilogos_io's parser stores every file value outside 1..31 as -1).  A model of 32..127 states is handed
+ *     to plain kernels that decode the whole byte (csrc/epg_wide.hip): any byte outside [0, S) is then "not a state".
  *   - `counts` outputs ACCUMULATE (+=) so that per-chromosome calls sum into one vector exactly like
  *     expectedCombination.py:30-35; zero them first.  They are what the single RCCL all-reduce runs on.
  *   - One host thread per device; calls on different devices/streams are independent.
  *
- * Limits of this build: 1 <= S <= 31 for the S1/S2 paths (ChromHMM models in the reference: 15, 18, 25),
+ * Limits of this build: 1 <= S <= 127 (states are int8; the tuned kernels serve 1..31 -- the reference's ChromHMM models have
+ * 15, 18 and 25 -- and larger models take a generic, slow path; epg_null_hist and the modal-state S3 kernel stop at 31 / 19),
  * N <= 65535 (per-bin counts are stored as uint16).
  */
 #ifndef EPILOGOS_AMD_H

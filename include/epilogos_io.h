@@ -35,6 +35,9 @@ int64_t epgio_count_rows(const char* path);
 /* Parse rows [row_lo, row_hi) (row_hi < 0: to the end of the file) with `threads` parser threads (0 = all cores).
  * Returns a handle owning the parsed table, or NULL. */
 epgio_table* epgio_open_table(const char* path, int64_t row_lo, int64_t row_hi, int32_t threads);
+/* The same for a state model of `max_state` states: up to 31 (what epgio_open_table assumes) values outside 1..31 are stored
+ * as "not a state", above that values outside 1..127 -- the GPU kernels of the wide models decode the whole byte. */
+epgio_table* epgio_open_table_ex(const char* path, int64_t row_lo, int64_t row_hi, int32_t threads, int32_t max_state);
 int64_t epgio_table_rows(const epgio_table* t);
 int32_t epgio_table_cols(const epgio_table* t);          /* number of state columns N */
 /* Smallest and largest state value of the parsed rows AS WRITTEN IN THE FILE (1-based); 0, 0 for an empty table.  The
@@ -42,7 +45,7 @@ int32_t epgio_table_cols(const epgio_table* t);          /* number of state colu
  * callers compare this range with their state model. */
 int epgio_table_state_range(const epgio_table* t, int32_t* lo, int32_t* hi);
 /* Copy the 0-based int8 states (file value - 1) into out[r * ldx + c]; bytes c >= N of a row are set to -1.  A value
- * outside 0..30 (the engine's models have at most 31 states) is stored as -1 = "not a state". */
+ * outside 0..30 (0..126 for a table opened for a model of more than 31 states) is stored as -1 = "not a state". */
 int epgio_table_copy_states(const epgio_table* t, int8_t* out, int64_t ldx);
 /* Verbatim text of the first three columns of every row, each terminated by '\n' ("chr\tstart\tend\n"),
  * concatenated; offsets[r]..offsets[r+1] delimit row r (newline included).  Valid until epgio_close_table. */

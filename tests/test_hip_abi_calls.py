@@ -64,7 +64,11 @@ def test_direct_calls_match_oracle(abi):
         abi.call("epg_bin_hist", _p(X), R, N, N - 1, S, None, _p(c1), st)
     assert e.value.code == -1
     with pytest.raises(abi.EpilogosHipError) as e:
-        abi.call("epg_bin_hist", _p(X), R, N, ldx, 40, None, _p(c1), st)
+        abi.call("epg_bin_hist", _p(X), R, N, ldx, 128, None, _p(c1), st)      # states are int8: 127 is the largest model
+    assert e.value.code == -2
+    with pytest.raises(abi.EpilogosHipError) as e:                              # the matrix-scanning null kernel stops at 31 states
+        abi.call("epg_null_hist", _p(X), N, ldx, _p(X), N, ldx, R, 40, N, N, 1, 0, _p(torch.empty((R, 40), dtype=torch.int16, device="cuda")),
+                 _p(torch.empty((R, 40), dtype=torch.int16, device="cuda")), st)
     assert e.value.code == -2
 
 
