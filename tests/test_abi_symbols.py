@@ -46,8 +46,10 @@ def test_version_and_argument_validation_without_gpu(lib):
     assert rc == -1 and b"bad shape" in lib.epg_last_error()
     rc = lib.epg_bin_hist(None, 10, 10, 5, 18, None, None, None)       # ldx < N
     assert rc == -1
-    rc = lib.epg_bin_hist(None, 10, 10, 16, 40, None, None, None)      # S > 31
+    rc = lib.epg_bin_hist(None, 10, 10, 16, 128, None, None, None)     # S > 127: states are int8
     assert rc == -2
+    rc = lib.epg_bin_hist(None, 10, 10, 16, 40, None, None, None)      # a wide model is taken; X is NULL
+    assert rc == -1
     assert lib.epg_ws_bytes(4, 10, 10, 18) == -1
     assert lib.epg_ws_bytes(1, 0, 833, 18) >= 834 * 18 * 12
 
