@@ -440,6 +440,35 @@ def test_three_rank_gloo_uneven_files_text_then_cache(tmp_path, golden_real):
         assert not list(outs[tag].glob(".part_*"))
 
 
+def test_more_ranks_than_files_and_an_empty_file(tmp_path, golden_real):
+    """Four ranks, three files of which one is empty: two ranks parse nothing and own bins all the same (everything they score
+    was handed over), the empty file still gets its (empty) output, outputs equal the single-process ones."""
+    x = golden_real["x"]
+    ind = tmp_path / "in"
+    ind.mkdir()
+    write_tsv(ind / "m_chr1.txt", x[:1200], chrom="chr1")
+    (ind / "m_chr2.txt").write_text("")
+    write_tsv(ind / "m_chr3.txt", x[1200:], chrom="chr3")
+    outs = {}
+    for world in (1, 4):
+        out = tmp_path / ("out%d" % world)
+        out.mkdir()
+        port = str(free_port())
+        env = dict(os.environ, PYTHONPATH=str(ROOT), MASTER_ADDR="127.0.0.1", MASTER_PORT=port, EPILOGOS_IO_LOG=str(tmp_path / ("io%d.log" % world)))
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+               "--master-addr", "127.0.0.1", "--master-port", port, str(ROOT / "tests" / "gloo_worker.py"), str(ind), str(out)]
+        res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+        assert res.returncode == 0, res.stdout + res.stderr
+        outs[world] = out
+        passes = _io_passes(tmp_path / ("io%d.log" % world))
+        assert len(passes) == 3 and all(v == [("read", 0, -1)] for v in passes.values()), passes
+    for stem, n in (("m_chr1", 1200), ("m_chr2", 0), ("m_chr3", x.shape[0] - 1200)):
+        one, four = _decompressed(outs[1] / ("scores_t_s1_%s.txt.gz" % stem)), _decompressed(outs[4] / ("scores_t_s1_%s.txt.gz" % stem))
+        assert one == four and len(one.splitlines()) == n
+    assert np.array_equal(np.load(outs[1] / "exp_freq_t_s1.npy"), np.load(outs[4] / "exp_freq_t_s1.npy"))
+    assert not list(outs[4].glob(".part_*"))
+
+
 def test_cli_rejects_states_outside_the_model(tmp_path, golden_real, fake_backend, state_info):
     """The reference dies with an IndexError when the data holds a state the -j model does not have (expected.py:113); the
     command line here must not run to completion either -- neither for a value just above the model nor for one that would
