@@ -267,7 +267,8 @@ static int grid_for_tiles(long R) {
     return (int)blocks;
 }
 
-int g_blocks_per_cu = 4;  // persistent grid size (epg_debug_set_variant tunes it for A/B runs)
+int g_blocks_per_cu = 2;  // persistent grid size (epg_debug_set_variant tunes it for A/B runs).  Round 3: two blocks (2 waves per
+                          // SIMD) measure 3-4 % faster than four on 1.9-7.5 M-bin shards and 1 % on 15 M bins (profiles/r03i_*)
 
 template <int S, int NG>
 static void launch_bin_hist(const char* X, long R, int N, long ldx, int Sout, u16* H, u64* counts, hipStream_t st) {
