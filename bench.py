@@ -26,8 +26,8 @@ through the sessions the command line uses (backend.HipBackend.open_single / ope
 of launches), each with its own roofline figure:
     "s2"     whole S2 job on the S1 matrix (K1, pair counts from the histograms, all-reduce, normalise, score pass),
     "s3"     S3 expected pass (matrix-core contraction) and score pass (LDS gathers) on `--s3-bins` bins,
-    "paired" paired S1 on 379 + 342 biosamples: two count passes, all-reduce, the hypergeometric null groups, four score
-             passes, deltas, null distances, STEP 4's per-bin reduction and the quiescence mask.
+    "paired" paired S1 on 379 + 342 biosamples: two count passes, all-reduce, the hypergeometric null groups, then scores of
+             the four groups, deltas, null distances and STEP 4's per-bin reduction in one pass, and the quiescence mask.
 `--configs none` skips them.  The headline step allocates like the product does (plain torch allocations); the effect of
 putting the histogram cache into another memory class than the matrix (engine.place_hist) is measured after
 the timed region and reported as the secondary field `placement_experiment`.
@@ -279,16 +279,15 @@ def bench_paired(torch, be, d, R, R_global, bin0, S, world, reps, fence, dev, di
         del sess, res
     wall_ms = float(np.median(walls)) * 1e3
     exp_ms, comb_ms, res_ms = (float(v) for v in np.median(np.array(phases), axis=0))
-    # bytes per bin: both matrices read + two histograms written; null groups: 2 H read, 2 written; four score passes (H read,
-    # float32 written); two pair_finish (2 score rows read, one written, + the distance); metrics (delta read, 8 B written);
-    # quiescence (2 H read, 1 B written)
-    bpb = (NA + NB) + 2 * 2 * S + 4 * 2 * S + 4 * (2 * S + 4 * S) + 2 * (3 * 4 * S) + 4 + (4 * S + 8) + (2 * 2 * S + 1)
+    # bytes per bin: both matrices read + two histograms written; null groups: 2 H read, 2 written; the fused score pass: 4 H read,
+    # delta (4 S) + null distance + STEP 4's distance and state (12) written; quiescence: 2 H read, 1 B written
+    bpb = (NA + NB) + 2 * 2 * S + 4 * 2 * S + (4 * 2 * S + 4 * S + 12) + (2 * 2 * S + 1)
     gb = R * bpb / (exp_ms + comb_ms + res_ms) / 1e6
     return {"bins_total": R_global, "bins_per_gpu": R, "biosamples": [NA, NB], "states": S, "saliency": 1, "reps": reps,
             "job_ms": round(wall_ms, 3), "value": round(R_global / wall_ms / 1e3, 3), "unit": "Mbins/s",
             "outputs_finite": ok, "quiescent_bins": nq,
             "phases_ms": {"two count passes": round(exp_ms, 3), "allreduce+check+normalise": round(comb_ms, 3),
-                          "null groups + 4 score passes + deltas + metrics + quiescence": round(res_ms, 3)},
+                          "null groups + scores/deltas/null distances/metrics (one pass) + quiescence": round(res_ms, 3)},
             "roofline": {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBPS, "algorithmic_bytes_per_bin": bpb,
                          "achieved": round(gb, 1), "frac": round(gb / HBM_PEAK_GBPS, 4),
                          "what": "whole job (device time of the three phases) against the bytes it has to move; the null groups "

@@ -233,12 +233,15 @@ class _HipSession:
     def _score_s1(self, H, N):
         """S1 score pass of the command line: the lookup table comes from the host (scores.s1ScoreTable: numpy's log2 on the
         exp_freq this session normalised), so the float32 scores are the reference's bit for bit; one table per group width."""
+        o32, _ = self.eng.score_s1_from_binhist_table(H, N, self.S, T32=self._s1_table(N))
+        return o32
+
+    def _s1_table(self, N):
         if N not in self._t1:
             from .scores import s1ScoreTable
             _t64, t32 = s1ScoreTable(self.q.cpu().numpy(), N)
             self._t1[N] = self.torch.from_numpy(t32).to(self.device)
-        o32, _ = self.eng.score_s1_from_binhist_table(H, N, self.S, T32=self._t1[N])
-        return o32
+        return self._t1[N]
 
     def finish_device(self, total_rows, N):
         """Count check (the reference dies on a state outside the model, expected.py:113; here such a byte is counted
@@ -402,6 +405,16 @@ class _HipPairedSession(_HipSession):
         # the null groups' histograms straight from the real groups' (multivariate hypergeometric, no pass over X)
         HnA, HnB = eng.null_hist_from_binhist(HA, HB, NA + NB, S, ga, gb, self.seed, row0)
         if self.sal == 1:
+            # one pass over the four histograms: table gathers, deltas, null distances and STEP 4's reduction (round 3); groups
+            # too wide for the tables to sit in LDS take the separate passes below
+            tabs = [self._s1_table(n) for n in (NA, NB, ga, gb)]
+            try:
+                delta, null, rdist, mdiff = eng.pair_scores_s1_from_binhist(HA, HB, HnA, HnB, S, NA, NB, ga, gb, *tabs)
+                quies = eng.quiescent_from_binhist(HA, NA, HB, NB, S, self.qstate)
+                return {"delta": delta, "null": null, "quies": quies, "rdist": rdist, "mdiff": mdiff}
+            except self.eng.EpilogosHipError as e:
+                if e.code != -2:
+                    raise
             sA, sB = self._score_s1(HA, NA), self._score_s1(HB, NB)
             nA, nB = self._score_s1(HnA, ga), self._score_s1(HnB, gb)
         else:                                            # quirk Q9: null halves keep the original groups' permutation counts

@@ -693,6 +693,170 @@ __global__ __launch_bounds__(256) void k_quiescent(const char* __restrict__ XA, 
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Paired S1, everything after the null groups in ONE pass over the four histograms of a bin (round 3): the scores of A, B
+// and the two null groups are gathers from S1 tables (the caller's, [N + 1, S] float32 per group width; scores.py:223-232 store
+// float32 scores), delta = scoreA - scoreB, the null distance = sign(sum nd) sum nd^2 of nd = nullA - nullB in numpy's pairwise
+// order, and STEP 4's per-bin reduction of delta (roiAndVisualPairwise.py:347-354) -- the arithmetic of k_score_s1_from_hist,
+// k_pair_finish and k_pair_metrics, bit for bit, without writing and re-reading four score arrays: 144 B read and 85 B written per
+// bin instead of ~950.  One lane per bin; a wave's 64 rows of the four histograms come in and its 64 delta rows go out as whole
+// lines through LDS; the tables (52 KB for 379 + 342 biosamples) are copied into LDS once per block.
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float text_roundtrip_f5(float v);
+constexpr int PF_WAVES = 6;                          // 384 threads: 6 x 64 rows x (4 x 2 S + 4 S) bytes of staging next to the tables
+
+// SC: the state count at compile time (the loops over the states unroll and their 4 S LDS reads overlap -- with a run-time S and
+// six waves per CU the kernel waited out every read: 2.2 ms for 15 M bins against 0.9); 0 = any S.
+// d * d as numpy computes it -- rounded to float32 BEFORE it is added.  `__fmul_rn` + `__fadd_rn` are ordinary multiplies and adds to
+// the optimiser (hipcc's default -ffp-contract=fast comes with the header they are inlined from, not with this function's pragma):
+// in the loops unrolled for a compile-time S it fused them into v_fma_f32 and STEP 4's distance lost its last bit.  The empty asm is
+// opaque: the product exists as a register value before anything can be added to it.
+__device__ __forceinline__ float sq_nofma(float d) {
+    float p = d * d;
+    asm volatile("" : "+v"(p));
+    return p;
+}
+
+template <int SC>
+__global__ __launch_bounds__(64 * PF_WAVES) void k_pair_fused_s1(const u16* __restrict__ HA, const u16* __restrict__ HB, const u16* __restrict__ HnA,
+                                                                  const u16* __restrict__ HnB, long R, int S_, const float* __restrict__ TA,
+                                                                  int entA, const float* __restrict__ TB, int entB, const float* __restrict__ TnA,
+                                                                  int entnA, const float* __restrict__ TnB, int entnB, float* __restrict__ delta,
+                                                                  float* __restrict__ ndist, float* __restrict__ rdist, int* __restrict__ maxdiff) {
+#pragma clang fp contract(off)   // numpy squares, rounds, then adds: no fused multiply-add anywhere in here
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int S = SC ? SC : S_;
+    // tables first (a null table that is the real group's table is not copied twice), then the waves' staging areas
+    float* tA = reinterpret_cast<float*>(smem);
+    float* tB = tA + entA;
+    float* tnA = TnA == TA ? tA : tB + entB;
+    float* tnB = TnB == TB ? tB : (TnA == TA ? tB + entB : tnA + entnA);
+    float* tend = (TnB == TB ? (TnA == TA ? tB + entB : tnA + entnA) : tnB + entnB);
+    for (int e = threadIdx.x; e < entA; e += blockDim.x) tA[e] = TA[e];
+    for (int e = threadIdx.x; e < entB; e += blockDim.x) tB[e] = TB[e];
+    if (TnA != TA) for (int e = threadIdx.x; e < entnA; e += blockDim.x) tnA[e] = TnA[e];
+    if (TnB != TB) for (int e = threadIdx.x; e < entnB; e += blockDim.x) tnB[e] = TnB[e];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int hb = 2 * S, rowb = 4 * S;
+    const size_t tab_bytes = ((size_t)(reinterpret_cast<char*>(tend) - smem) + 15) & ~(size_t)15;
+    char* stage = smem + tab_bytes + (size_t)wave * 64 * (4 * hb + rowb);
+    char* sA = stage, *sB = sA + 64 * hb, *snA = sB + 64 * hb, *snB = snA + 64 * hb, *sD = snB + 64 * hb;
+    const long ntiles = (R + 63) >> 6;
+    for (long tile = (long)blockIdx.x * PF_WAVES + wave; tile < ntiles; tile += (long)gridDim.x * PF_WAVES) {
+        const long row0 = tile * 64;
+        const int rows = (int)(R - row0 < 64 ? R - row0 : 64);
+        load_staged(sA, reinterpret_cast<const char*>(HA + row0 * S), rows * hb, lane);
+        load_staged(sB, reinterpret_cast<const char*>(HB + row0 * S), rows * hb, lane);
+        load_staged(snA, reinterpret_cast<const char*>(HnA + row0 * S), rows * hb, lane);
+        load_staged(snB, reinterpret_cast<const char*>(HnB + row0 * S), rows * hb, lane);
+        __builtin_amdgcn_wave_barrier();
+        if (lane < rows) {
+            const u16* ha = reinterpret_cast<const u16*>(sA + lane * hb);
+            const u16* hbq = reinterpret_cast<const u16*>(sB + lane * hb);
+            const u16* hna = reinterpret_cast<const u16*>(snA + lane * hb);
+            const u16* hnb = reinterpret_cast<const u16*>(snB + lane * hb);
+            float* pd = reinterpret_cast<float*>(sD + lane * rowb);
+            // a score = the table entry of (count, state); count 0 scores 0 (k_score_s1_from_hist)
+            auto sc = [S](const float* t, u32 c, int s) { return c ? t[(long)c * S + s] : 0.0f; };
+            // delta and STEP 4's reduction of it: ascending states, "%.5f" round trip, ties to the higher state (k_pair_metrics)
+            float sq = 0.f, sd = 0.f, best = -1.f;
+            int arg = S;
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                const float d0 = sc(tA, ha[s], s) - sc(tB, hbq[s], s);
+                pd[s] = d0;
+                const float d = text_roundtrip_f5(d0);
+                sq = __fadd_rn(sq, sq_nofma(d));
+                sd = __fadd_rn(sd, d);
+                if (fabsf(d) >= best) { best = fabsf(d); arg = s + 1; }
+            }
+            const float sg = sd > 0.f ? 1.f : (sd < 0.f ? -1.f : sd);
+            rdist[row0 + lane] = __fmul_rn(sq, sg);
+            maxdiff[row0 + lane] = arg;
+            // the null distance: numpy's pairwise order over nd = nullA - nullB (k_pair_finish)
+            auto nd = [&](int s) { return sc(tnA, hna[s], s) - sc(tnB, hnb[s], s); };
+            float nsd, nsq;
+            if (S < 8) {
+                nsd = 0.f;
+                nsq = 0.f;
+                for (int s = 0; s < S; ++s) {
+                    const float d = nd(s);
+                    nsd += d;
+                    nsq += sq_nofma(d);
+                }
+            } else {
+                float rd[8], rq[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const float d = nd(k);
+                    rd[k] = d;
+                    rq[k] = sq_nofma(d);
+                }
+                int i = 8;
+                for (; i < S - (S % 8); i += 8) {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const float d = nd(i + k);
+                        rd[k] += d;
+                        rq[k] += sq_nofma(d);
+                    }
+                }
+                nsd = ((rd[0] + rd[1]) + (rd[2] + rd[3])) + ((rd[4] + rd[5]) + (rd[6] + rd[7]));
+                nsq = ((rq[0] + rq[1]) + (rq[2] + rq[3])) + ((rq[4] + rq[5]) + (rq[6] + rq[7]));
+                for (; i < S; ++i) {
+                    const float d = nd(i);
+                    nsd += d;
+                    nsq += sq_nofma(d);
+                }
+            }
+            const float nsg = nsd > 0.f ? 1.f : (nsd < 0.f ? -1.f : nsd);
+            ndist[row0 + lane] = nsq * nsg;
+        }
+        __builtin_amdgcn_wave_barrier();
+        store_staged(sD, reinterpret_cast<char*>(delta + row0 * S), rows * rowb, lane);
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+int pair_scores_s1_impl(const uint16_t* HA, const uint16_t* HB, const uint16_t* HnA, const uint16_t* HnB, int64_t R, int32_t S, int32_t NA,
+                        int32_t NB, int32_t ga, int32_t gb, const float* TA, const float* TB, const float* TnA, const float* TnB, float* delta,
+                        float* ndist, float* rdist, int32_t* maxdiff, hipStream_t st) {
+    if (R < 0 || S < 1 || S > 127 || NA < 1 || NB < 1 || ga < 1 || gb < 1) return fail(EPG_ERR_INVALID_ARG, "pair_scores_s1: bad shape");
+    if (R == 0) return EPG_OK;
+    if (!HA || !HB || !HnA || !HnB || !TA || !TB || !TnA || !TnB || !delta || !ndist || !rdist || !maxdiff)
+        return fail(EPG_ERR_INVALID_ARG, "pair_scores_s1: NULL argument");
+    if ((reinterpret_cast<uintptr_t>(HA) | reinterpret_cast<uintptr_t>(HB) | reinterpret_cast<uintptr_t>(HnA) | reinterpret_cast<uintptr_t>(HnB) |
+         reinterpret_cast<uintptr_t>(delta)) & 15)
+        return fail(EPG_ERR_INVALID_ARG, "pair_scores_s1: histograms and delta must be 16-byte aligned");
+    const int entA = (NA + 1) * S, entB = (NB + 1) * S, entnA = (ga + 1) * S, entnB = (gb + 1) * S;
+    size_t tab = (size_t)(entA + entB + (TnA == TA ? 0 : entnA) + (TnB == TB ? 0 : entnB)) * 4;
+    tab = (tab + 15) & ~(size_t)15;
+    const size_t shmem = tab + (size_t)PF_WAVES * 64 * (4 * 2 * S + 4 * S);
+    // the tables of wide groups do not fit next to the staging areas: the caller takes the four score passes, pair_finish and
+    // pair_metrics instead (same results)
+    if (shmem > 160 * 1024) return fail(EPG_ERR_UNSUPPORTED, "pair_scores_s1: %zu bytes of LDS needed for groups of %d / %d / %d / %d columns", shmem, NA, NB, ga, gb);
+    long blocks = ((R + 63) / 64 + PF_WAVES - 1) / PF_WAVES;
+    if (blocks > num_cus()) blocks = num_cus();
+#define PF_LAUNCH(SC)                                                                                                            \
+    do {                                                                                                                         \
+        static bool attr_set = false;                                                                                            \
+        if (!attr_set) {                                                                                                         \
+            EPG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pair_fused_s1<SC>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+            attr_set = true;                                                                                                     \
+        }                                                                                                                        \
+        hipLaunchKernelGGL(k_pair_fused_s1<SC>, dim3((unsigned)blocks), dim3(64 * PF_WAVES), shmem, st, HA, HB, HnA, HnB, (long)R, S, TA, entA, TB, \
+                           entB, TnA, entnA, TnB, entnB, delta, ndist, rdist, maxdiff);                                          \
+    } while (0)
+    if (S == 18) PF_LAUNCH(18);
+    else if (S == 15) PF_LAUNCH(15);
+    else if (S == 25) PF_LAUNCH(25);
+    else PF_LAUNCH(0);
+#undef PF_LAUNCH
+    EPG_LAUNCH_CHECK("k_pair_fused_s1");
+    return EPG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // host-side dispatch
 // ---------------------------------------------------------------------------------------------------------------
 int wide_hist_s2_from_binhist(const uint16_t* H, const uint16_t* H2, int64_t R, int32_t S, int64_t* counts, hipStream_t st);

@@ -294,6 +294,21 @@ def score_s3(X, N, S, q, want32=True, want64=False, ws=None):
     return o32, o64
 
 
+def pair_scores_s1_from_binhist(HA, HB, HnA, HnB, S, NA, NB, ga, gb, TA, TB, TnA, TnB):
+    """Paired S1 in one pass over the four histograms (epg_pair_scores_s1_from_binhist): delta [R, S], null distance [R], STEP 4's
+    distance [R] and 1-based largest-difference state [R].  T*: float32 [width + 1, S] device tables (scores.s1ScoreTable).
+    Raises EpilogosHipError(-2) when the tables do not fit a CU's LDS; the separate calls give the same results."""
+    R = HA.shape[0]
+    dev = HA.device
+    delta = torch.empty((R, S), dtype=torch.float32, device=dev)
+    null = torch.empty(R, dtype=torch.float32, device=dev)
+    dist = torch.empty(R, dtype=torch.float32, device=dev)
+    maxdiff = torch.empty(R, dtype=torch.int32, device=dev)
+    _abi.call("epg_pair_scores_s1_from_binhist", _ptr(HA), _ptr(HB), _ptr(HnA), _ptr(HnB), R, S, NA, NB, ga, gb, _ptr(TA), _ptr(TB), _ptr(TnA),
+              _ptr(TnB), _ptr(delta), _ptr(null), _ptr(dist), _ptr(maxdiff), _stream())
+    return delta, null, dist, maxdiff
+
+
 def pair_finish(a, b, want_dist=True):
     R, S = a.shape
     delta = torch.empty_like(a)

@@ -114,6 +114,19 @@ int epg_combine_score_s1(int64_t* counts, int32_t rezero, const uint16_t* H, int
 int epg_score_s1_from_binhist_table(const uint16_t* H, int64_t R, int32_t N, int32_t S, const double* T64, const float* T32,
                                     double* out64, float* out32, void* stream);
 
+/* Paired S1, everything between the null groups and the output files in one pass over the four per-bin histograms of a bin
+ * (real groups A, B of NA, NB columns; null groups of ga, gb columns): with the groups' S1 tables T*[c, s] (device, [width + 1, S]
+ * float32, as for epg_score_s1_from_binhist_table; a null table may be the same pointer as its real group's)
+ *   delta[bin, s]  = T_A[hA[s], s] - T_B[hB[s], s]                    (scores.py:223-226: float32 scores, float32 difference)
+ *   null_dist[bin] = sign(sum nd) * sum nd^2, nd = T_nA[hnA] - T_nB[hnB]  (scores.py:229-232, numpy's float32 pairwise order)
+ *   dist, maxdiff  = STEP 4's reduction of delta as it reads it back from the "%.5f" text (roiAndVisualPairwise.py:347-354)
+ * -- the results of four epg_score_s1_from_binhist_table, two epg_pair_finish and one epg_pair_metrics, bit for bit.
+ * EPG_ERR_UNSUPPORTED when the tables do not fit a CU's LDS next to the staging areas (groups of several thousand columns):
+ * the separate calls serve then. */
+int epg_pair_scores_s1_from_binhist(const uint16_t* HA, const uint16_t* HB, const uint16_t* HnA, const uint16_t* HnB, int64_t R, int32_t S,
+                                    int32_t NA, int32_t NB, int32_t ga, int32_t gb, const float* TA, const float* TB, const float* TnA,
+                                    const float* TnB, float* delta, float* null_dist, float* dist, int32_t* maxdiff, void* stream);
+
 /* S2: p[i,j] = (h_i*h_j - [i==j]*h_i) / perms, score[b, j] = sum_i kl(p[i,j], q[i,j]) in ascending i
  *     -- scores.py:347-452 s2Score/rowObsS2.  perms = N*(N-1) of the ORIGINAL group (scores.py:371,397-398). */
 int epg_score_s2(const int8_t* X, int64_t R, int32_t N, int64_t ldx, int32_t S, int64_t perms, const float* q,

@@ -348,3 +348,36 @@ def test_paired_scores_golden(eng, golden_pair):
         np.testing.assert_allclose(_np(o32), g["s1_" + key], rtol=2e-7, atol=0)
         o32, _ = eng.score_s2(X, 5, S, q2)
         np.testing.assert_allclose(_np(o32), g["s2_" + key], rtol=3e-7, atol=ATOL)
+
+
+@pytest.mark.parametrize("NA,NB,ga,gb,R", [(379, 342, 379, 342, 5000), (5, 5, 5, 5, 2048), (40, 33, 20, 20, 3001), (7, 9, 9, 7, 64), (12, 12, 12, 12, 1)])
+def test_paired_s1_in_one_pass_equals_the_separate_passes(eng, NA, NB, ga, gb, R):
+    """epg_pair_scores_s1_from_binhist (scores of A, B and the null groups as table gathers, delta, null distance, STEP 4's
+    reduction, one pass over the four histograms) against four epg_score_s1_from_binhist_table + two epg_pair_finish +
+    epg_pair_metrics: bit for bit, for equal and unequal null widths (-g) and ragged row counts; and against the oracle."""
+    from epilogos_amd.scores import s1ScoreTable
+    xa, xb = synth_states(R, NA, seed=NA), synth_states(R, NB, seed=NB + 1)
+    XA, XB = eng.states_to_device(xa), eng.states_to_device(xb)
+    HA, cA = eng.bin_hist(XA, NA, S)
+    HB, _ = eng.bin_hist(XB, NB, S, counts=cA)
+    q = eng.normalise(cA).cpu().numpy()
+    HnA, HnB = eng.null_hist_from_binhist(HA, HB, NA + NB, S, ga, gb, seed=3)
+    tabs = {}
+    for n in (NA, NB, ga, gb):
+        if n not in tabs:
+            tabs[n] = torch.from_numpy(s1ScoreTable(q, n)[1]).cuda()
+    delta, null, dist, mdiff = eng.pair_scores_s1_from_binhist(HA, HB, HnA, HnB, S, NA, NB, ga, gb, tabs[NA], tabs[NB], tabs[ga], tabs[gb])
+    sA, _ = eng.score_s1_from_binhist_table(HA, NA, S, T32=tabs[NA])
+    sB, _ = eng.score_s1_from_binhist_table(HB, NB, S, T32=tabs[NB])
+    nA, _ = eng.score_s1_from_binhist_table(HnA, ga, S, T32=tabs[ga])
+    nB, _ = eng.score_s1_from_binhist_table(HnB, gb, S, T32=tabs[gb])
+    d2, _ = eng.pair_finish(sA, sB, want_dist=False)
+    _, n2 = eng.pair_finish(nA, nB)
+    r2, m2 = eng.pair_metrics(d2, roundtrip=True)
+    assert torch.equal(delta, d2) and torch.equal(null, n2) and torch.equal(dist, r2) and torch.equal(mdiff, m2)
+    ref_a = onp.score_s1(xa, q, S).astype(np.float32)
+    ref_b = onp.score_s1(xb, q, S).astype(np.float32)
+    rd, _ = onp.pair_finish(ref_a, ref_b)
+    assert np.array_equal(_np(delta), rd)
+    wd, wx = onp.pair_metrics(rd, True)
+    assert np.array_equal(_np(dist), wd) and np.array_equal(_np(mdiff), wx)
