@@ -585,6 +585,16 @@ __device__ __forceinline__ void load_staged(char* lds, const char* src, int nbyt
         *reinterpret_cast<u32*>(lds + o) = *reinterpret_cast<const u32*>(src + o);
 }
 
+// d * d as numpy computes it -- rounded to float32 BEFORE it is added.  `__fmul_rn` + `__fadd_rn` are ordinary multiplies and adds to
+// the optimiser (hipcc's default -ffp-contract=fast comes with the header they are inlined from, not with this function's pragma):
+// in the loops unrolled for a compile-time S it fused them into v_fma_f32 and STEP 4's distance lost its last bit.  The empty asm is
+// opaque: the product exists as a register value before anything can be added to it.
+__device__ __forceinline__ float sq_nofma(float d) {
+    float p = d * d;
+    asm volatile("" : "+v"(p));
+    return p;
+}
+
 // One lane per row, rows handed over through LDS: a wave's 64 rows of a and b are 64*S contiguous floats each, fetched with
 // whole-line loads (a lane reading its own 72-byte row straight from memory made every load instruction touch 64 lines:
 // 1.37 ms for 15 M bins, 2.4 TB/s); the lane then walks its row in LDS with numpy's blocked order -- eight partial sums in
@@ -617,7 +627,7 @@ __global__ __launch_bounds__(256) void k_pair_finish(const float* __restrict__ a
                     const float d = pa[s] - pb[s];
                     pd[s] = d;
                     sd += d;
-                    sq += __fmul_rn(d, d);
+                    sq += sq_nofma(d);
                 }
             } else {
                 float rd[8], rq[8];
@@ -626,7 +636,7 @@ __global__ __launch_bounds__(256) void k_pair_finish(const float* __restrict__ a
                     const float d = pa[k] - pb[k];
                     pd[k] = d;
                     rd[k] = d;
-                    rq[k] = __fmul_rn(d, d);
+                    rq[k] = sq_nofma(d);
                 }
                 int i = 8;
                 for (; i < S - (S % 8); i += 8) {
@@ -635,7 +645,7 @@ __global__ __launch_bounds__(256) void k_pair_finish(const float* __restrict__ a
                         const float d = pa[i + k] - pb[i + k];
                         pd[i + k] = d;
                         rd[k] += d;
-                        rq[k] += __fmul_rn(d, d);
+                        rq[k] += sq_nofma(d);
                     }
                 }
                 sd = ((rd[0] + rd[1]) + (rd[2] + rd[3])) + ((rd[4] + rd[5]) + (rd[6] + rd[7]));
@@ -644,7 +654,7 @@ __global__ __launch_bounds__(256) void k_pair_finish(const float* __restrict__ a
                     const float d = pa[i] - pb[i];
                     pd[i] = d;
                     sd += d;
-                    sq += __fmul_rn(d, d);
+                    sq += sq_nofma(d);
                 }
             }
             if (dist) {
@@ -706,16 +716,6 @@ constexpr int PF_WAVES = 6;                          // 384 threads: 6 x 64 rows
 
 // SC: the state count at compile time (the loops over the states unroll and their 4 S LDS reads overlap -- with a run-time S and
 // six waves per CU the kernel waited out every read: 2.2 ms for 15 M bins against 0.9); 0 = any S.
-// d * d as numpy computes it -- rounded to float32 BEFORE it is added.  `__fmul_rn` + `__fadd_rn` are ordinary multiplies and adds to
-// the optimiser (hipcc's default -ffp-contract=fast comes with the header they are inlined from, not with this function's pragma):
-// in the loops unrolled for a compile-time S it fused them into v_fma_f32 and STEP 4's distance lost its last bit.  The empty asm is
-// opaque: the product exists as a register value before anything can be added to it.
-__device__ __forceinline__ float sq_nofma(float d) {
-    float p = d * d;
-    asm volatile("" : "+v"(p));
-    return p;
-}
-
 template <int SC>
 __global__ __launch_bounds__(64 * PF_WAVES) void k_pair_fused_s1(const u16* __restrict__ HA, const u16* __restrict__ HB, const u16* __restrict__ HnA,
                                                                   const u16* __restrict__ HnB, long R, int S_, const float* __restrict__ TA,
@@ -968,7 +968,7 @@ __global__ __launch_bounds__(256) void k_pair_metrics(const float* __restrict__ 
             for (int s = 0; s < S; ++s) {
                 float d = pr[s];
                 if (roundtrip) d = text_roundtrip_f5(d);
-                sq = __fadd_rn(sq, __fmul_rn(d, d));          // np.square, then a separate add: no fused multiply-add
+                sq = __fadd_rn(sq, sq_nofma(d));          // np.square, then a separate add: no fused multiply-add
                 sd = __fadd_rn(sd, d);
                 if (fabsf(d) >= best) { best = fabsf(d); arg = s + 1; }   // >= : ties go to the higher state
             }
