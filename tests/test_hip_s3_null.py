@@ -304,3 +304,45 @@ def test_null_hist_from_binhist_is_a_uniform_shuffle(eng):
     cov = np.cov(oa[:, 0], oa[:, 5])[0, 1]
     want = -NA * (8 / M) * (6 / M) * (M - NA) / (M - 1)
     assert abs(cov - want) < 0.05 * abs(want)
+
+
+def test_null_hist_from_binhist_large_categories_follow_the_hypergeometric_law(eng):
+    """The law of the histogram-based sampler on a wide row with large categories: same row repeated with 70, 45, 30, 9 and 3
+    columns per state plus 2 stateless ones -- means, variances, covariances within a group and across the two groups, and the
+    empirical pmfs against numpy's argsort shuffle (the reference's method, helpers.py:183-184), for the default group sizes and
+    for -g 40 (a third outcome: a column joins neither group).  (Written for a round-3 experiment that drew categories above 16
+    columns by hypergeometric inversion from the mode instead of column by column: exact and no faster -- a float64 division per
+    step of the walk costs what ten column draws do, and a loop per category makes a wave wait for its largest count in every
+    category -- so the column-by-column sampler stayed)"""
+    R, NA, NB = 40000, 90, 69
+    M = NA + NB
+    base = np.array([17] * 70 + [5] * 45 + [4] * 30 + [0] * 9 + [11] * 3 + [-1] * 2, dtype=np.int8)
+    assert base.size == M
+    rng = np.random.default_rng(1)
+    cols = rng.permutation(M)                                       # which group a column starts in does not matter
+    xa = np.tile(base[cols[:NA]], (R, 1))
+    xb = np.tile(base[cols[NA:]], (R, 1))
+    XA, XB = eng.states_to_device(xa), eng.states_to_device(xb)
+    HA, _ = eng.bin_hist(XA, NA, S, want_counts=False)
+    HB, _ = eng.bin_hist(XB, NB, S, want_counts=False)
+    comb = np.tile(base, (R, 1))
+    for ga, gb in ((NA, NB), (40, 40)):
+        OA, OB = eng.null_hist_from_binhist(HA, HB, M, S, ga, gb, seed=2024)
+        oa, ob = eng.hist_to_numpy(OA).astype(np.float64), eng.hist_to_numpy(OB).astype(np.float64)
+        sh = onp.shuffle_rows(comb, np.random.default_rng(ga).random(comb.shape))
+        ra, rb = sh[:, :ga], sh[:, ga:ga + gb]
+        for s, K in ((17, 70), (5, 45), (4, 30), (0, 9), (11, 3)):
+            for o, r, n in ((oa, ra, ga), (ob, rb, gb)):
+                mean = n * K / M
+                var = n * (K / M) * (1 - K / M) * (M - n) / (M - 1)
+                assert abs(o[:, s].mean() - mean) < 5 * np.sqrt(var / R), (s, ga)
+                assert abs(o[:, s].var() - var) < 0.06 * var, (s, ga)
+                pm_new = np.bincount(o[:, s].astype(int), minlength=n + 1) / R
+                pm_ref = np.bincount((r == s).sum(axis=1), minlength=n + 1) / R
+                assert np.abs(pm_new - pm_ref).max() < 0.012, (s, ga)
+        # joint laws: two large categories within A; one category across A and B
+        want = -ga * (70 / M) * (45 / M) * (M - ga) / (M - 1)
+        assert abs(np.cov(oa[:, 17], oa[:, 5])[0, 1] - want) < 0.06 * abs(want)
+        want_ab = -ga * gb * (70 / M) * (1 - 70 / M) / (M - 1)
+        assert abs(np.cov(oa[:, 17], ob[:, 17])[0, 1] - want_ab) < 0.06 * abs(want_ab)
+        assert (oa.sum(axis=1) + (oa[:, :0].sum(axis=1)) <= ga).all() and (oa + ob <= np.bincount(base[base >= 0], minlength=S)).all()
