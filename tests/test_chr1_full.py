@@ -142,6 +142,17 @@ def test_hip_s2_and_paired_on_full_chr1(g):
     np.testing.assert_allclose(delta.cpu().numpy(), ref_delta, rtol=0, atol=2e-7)
     m = engine.quiescent(XA, 5, XB, 5, S - 1)
     assert int(m.sum().item()) == int(g["pair_quiescent_count"])
+    # the command line's route (round 3): tables from the host, all of it in one pass over the histograms -- the reference's
+    # float32 deltas bit for bit, on all 1 246 253 bins
+    from epilogos_amd.scores import s1ScoreTable
+    HA, _ = engine.bin_hist(XA, 5, S, want_counts=False)
+    HB, _ = engine.bin_hist(XB, 5, S, want_counts=False)
+    t5 = torch.from_numpy(s1ScoreTable(g["pair_exp"], 5)[1]).cuda()
+    HnA, HnB = engine.null_hist_from_binhist(HA, HB, 10, S, 5, 5, seed=1)
+    d1, _null, rdist, mdiff = engine.pair_scores_s1_from_binhist(HA, HB, HnA, HnB, S, 5, 5, 5, 5, t5, t5, t5, t5)
+    assert np.array_equal(d1.cpu().numpy(), ref_delta)
+    wd, wx = onp.pair_metrics(ref_delta, True)
+    assert np.array_equal(rdist.cpu().numpy(), wd) and np.array_equal(mdiff.cpu().numpy(), wx)
 
 
 @pytest.mark.gpu
