@@ -36,6 +36,7 @@ import argparse
 import json
 import os
 import sys
+import threading
 import time
 from pathlib import Path
 
@@ -311,6 +312,9 @@ def main():
     ap.add_argument("--configs", default="s2,s3,paired", help="BASELINE configs 3-5 measured next to the headline: any of s2,s3,paired; none")
     ap.add_argument("--s3-bins", type=int, default=2_000_000, help="bins of the S3 measurement (whole job, all ranks)")
     ap.add_argument("--config-reps", type=int, default=3)
+    ap.add_argument("--extras-deadline", type=int, default=900,
+                    help="seconds the measurements after the timed region (placement experiment, --configs) may take before rank 0 "
+                         "prints the line without the rest and every rank exits; 0 = no limit")
     ap.add_argument("--graph", action="store_true", help="capture the step (K1, all-reduce, combine, score) in a hipGraph and replay it "
                                                          "(kernels_ms then comes from an un-captured probe after the timed region)")
     ap.add_argument("--pg", action="store_true", help="one GPU: still join a one-rank RCCL process group, so that the step contains the all-reduce")
@@ -473,45 +477,13 @@ def main():
         allreduce_probe = {"tensor": "int64[%d]" % S, "calls": n_ar, "device_us_per_call_back_to_back": round(e0.elapsed_time(e1) / n_ar * 1e3, 2),
                            "host_us_per_call": round(host_us, 2), "backend": args.backend, "world": world}
 
-    # ---- secondary: the histogram cache in another memory class than the matrix (not what the product does: DESIGN.md 3)
+    # ---- the line: everything the timed region produced is in it from here on; what follows (placement experiment, BASELINE
+    # configs 3-5) fills `placement` and `configs` in.  A watchdog on every rank bounds those extras: past --extras-deadline
+    # seconds rank 0 prints the line with what it has and every rank leaves, so that a collective that never completes in a
+    # secondary measurement cannot take the headline of a multi-GPU run with it.
     placement = {"headline": "plain torch allocations for X, H and the scores -- the same code path as backend._HipSession"}
-    if args.placement_experiment and R * X.stride(0) >= (1 << 30) and not args.packed:
-        try:
-            Hp, rep = engine.place_hist(X, N, S, park=True)
-            dtp, evp, _ = timed_steps(Hp, min(args.steps, 10), 2)
-            rep["k_bin_hist_ms"] = round(float(np.mean([e[0].elapsed_time(e[1]) for e in evp])), 4)
-            rep["frac"] = round(R * N / (rep["k_bin_hist_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)
-            rep["ms_per_step"] = round(dtp / min(args.steps, 10) * 1e3, 4)
-            placement["experiment"] = rep
-            del Hp
-        except Exception as e:                 # an experiment: never let it take the measurement down
-            placement["experiment"] = {"failed": repr(e)[:200]}
-        engine.release_parked()
-
-    # ---- BASELINE configs 3-5 through the product's sessions
-    want = [] if args.configs in ("none", "") else [c.strip() for c in args.configs.split(",") if c.strip()]
     configs = {}
-    if want:
-        from epilogos_amd import backend as _backend
-        from epilogos_amd.driver import _Dist
-        be = _backend.HipBackend(device=dev)
-        d = _Dist()
-        for name in want:
-            try:
-                if name == "s2":
-                    configs["s2"] = bench_single(torch, be, d, 2, X, N, S, R, R_global, world, args.config_reps, fence)
-                elif name == "s3":
-                    r3g = min(args.s3_bins, R_global)
-                    lo, hi = rank * r3g // world, (rank + 1) * r3g // world
-                    configs["s3"] = bench_single(torch, be, d, 3, X[: hi - lo], N, S, hi - lo, r3g, world, args.config_reps, fence)
-                elif name == "paired":
-                    configs["paired"] = bench_paired(torch, be, d, R, R_global, bin0, S, world, args.config_reps, fence, dev, args.dist)
-                else:
-                    configs[name] = {"error": "unknown config"}
-            except Exception as e:
-                configs[name] = {"error": repr(e)[:300]}
-            torch.cuda.empty_cache()
-
+    line = None
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
         value = R_global * args.steps / dt / 1e6
@@ -556,7 +528,70 @@ def main():
             "configs": configs,
             "cpu_baseline": cpu,
         }
-        print(json.dumps(line), flush=True)
+    emitted = threading.Lock()
+
+    def emit():
+        if rank == 0 and emitted.acquire(blocking=False):
+            for attempt in range(5):                       # the watchdog may serialise while the main thread adds a config
+                try:
+                    text = json.dumps(line)
+                    break
+                except RuntimeError:
+                    time.sleep(0.01)
+            print(text, flush=True)
+
+    def bail():
+        configs["deadline"] = "extras stopped after %d s (--extras-deadline)" % args.extras_deadline
+        emit()
+        sys.stdout.flush()
+        os._exit(0)
+
+    watchdog = None
+    if args.extras_deadline > 0:
+        watchdog = threading.Timer(args.extras_deadline, bail)
+        watchdog.daemon = True
+        watchdog.start()
+
+    # ---- secondary: the histogram cache in another memory class than the matrix (not what the product does: DESIGN.md 3)
+    if args.placement_experiment and R * X.stride(0) >= (1 << 30) and not args.packed:
+        try:
+            Hp, rep = engine.place_hist(X, N, S, park=True)
+            dtp, evp, _ = timed_steps(Hp, min(args.steps, 10), 2)
+            rep["k_bin_hist_ms"] = round(float(np.mean([e[0].elapsed_time(e[1]) for e in evp])), 4)
+            rep["frac"] = round(R * N / (rep["k_bin_hist_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)
+            rep["ms_per_step"] = round(dtp / min(args.steps, 10) * 1e3, 4)
+            placement["experiment"] = rep
+            del Hp
+        except Exception as e:                 # an experiment: never let it take the measurement down
+            placement["experiment"] = {"failed": repr(e)[:200]}
+        engine.release_parked()
+
+    # ---- BASELINE configs 3-5 through the product's sessions
+    want = [] if args.configs in ("none", "") else [c.strip() for c in args.configs.split(",") if c.strip()]
+    if want:
+        from epilogos_amd import backend as _backend
+        from epilogos_amd.driver import _Dist
+        be = _backend.HipBackend(device=dev)
+        d = _Dist()
+        for name in want:
+            try:
+                if name == "s2":
+                    configs["s2"] = bench_single(torch, be, d, 2, X, N, S, R, R_global, world, args.config_reps, fence)
+                elif name == "s3":
+                    r3g = min(args.s3_bins, R_global)
+                    lo, hi = rank * r3g // world, (rank + 1) * r3g // world
+                    configs["s3"] = bench_single(torch, be, d, 3, X[: hi - lo], N, S, hi - lo, r3g, world, args.config_reps, fence)
+                elif name == "paired":
+                    configs["paired"] = bench_paired(torch, be, d, R, R_global, bin0, S, world, args.config_reps, fence, dev, args.dist)
+                else:
+                    configs[name] = {"error": "unknown config"}
+            except Exception as e:
+                configs[name] = {"error": repr(e)[:300]}
+            torch.cuda.empty_cache()
+
+    if watchdog is not None:
+        watchdog.cancel()
+    emit()
     if use_pg:
         dist.destroy_process_group()
 

@@ -413,3 +413,25 @@ def test_bench_strong_scaling_two_ranks_on_one_gpu(tmp_path):
     for l in (s, w):
         assert abs(l["value"] - l["config"]["bins_total"] / l["ms_per_step"] / 1e3) < 1e-2 * l["value"]
         assert l["roofline"]["bound"] == "hbm" and l["unit"] == "Mbins/s"
+
+
+def test_bench_extras_deadline_keeps_the_headline(tmp_path):
+    """The measurements after the timed region run under a watchdog: with a deadline they cannot meet, rank 0 still prints the
+    one JSON line (headline, roofline, kernels) with a note instead of the remaining configs, and both ranks exit with 0."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parents[1]
+    port = str(free_port())
+    env = dict(os.environ, PYTHONPATH=str(root), MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", port, str(root / "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--bins", "2000001",
+           "--backend", "gloo", "--no-cpu-baseline", "--config-reps", "200", "--extras-deadline", "2"]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=str(root))
+    assert res.returncode == 0, res.stdout + res.stderr
+    out = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(out) == 1
+    line = json.loads(out[0])
+    assert line["value"] > 0 and line["roofline"]["frac"] > 0 and "deadline" in line["configs"]
