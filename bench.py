@@ -553,7 +553,7 @@ def main():
         watchdog.start()
 
     # ---- secondary: the histogram cache in another memory class than the matrix (not what the product does: DESIGN.md 3)
-    if args.placement_experiment and R * X.stride(0) >= (1 << 30) and not args.packed:
+    if args.placement_experiment and world == 1 and R * X.stride(0) >= (1 << 30) and not args.packed:   # a single-GPU experiment
         try:
             Hp, rep = engine.place_hist(X, N, S, park=True)
             dtp, evp, _ = timed_steps(Hp, min(args.steps, 10), 2)
