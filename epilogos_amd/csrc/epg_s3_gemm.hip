@@ -43,11 +43,14 @@ constexpr int G_BLK = 96;                               // rows of a wave's bloc
 constexpr int G_BM = G_WM * G_BLK, G_BN = G_WN * G_BLK; // rows of C per workgroup
 constexpr int G_TA = G_BM / 32, G_TB = G_BN / 32;       // operand tiles per k-step
 constexpr int G_KS = 2;                                 // k-steps (of 64 bins) per stage
-constexpr int G_STAGES = 3;                             // LDS ring depth; loads run two to three stages ahead
 constexpr int G_LOADS = (G_KS * (G_TA + G_TB) + G_NW - 1) / G_NW;   // 1 KiB LDS-DMA loads per wave and stage (6; 5 of 40 slots for 2 x 4)
 constexpr int G_LA = G_LOADS - 3;                       // of which between the MFMAs of a stage's first / second k-step: G_LA / 3
-constexpr int G_STAGE_BYTES = G_NW * G_LOADS * 1024;
-constexpr int G_LDS_BYTES = G_STAGES * G_STAGE_BYTES + G_NW * 1024;   // ring + one scrap KiB per wave for the tail's dummy loads
+constexpr int G_STAGE_TILES = G_KS * (G_TA + G_TB);     // 36 for 2 x 4 waves: the surplus load slots (36..39) land in the scrap
+constexpr int G_STAGE_BYTES = G_STAGE_TILES * 1024;
+// LDS ring of STAGES stages (template parameter of the kernel: 3 or 4) + one scrap KiB per wave for dummy / surplus loads
+__host__ __device__ constexpr int g_lds_bytes(int stages) { return stages * G_STAGE_BYTES + G_NW * 1024; }
+constexpr int G_RING_DEFAULT = 3;
+static_assert(g_lds_bytes(4) <= 160 * 1024, "the ring of four must fit a CU's LDS");
 constexpr int G_PATCH_P = 8, G_PATCH_Q = G_WN == 2 ? 8 : 4;           // workgroup ordering: patches of the (P, Q) task grid
 static_assert(G_LA == 2 || G_LA == 3, "five or six loads per wave and stage");
 constexpr long G_KC_MAX = 1048576;                      // bins per chunk the workspace size is quoted for (multiple of 512; < 2^24)
@@ -128,14 +131,15 @@ __device__ __forceinline__ void g_wait_lds(GOps& o) {
                                                                 acc[I][J], 4, 4, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f)
 
 // nine MFMAs of one k-step (fp4 operands: four registers are read)
+template <bool PRIO = true>
 __device__ __forceinline__ void g_mfma(const GOps& o, bool active, v16f (&acc)[3][3]) {
     if (!active) return;
-    __builtin_amdgcn_s_setprio(1);
+    if (PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int a = 0; a < 3; ++a)
 #pragma unroll
         for (int b = 0; b < 3; ++b) G_MFMA(a, b);
-    __builtin_amdgcn_s_setprio(0);
+    if (PRIO) __builtin_amdgcn_s_setprio(0);
 }
 
 // The same with the wave's five LDS-DMA loads of a later stage spread between the MFMAs.  Issuing an LDS-DMA load costs the
@@ -168,117 +172,14 @@ __device__ __forceinline__ void g_mfma_loads(const GOps& o, bool active, v16f (&
     __builtin_amdgcn_s_setprio(0);
 }
 
-__global__ __launch_bounds__(64 * G_NW, 2) void k_s3_syrk_fp4(const char* __restrict__ E4, int NT, long nstages, long stages_per_split,
-                                                         const int* __restrict__ tasks, int ntasks, int N, int S,
-                                                         int* __restrict__ counts, int dbg, const int* __restrict__ gate, int want,
-                                                         int* __restrict__ marg) {
-    if (gate && *gate != want) return;
-    extern __shared__ __attribute__((aligned(1024))) char smem[];
-    const int lane = threadIdx.x & 63;
-    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int wm = w / G_WN, wn = w % G_WN;
-    // XCD b % 8 takes a contiguous run of the patch-ordered task list (bijective for any ntasks)
-    const int xcd = blockIdx.x & 7, q8 = ntasks >> 3, r8 = ntasks & 7;
-    const int tix = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (blockIdx.x >> 3);
-    const int task = tasks[tix];
-    const int P = task & 0xffff, Q = task >> 16;
-    const int bm = G_WM * P + wm, bn = G_WN * Q + wn;
-    const bool active = bm <= bn && !(dbg & 8);                             // wave-uniform (dbg 8: data path only, no MFMAs)
-    const long g0 = (long)blockIdx.y * stages_per_split;
-    const int G = (int)(nstages - g0 < stages_per_split ? nstages - g0 : stages_per_split);   // < 2^24 / 128
-    if (G <= 0) return;
-
-    // this wave's five load slots of a stage: slot = w + 8 j -> (k-step, tile) -> source offset inside the stage's two k-steps
-    long soff[G_LOADS];
-    u32 doff[G_LOADS];
-#pragma unroll
-    for (int j = 0; j < G_LOADS; ++j) {
-        const int slot = w + G_NW * j;
-        const int s = slot < G_KS * (G_TA + G_TB) ? slot : 0;              // surplus slots (2 x 4 waves: 36..39): a harmless duplicate
-        const int ks = s / (G_TA + G_TB), t = s - ks * (G_TA + G_TB);
-        const int gt = (dbg & 1) ? t : (t < G_TA ? P * G_TA + t : Q * G_TB + (t - G_TA));   // dbg 1: every workgroup the same panels
-        soff[j] = ((long)ks * NT + gt) * 1024 + lane * 16;
-        doff[j] = (u32)slot * 1024;
-    }
-    const char* src0 = E4 + g0 * G_KS * (long)NT * 1024;
-    const long stage_stride = (long)G_KS * NT * 1024;
-    auto issue1 = [&](int g, int slot, int j) {
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src0 + g * stage_stride + soff[j]),
-                                         (__attribute__((address_space(3))) void*)(smem + slot * G_STAGE_BYTES + doff[j]), 16, 0, 0);
-    };
-    auto issue = [&](int g, int slot) {
-#pragma unroll
-        for (int j = 0; j < G_LOADS; ++j) issue1(g, slot, j);
-    };
-
-    v16f acc[3][3];
-#pragma unroll
-    for (int a = 0; a < 3; ++a)
-#pragma unroll
-        for (int b = 0; b < 3; ++b)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-
-    const u32 lds0 = (u32)(uintptr_t)smem + (u32)lane * 16;
-    const u32 baseA = lds0 + (u32)(wm * 3) * 1024, baseB = lds0 + (u32)(G_TA + wn * 3) * 1024;
-    // Software pipeline.  LDS-DMA runs two to three stages ahead (ring of three: a stage's slot is refilled only after the
-    // barrier that every wave passes once its last operands of that stage sit in registers).  The operand tiles of k-step
-    // k + 1 are requested BEFORE the nine MFMAs of k-step k are issued and waited for after them, so the 48 KiB a
-    // workgroup reads from LDS per k-step (~190 LDS cycles) and the read latency hide under matrix work instead of
-    // standing between the two waves of a SIMD after every barrier (first version: 2400 cycles per stage for 1584 of MFMA).
-    issue(0, 0);
-    issue(G > 1 ? 1 : 0, 1);                               // a chunk shorter than the pipeline refetches stage 0: never read
-#pragma unroll
-    for (int j = G_LA; j < G_LOADS; ++j) issue1(G > 2 ? 2 : 0, 2, j);  // stage 2's first G_LA loads go out in the loop's first turn
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G_LOADS + 3) : "memory");
-    __builtin_amdgcn_s_barrier();
-    GOps o0, o1;
-    g_read<0>(o0, baseA, baseB);
-    g_wait_lds(o0);
-    // A wave's five DMA loads of a stage go out between MFMAs, two in one batch and three in the next, never in a row:
-    // issuing an LDS-DMA load holds a wave up for 60-180 cycles, and the two waves of a SIMD reach the same point together.
-    // Stage g + 2 is fetched into the slot of stage g - 1: loads j = 2, 3, 4 between the MFMAs of k-step 1 of stage g - 1
-    // (after that turn's barrier: the slot is free) and j = 0, 1 between those of k-step 0 of stage g.  Issue order per wave:
-    // ... s(g+1){2,3,4} s(g+1){0,1} s(g+2){2,3,4} s(g+2){0,1} | wait for stage g + 1 = vmcnt(5).  Past the last stage the
-    // same instructions fetch stage 0 into the ring's scrap slots, so the loop has no load-dependent control flow.
-    auto loads_for = [&](int gs, int into_slot) {
-        const bool real = gs < G && !(dbg & 16);           // dbg 16: no operand traffic in the loop (dummy loads of stage 0)
-        const char* lsrc = src0 + (real ? (long)gs * stage_stride : 0L);
-        char* ldst = smem + into_slot * G_STAGE_BYTES;
-        return [=, &soff, &doff](int j) {
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(lsrc + soff[j]),
-                                             (__attribute__((address_space(3))) void*)(real ? ldst + doff[j] : smem + G_STAGES * G_STAGE_BYTES + w * 1024), 16, 0, 0);
-        };
-    };
-    int slot = 0, slot_prev = G_STAGES - 1;                // ring slots of stage g and g - 1 (no division in the loop)
-    for (int g = 0; g < G; ++g) {
-        const u32 so = (u32)slot * G_STAGE_BYTES;
-        const int slot1 = slot == G_STAGES - 1 ? 0 : slot + 1;
-        g_read<1>(o1, baseA + so, baseB + so);
-        g_mfma_loads<0, G_LA>(o0, active, acc, loads_for(g + 2, slot_prev));
-        g_wait_lds(o1);
-        if (g + 1 < G) {
-            // stage g + 1: this wave's loads have landed (the five of stage g + 2 -- real or, at the tail, dummies -- stay in
-            // flight); after the barrier everybody's.  Every wave that reaches the barrier holds its last operands of stage g
-            // in registers: the slot is free.
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G_LOADS) : "memory");
-            __builtin_amdgcn_s_barrier();
-            const u32 sn = (u32)slot1 * G_STAGE_BYTES;
-            g_read<0>(o0, baseA + sn, baseB + sn);
-        }
-        g_mfma_loads<G_LA, 3>(o1, active, acc, loads_for(g + 3, slot));
-        if (g + 1 < G) g_wait_lds(o0);
-        slot_prev = slot;
-        slot = slot1;
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the tail's dummy loads
-    __builtin_amdgcn_s_barrier();
-    // Epilogue.  Direct cells C[a,b,i,j]: a lane holds column n = (b, j), consecutive lanes consecutive j -- the atomics of
-    // one instruction fall into a few 72-byte runs.  Mirrored cells C[b,a,j,i] want consecutive lanes on consecutive i, i.e.
-    // lanes along m: the tile goes through a padded 32 x 33 LDS scratch (the ring is free once every wave has passed the
-    // barrier below) and comes back transposed.  With lanes along n the mirrored atomics touched 32 lines per instruction
-    // and an epilogue cost ~1.8 ms per launch (3.5-3.9 ms per chunk with the two K splits).
-    if (!active || (dbg & 2)) return;                     // dbg 2: no epilogue (measurements only)
+// Epilogue of both contraction kernels (the LDS ring is free: every wave has passed a barrier after its last operand read).
+// Direct cells C[a,b,i,j]: a lane holds column n = (b, j), consecutive lanes consecutive j -- the atomics of
+// one instruction fall into a few 72-byte runs.  Mirrored cells C[b,a,j,i] want consecutive lanes on consecutive i, i.e.
+// lanes along m: the tile goes through a padded 32 x 33 LDS scratch (the ring is free once every wave has passed the
+// barrier below) and comes back transposed.  With lanes along n the mirrored atomics touched 32 lines per instruction
+// and an epilogue cost ~1.8 ms per launch (3.5-3.9 ms per chunk with the two K splits).
+__device__ __forceinline__ void g_epilogue(v16f (&acc)[3][3], char* smem, int w, int lane, int bm, int bn, int N, int S,
+                                           int* __restrict__ counts, int* __restrict__ marg) {
     const int NS = N * S;
     const long SS = (long)S * S;
     float* scr = reinterpret_cast<float*>(smem) + w * (32 * 33);
@@ -318,6 +219,308 @@ __global__ __launch_bounds__(64 * G_NW, 2) void k_s3_syrk_fp4(const char* __rest
                 __builtin_amdgcn_wave_barrier();
             }
         }
+}
+
+template <int G_STAGES>
+__global__ __launch_bounds__(64 * G_NW, 2) void k_s3_syrk_fp4(const char* __restrict__ E4, int NT, long nstages, long stages_per_split,
+                                                         const int* __restrict__ tasks, int ntasks, int N, int S,
+                                                         int* __restrict__ counts, int dbg, const int* __restrict__ gate, int want,
+                                                         int* __restrict__ marg) {
+    if (gate && *gate != want) return;
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = w / G_WN, wn = w % G_WN;
+    // XCD b % 8 takes a contiguous run of the patch-ordered task list (bijective for any ntasks)
+    const int xcd = blockIdx.x & 7, q8 = ntasks >> 3, r8 = ntasks & 7;
+    const int tix = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (blockIdx.x >> 3);
+    const int task = tasks[tix];
+    const int P = task & 0xffff, Q = task >> 16;
+    const int bm = G_WM * P + wm, bn = G_WN * Q + wn;
+    const bool active = bm <= bn && !(dbg & 8);                             // wave-uniform (dbg 8: data path only, no MFMAs)
+    const long g0 = (long)blockIdx.y * stages_per_split;
+    const int G = (int)(nstages - g0 < stages_per_split ? nstages - g0 : stages_per_split);   // < 2^24 / 128
+    if (G <= 0) return;
+
+    // this wave's five load slots of a stage: slot = w + 8 j -> (k-step, tile) -> source offset inside the stage's two k-steps
+    long soff[G_LOADS];
+    u32 doff[G_LOADS];
+    bool surplus[G_LOADS];
+    char* const scrap = smem + G_STAGES * G_STAGE_BYTES + w * 1024;
+#pragma unroll
+    for (int j = 0; j < G_LOADS; ++j) {
+        const int slot = w + G_NW * j;
+        surplus[j] = slot >= G_STAGE_TILES;                                // 2 x 4 waves: slots 36..39, a duplicate load into the scrap
+        const int s = surplus[j] ? 0 : slot;
+        const int ks = s / (G_TA + G_TB), t = s - ks * (G_TA + G_TB);
+        const int gt = (dbg & 1) ? t : (t < G_TA ? P * G_TA + t : Q * G_TB + (t - G_TA));   // dbg 1: every workgroup the same panels
+        soff[j] = ((long)ks * NT + gt) * 1024 + lane * 16;
+        doff[j] = (u32)slot * 1024;
+    }
+    const char* src0 = E4 + g0 * G_KS * (long)NT * 1024;
+    const long stage_stride = (long)G_KS * NT * 1024;
+    auto issue1 = [&](int g, int slot, int j) {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src0 + g * stage_stride + soff[j]),
+                                         (__attribute__((address_space(3))) void*)(surplus[j] ? scrap : smem + slot * G_STAGE_BYTES + doff[j]), 16, 0, 0);
+    };
+    auto issue = [&](int g, int slot) {
+#pragma unroll
+        for (int j = 0; j < G_LOADS; ++j) issue1(g, slot, j);
+    };
+
+    v16f acc[3][3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    const u32 lds0 = (u32)(uintptr_t)smem + (u32)lane * 16;
+    const u32 baseA = lds0 + (u32)(wm * 3) * 1024, baseB = lds0 + (u32)(G_TA + wn * 3) * 1024;
+    // Software pipeline.  LDS-DMA runs two to three stages ahead (ring of three: a stage's slot is refilled only after the
+    // barrier that every wave passes once its last operands of that stage sit in registers).  The operand tiles of k-step
+    // k + 1 are requested BEFORE the nine MFMAs of k-step k are issued and waited for after them, so the 48 KiB a
+    // workgroup reads from LDS per k-step (~190 LDS cycles) and the read latency hide under matrix work instead of
+    // standing between the two waves of a SIMD after every barrier (first version: 2400 cycles per stage for 1584 of MFMA).
+    issue(0, 0);
+#pragma unroll
+    for (int s = 1; s < G_STAGES - 1; ++s) issue(G > s ? s : 0, s);   // a chunk shorter than the pipeline refetches stage 0: never read
+#pragma unroll
+    for (int j = G_LA; j < G_LOADS; ++j)                   // the last ring slot's first G_LA loads go out in the loop's first turn
+        issue1(G > G_STAGES - 1 ? G_STAGES - 1 : 0, G_STAGES - 1, j);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((G_STAGES - 2) * G_LOADS + 3) : "memory");
+    __builtin_amdgcn_s_barrier();
+    GOps o0, o1;
+    g_read<0>(o0, baseA, baseB);
+    g_wait_lds(o0);
+    // A wave's five DMA loads of a stage go out between MFMAs, two in one batch and three in the next, never in a row:
+    // issuing an LDS-DMA load holds a wave up for 60-180 cycles, and the two waves of a SIMD reach the same point together.
+    // Stage g + 2 is fetched into the slot of stage g - 1: loads j = 2, 3, 4 between the MFMAs of k-step 1 of stage g - 1
+    // (after that turn's barrier: the slot is free) and j = 0, 1 between those of k-step 0 of stage g.  Issue order per wave:
+    // ... s(g+1){2,3,4} s(g+1){0,1} s(g+2){2,3,4} s(g+2){0,1} | wait for stage g + 1 = vmcnt(5).  Past the last stage the
+    // same instructions fetch stage 0 into the ring's scrap slots, so the loop has no load-dependent control flow.
+    auto loads_for = [&](int gs, int into_slot) {
+        const bool real = gs < G && !(dbg & 16);           // dbg 16: no operand traffic in the loop (dummy loads of stage 0)
+        const char* lsrc = src0 + (real ? (long)gs * stage_stride : 0L);
+        char* ldst = smem + into_slot * G_STAGE_BYTES;
+        return [=, &soff, &doff, &surplus](int j) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(lsrc + soff[j]),
+                                             (__attribute__((address_space(3))) void*)(real && !surplus[j] ? ldst + doff[j] : scrap), 16, 0, 0);
+        };
+    };
+    int slot = 0, slot_prev = G_STAGES - 1;                // ring slots of stage g and g - 1 (no division in the loop)
+    for (int g = 0; g < G; ++g) {
+        const u32 so = (u32)slot * G_STAGE_BYTES;
+        const int slot1 = slot == G_STAGES - 1 ? 0 : slot + 1;
+        g_read<1>(o1, baseA + so, baseB + so);
+        g_mfma_loads<0, G_LA>(o0, active, acc, loads_for(g + G_STAGES - 1, slot_prev));
+        g_wait_lds(o1);
+        if (g + 1 < G) {
+            // stage g + 1: this wave's loads have landed (the five of stage g + 2 -- real or, at the tail, dummies -- stay in
+            // flight); after the barrier everybody's.  Every wave that reaches the barrier holds its last operands of stage g
+            // in registers: the slot is free.
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((G_STAGES - 2) * G_LOADS) : "memory");
+            __builtin_amdgcn_s_barrier();
+            const u32 sn = (u32)slot1 * G_STAGE_BYTES;
+            g_read<0>(o0, baseA + sn, baseB + sn);
+        }
+        g_mfma_loads<G_LA, 3>(o1, active, acc, loads_for(g + G_STAGES, slot));
+        if (g + 1 < G) g_wait_lds(o0);
+        slot_prev = slot;
+        slot = slot1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the tail's dummy loads
+    __builtin_amdgcn_s_barrier();
+    if (!active || (dbg & 2)) return;                     // dbg 2: no epilogue (measurements only)
+    g_epilogue(acc, smem, w, lane, bm, bn, N, S, counts, marg);
+}
+
+// ---- the same contraction with the two waves of a SIMD in opposite phases ("ping-pong", round 3) ---------------------------
+// In k_s3_syrk_fp4 all eight waves of the workgroup run the same phase at the same time: the partners on a SIMD issue their
+// operand reads, their DMA pieces and their MFMAs together, and the matrix pipe idles whenever both are busy with something
+// else (1735 cycles per stage for 1274 of matrix work).  Here waves 0-3 ("X") and their SIMD partners 4-7 ("Y") alternate
+// half a stage apart, a barrier after every half:
+//     half 2t     X: the 18 MFMAs of stage t (both k-steps sit in 48 registers)      Y: ds_read stage t, DMA its share of stage t - 1 + R
+//     half 2t + 1 X: ds_read stage t + 1, DMA its share of stage t + R               Y: the 18 MFMAs of stage t
+// so a SIMD's matrix pipe is fed by one wave while the other does everything that is not matrix work.  The 36 tiles of a stage
+// are fetched by X (5 per wave) and Y (4 per wave) with no surplus load; the ring holds R = 4 stages: the slot of stage t is
+// free once Y has read it (end of half 2t) and takes stage t + R in the next two halves, which X reads in half 2t + 2R - 1 --
+// every wave waits for its own pieces at the end of a load half with the two most recent batches still in flight (a batch has
+// four halves, about two stages, to land).  Past the last stage the same instructions fetch stage 0 into the scrap.
+// the main loop of one role (ROLE 0: compute first; ROLE 1: load first), NL = pieces of a stage this wave fetches
+template <int R, int ROLE, int MODE, bool TRACE>
+__device__ __forceinline__ void g_pp_loop(v16f (&acc)[3][3], char* smem, char* scrap, const char* src0, long stage_stride, const u32 (&soff)[5],
+                                          const u32 (&doff)[5], u32 baseA, u32 baseB, int G, bool active, int dbg, u32* trace) {
+    constexpr int NL = ROLE == 0 ? 5 : 4;
+    // TRACE (EPG_S3_DBG & 32, measurements only): the shader clock at the four segment boundaries of the first 64 stages
+    int tn = 0, tcur = 0;
+    auto stamp = [&]() {
+        if (TRACE && tcur >= 1000 && tn < 256) {                                       // 64 stages in steady state
+            const u32 c = (u32)__builtin_readcyclecounter();
+            if ((threadIdx.x & 63) == 0) trace[tn] = c;
+            ++tn;
+        }
+    };
+    auto dma = [&](int gs, int sl) {
+        const bool real = gs < G && !(dbg & 16);
+        const char* lsrc = src0 + (real ? (long)gs * stage_stride : 0L);              // wave-uniform base, 32-bit lane offsets
+        char* ldst = smem + sl * G_STAGE_BYTES;
+#pragma unroll
+        for (int j = 0; j < NL; ++j) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(lsrc + soff[j]),
+                                             (__attribute__((address_space(3))) void*)(real ? ldst + doff[j] : scrap), 16, 0, 0);
+        }
+    };
+    GOps o0, o1;
+    if (ROLE == 0) {
+        g_read<0>(o0, baseA, baseB);
+        g_read<1>(o1, baseA, baseB);
+        g_wait_lds(o0);
+        g_wait_lds(o1);
+    }
+    // MODE 0: a wave's DMA pieces go out in its load half, after the operand reads.  MODE 1: in its compute half, right after
+    // the 18 MFMAs are issued -- X fetches stage t - 1 + R into the slot of stage t - 1 (read by everybody two halves ago), Y
+    // stage t + R into the slot of stage t -- so that a load half is the twelve ds_read_b128 and nothing else.
+    // Priorities: MODE 0 / 1 raise the wave for its MFMAs (as k_s3_syrk_fp4 does), MODE 2 never, MODE 3 for its load half.
+    constexpr bool CP = MODE <= 1, LP = MODE == 3;
+    int slot = 0, slot_prev = R - 1;
+    for (int t = 0; t < G; ++t) {
+        const int slot1 = slot == R - 1 ? 0 : slot + 1;
+        tcur = t;
+        if (ROLE == 0) {
+            stamp();
+            g_mfma<CP>(o0, active, acc);
+            g_mfma<CP>(o1, active, acc);
+            __builtin_amdgcn_sched_barrier(0);
+            if (MODE == 1) {
+                dma(t > 0 ? t - 1 + R : G, slot_prev);     // t = 0: a dummy keeps the count
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NL) : "memory");
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            stamp();
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            stamp();
+            if (LP) __builtin_amdgcn_s_setprio(1);
+            const u32 sn = (u32)(t + 1 < G ? slot1 : slot) * G_STAGE_BYTES;            // past the end: a harmless re-read
+            g_read<0>(o0, baseA + sn, baseB + sn);
+            g_read<1>(o1, baseA + sn, baseB + sn);
+            if (MODE != 1) dma(t + R, slot);                                          // the slot of stage t is free now
+            g_wait_lds(o0);
+            g_wait_lds(o1);
+            if (MODE != 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NL) : "memory");
+            if (LP) __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            stamp();
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        } else {
+            stamp();
+            if (LP) __builtin_amdgcn_s_setprio(1);
+            const u32 so = (u32)slot * G_STAGE_BYTES;
+            g_read<0>(o0, baseA + so, baseB + so);
+            g_read<1>(o1, baseA + so, baseB + so);
+            if (MODE != 1) dma(t > 0 ? t - 1 + R : G, slot_prev);   // t = 0: stage R - 1 came with the prologue; a dummy keeps the count
+            g_wait_lds(o0);
+            g_wait_lds(o1);
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NL) : "memory");
+            if (LP) __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            stamp();
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            stamp();
+            g_mfma<CP>(o0, active, acc);
+            g_mfma<CP>(o1, active, acc);
+            __builtin_amdgcn_sched_barrier(0);
+            if (MODE == 1) {
+                dma(t + R, slot);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            stamp();
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        slot_prev = slot;
+        slot = slot1;
+    }
+}
+
+template <int R, int MODE, bool TRACE>
+__global__ __launch_bounds__(64 * G_NW, 2) void k_s3_syrk_pp(const char* __restrict__ E4, int NT, long nstages, long stages_per_split,
+                                                        const int* __restrict__ tasks, int ntasks, int N, int S,
+                                                        int* __restrict__ counts, int dbg, const int* __restrict__ gate, int want,
+                                                        int* __restrict__ marg) {
+    static_assert(G_NW == 8 && G_STAGE_TILES == 36, "2 x 4 waves: X fetches 4 x 5 tiles of a stage, Y 4 x 4");
+    if (gate && *gate != want) return;
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = w / G_WN, wn = w % G_WN;
+    const int role = w >> 2;                                // waves w and w + 4 share a SIMD (MI355X_MICROARCH.md, LDS section)
+    const int xcd = blockIdx.x & 7, q8 = ntasks >> 3, r8 = ntasks & 7;
+    const int tix = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (blockIdx.x >> 3);
+    const int task = tasks[tix];
+    const int P = task & 0xffff, Q = task >> 16;
+    const int bm = G_WM * P + wm, bn = G_WN * Q + wn;
+    const bool active = bm <= bn && !(dbg & 8);
+    const long g0 = (long)blockIdx.y * stages_per_split;
+    const int G = (int)(nstages - g0 < stages_per_split ? nstages - g0 : stages_per_split);
+    if (G <= 0) return;
+
+    u32 soff[5], doff[5];                                   // byte offsets inside a stage of the operand (< 2 NT KiB) / of the ring slot
+    char* const scrap = smem + R * G_STAGE_BYTES + w * 1024;
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+        const int s = role == 0 ? w * 5 + j : (j < 4 ? 20 + (w - 4) * 4 + j : 0);       // Y has no fifth piece
+        const int ks = s / (G_TA + G_TB), t = s - ks * (G_TA + G_TB);
+        const int gt = (dbg & 1) ? t : (t < G_TA ? P * G_TA + t : Q * G_TB + (t - G_TA));
+        soff[j] = (u32)(ks * NT + gt) * 1024u + (u32)lane * 16u;
+        doff[j] = (u32)s * 1024;
+    }
+    const char* src0 = E4 + g0 * G_KS * (long)NT * 1024;
+    const long stage_stride = (long)G_KS * NT * 1024;
+
+    v16f acc[3][3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    const u32 lds0 = (u32)(uintptr_t)smem + (u32)lane * 16;
+    const u32 baseA = lds0 + (u32)(wm * 3) * 1024, baseB = lds0 + (u32)(G_TA + wn * 3) * 1024;
+    // prologue: the first R stages, everything landed, one barrier
+#pragma unroll
+    for (int s = 0; s < R; ++s) {
+        const bool real = s < G;
+        const char* lsrc = src0 + (real ? (long)s * stage_stride : 0L);
+#pragma unroll
+        for (int j = 0; j < 5; ++j)
+            if (j < 4 || role == 0)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(lsrc + soff[j]),
+                                                 (__attribute__((address_space(3))) void*)(real ? smem + s * G_STAGE_BYTES + doff[j] : scrap), 16, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    u32* trace = reinterpret_cast<u32*>(smem + g_lds_bytes(R)) + w * 256;           // TRACE: 1 KiB per wave past the ring
+    if (role == 0)
+        g_pp_loop<R, 0, MODE, TRACE>(acc, smem, scrap, src0, stage_stride, soff, doff, baseA, baseB, G, active, dbg, trace);
+    else
+        g_pp_loop<R, 1, MODE, TRACE>(acc, smem, scrap, src0, stage_stride, soff, doff, baseA, baseB, G, active, dbg, trace);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the tail's dummy loads
+    __builtin_amdgcn_s_barrier();
+    if (TRACE && blockIdx.x == 96 && blockIdx.y == 0 && lane == 0 && (w == 0 || w == 4)) {   // task (P 0, Q 3): all eight waves active
+        // X: [before MFMAs, after MFMAs, after barrier, after loads] per stage; Y: [before loads, after loads, after barrier, after MFMAs]
+        // X: [MFMAs issued | barrier | load segment || barrier]   Y: [load segment | barrier | MFMAs issued || barrier]
+        for (int i = 0; i + 5 <= 256; i += 4)
+            printf("trace w%d stage %d: %u %u %u || %u\n", w, i / 4, trace[i + 1] - trace[i], trace[i + 2] - trace[i + 1], trace[i + 3] - trace[i + 2],
+                   trace[i + 4] - trace[i + 3]);
+    }
+    if (!active || (dbg & 2)) return;
+    g_epilogue(acc, smem, w, lane, bm, bn, N, S, counts, marg);
 }
 
 int transpose_states(const char* X, int64_t R, int32_t N, int64_t ldx, int32_t S, char* XT, int64_t Rp, int shift, hipStream_t st);
@@ -461,12 +664,22 @@ int hist_s3_gemm(const char* X, int64_t R, int32_t N, int64_t ldx, int32_t S, in
     static bool attr_set = false;
     if (dbg_env & 4) {
         int nblk = -1;
-        hipOccupancyMaxActiveBlocksPerMultiprocessor(&nblk, reinterpret_cast<const void*>(k_s3_syrk_fp4), 64 * G_NW, G_LDS_BYTES);
-        fprintf(stderr, "k_s3_syrk_fp4: %d workgroups of %d threads per CU with %d bytes of LDS\n", nblk, 64 * G_NW, G_LDS_BYTES);
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&nblk, reinterpret_cast<const void*>(k_s3_syrk_fp4<G_RING_DEFAULT>), 64 * G_NW,
+                                                     g_lds_bytes(G_RING_DEFAULT));
+        fprintf(stderr, "k_s3_syrk_fp4: %d workgroups of %d threads per CU with %d bytes of LDS\n", nblk, 64 * G_NW, g_lds_bytes(G_RING_DEFAULT));
     }
     if (!attr_set) {
-        EPG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_s3_syrk_fp4), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    G_LDS_BYTES));
+        EPG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_s3_syrk_fp4<3>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    g_lds_bytes(3)));
+        EPG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_s3_syrk_fp4<4>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    g_lds_bytes(4)));
+#define EPG_PP_ATTR(MODE)                                                                                                             \
+    EPG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_s3_syrk_pp<4, MODE, false>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                g_lds_bytes(4)));                                                                                    \
+    EPG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_s3_syrk_pp<4, MODE, true>), hipFuncAttributeMaxDynamicSharedMemorySize,  \
+                                g_lds_bytes(4) + G_NW * 1024));
+        EPG_PP_ATTR(0) EPG_PP_ATTR(1) EPG_PP_ATTR(2) EPG_PP_ATTR(3)
+#undef EPG_PP_ATTR
         attr_set = true;
     }
     // chunk = as many bins of the operand as the caller's workspace holds (every chunk ends in one epilogue of ~2 atomics
@@ -553,8 +766,34 @@ static int hist_s3_gemm_run(const char* XT, long Rp, int N, int S, int32_t* coun
         if (splits > 65535) splits = 65535;
         const long per = (nstages + splits - 1) / splits;
         const long nsplit = (nstages + per - 1) / per;
-        hipLaunchKernelGGL(k_s3_syrk_fp4, dim3((unsigned)ntasks, (unsigned)nsplit), dim3(64 * G_NW), G_LDS_BYTES, st, E4, NT, nstages,
-                           per, tasks, ntasks, N, S, counts, dbg_env, gate, want, marg);
+        // EPG_S3_RING=3|4: depth of the LDS ring the operand stages are prefetched into (A/B measurements)
+        static const int ring = [] { const char* e = getenv("EPG_S3_RING"); const int r = e ? atoi(e) : G_RING_DEFAULT; return r == 3 || r == 4 ? r : G_RING_DEFAULT; }();
+        // EPG_S3_SYRK=pp: the ping-pong schedule (k_s3_syrk_pp), DMA pieces in the load halves, MFMAs at priority 1; pq: DMA pieces
+        // in the compute halves; pn: as pp without priorities; pl: as pp with the LOAD half at priority 1
+        static const int pp = [] {
+            const char* e = getenv("EPG_S3_SYRK");
+            return !e || e[0] != 'p' ? 0 : e[1] == 'q' ? 2 : e[1] == 'n' ? 3 : e[1] == 'l' ? 4 : 1;
+        }();
+        const bool tr = dbg_env & 32;
+        const size_t lds_pp = g_lds_bytes(4) + (tr ? G_NW * 1024 : 0);
+#define EPG_PP_LAUNCH(MODE, TR)                                                                                                      \
+    hipLaunchKernelGGL((k_s3_syrk_pp<4, MODE, TR>), dim3((unsigned)ntasks, (unsigned)nsplit), dim3(64 * G_NW), lds_pp, st, E4, NT, nstages, \
+                       per, tasks, ntasks, N, S, counts, dbg_env, gate, want, marg)
+#define EPG_PP_MODE(M)                                                                                                               \
+    if (tr) EPG_PP_LAUNCH(M, true);                                                                                                  \
+    else EPG_PP_LAUNCH(M, false)
+        if (pp == 1) { EPG_PP_MODE(0); }
+        else if (pp == 2) { EPG_PP_MODE(1); }
+        else if (pp == 3) { EPG_PP_MODE(2); }
+        else if (pp == 4) { EPG_PP_MODE(3); }
+#undef EPG_PP_MODE
+#undef EPG_PP_LAUNCH
+        else if (ring == 4)
+            hipLaunchKernelGGL(k_s3_syrk_fp4<4>, dim3((unsigned)ntasks, (unsigned)nsplit), dim3(64 * G_NW), g_lds_bytes(4), st, E4, NT, nstages,
+                               per, tasks, ntasks, N, S, counts, dbg_env, gate, want, marg);
+        else
+            hipLaunchKernelGGL(k_s3_syrk_fp4<3>, dim3((unsigned)ntasks, (unsigned)nsplit), dim3(64 * G_NW), g_lds_bytes(3), st, E4, NT, nstages,
+                               per, tasks, ntasks, N, S, counts, dbg_env, gate, want, marg);
         EPG_LAUNCH_CHECK("k_s3_syrk_fp4");
     }
     return EPG_OK;

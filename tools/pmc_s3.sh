@@ -11,6 +11,7 @@ declare -A groups
 groups[sq]="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_LDS"
 groups[mfma]="SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F8 SQ_INSTS_MFMA SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INST_LEVEL_VMEM SQ_INSTS_VMEM_RD"
 groups[tcc]="TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum"
+groups[clk]="GRBM_GUI_ACTIVE GRBM_COUNT SQ_BUSY_CU_CYCLES"
 groups[fetch]="FETCH_SIZE"
 groups[write]="WRITE_SIZE"
 cd /tmp
