@@ -131,15 +131,14 @@ __device__ __forceinline__ void g_wait_lds(GOps& o) {
                                                                 acc[I][J], 4, 4, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f)
 
 // nine MFMAs of one k-step (fp4 operands: four registers are read)
-template <bool PRIO = true>
 __device__ __forceinline__ void g_mfma(const GOps& o, bool active, v16f (&acc)[3][3]) {
     if (!active) return;
-    if (PRIO) __builtin_amdgcn_s_setprio(1);
+    __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int a = 0; a < 3; ++a)
 #pragma unroll
         for (int b = 0; b < 3; ++b) G_MFMA(a, b);
-    if (PRIO) __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_s_setprio(0);
 }
 
 // The same with the wave's five LDS-DMA loads of a later stage spread between the MFMAs.  Issuing an LDS-DMA load costs the
@@ -336,20 +335,26 @@ __global__ __launch_bounds__(64 * G_NW, 2) void k_s3_syrk_fp4(const char* __rest
     g_epilogue(acc, smem, w, lane, bm, bn, N, S, counts, marg);
 }
 
-// ---- the same contraction with the two waves of a SIMD in opposite phases ("ping-pong", round 3) ---------------------------
-// In k_s3_syrk_fp4 all eight waves of the workgroup run the same phase at the same time: the partners on a SIMD issue their
-// operand reads, their DMA pieces and their MFMAs together, and the matrix pipe idles whenever both are busy with something
-// else (1735 cycles per stage for 1274 of matrix work).  Here waves 0-3 ("X") and their SIMD partners 4-7 ("Y") alternate
-// half a stage apart, a barrier after every half:
+// ---- the same contraction with the two waves of a SIMD in opposite phases ("ping-pong", round 3; EPG_S3_SYRK=pp) -----------
+// In k_s3_syrk_fp4 all eight waves of the workgroup run the same phase at the same time.  Here waves 0-3 ("X") and their SIMD
+// partners 4-7 ("Y") alternate half a stage apart, a barrier after every half:
 //     half 2t     X: the 18 MFMAs of stage t (both k-steps sit in 48 registers)      Y: ds_read stage t, DMA its share of stage t - 1 + R
 //     half 2t + 1 X: ds_read stage t + 1, DMA its share of stage t + R               Y: the 18 MFMAs of stage t
-// so a SIMD's matrix pipe is fed by one wave while the other does everything that is not matrix work.  The 36 tiles of a stage
-// are fetched by X (5 per wave) and Y (4 per wave) with no surplus load; the ring holds R = 4 stages: the slot of stage t is
-// free once Y has read it (end of half 2t) and takes stage t + R in the next two halves, which X reads in half 2t + 2R - 1 --
-// every wave waits for its own pieces at the end of a load half with the two most recent batches still in flight (a batch has
-// four halves, about two stages, to land).  Past the last stage the same instructions fetch stage 0 into the scrap.
+// The 36 tiles of a stage are fetched by X (5 per wave) and Y (4 per wave) with no surplus load; the ring holds R = 4 stages:
+// the slot of stage t is free once Y has read it (end of half 2t) and takes stage t + R in the next two halves, which X reads
+// in half 2t + 2R - 1 -- every wave waits for its own pieces at the end of a load half with the two most recent batches still
+// in flight (a batch has four halves, about two stages, to land).  Past the last stage the same instructions fetch stage 0
+// into the scrap.
+// MEASURED (profiles/r03p_s3_syrk_pingpong.txt): same counts, 0-1.5 % faster than k_s3_syrk_fp4 depending on the box -- not
+// the default.  The segment trace (EPG_S3_DBG & 32: s_memtime at the segment boundaries of one workgroup) shows why the
+// schedule cannot pay: a wave's 18 MFMAs take ~570 cycles to ISSUE (issue blocks on the pipe, 32 cycles each), and its load
+// half -- twelve ds_read_b128 and four or five DMA pieces -- takes 650-950 cycles while the partner's MFMAs run (400 with the
+// matrix pipe idle), whatever the priorities (none, MFMAs at 1, loads at 1) and wherever the DMA pieces go (moved behind the
+// MFMAs of the compute half they simply add to it: 810 cycles).  A wave's own instructions issue in order, so a stage costs
+// every wave its MFMA issue time plus its load time, ~1700 cycles; two waves per SIMD is all the registers allow (144
+// accumulators + 48 operand registers each), and the matrix pipe (2 x 576 cycles per stage) waits a third of the time.
 // the main loop of one role (ROLE 0: compute first; ROLE 1: load first), NL = pieces of a stage this wave fetches
-template <int R, int ROLE, int MODE, bool TRACE>
+template <int R, int ROLE, bool TRACE>
 __device__ __forceinline__ void g_pp_loop(v16f (&acc)[3][3], char* smem, char* scrap, const char* src0, long stage_stride, const u32 (&soff)[5],
                                           const u32 (&doff)[5], u32 baseA, u32 baseB, int G, bool active, int dbg, u32* trace) {
     constexpr int NL = ROLE == 0 ? 5 : 4;
@@ -379,65 +384,47 @@ __device__ __forceinline__ void g_pp_loop(v16f (&acc)[3][3], char* smem, char* s
         g_wait_lds(o0);
         g_wait_lds(o1);
     }
-    // MODE 0: a wave's DMA pieces go out in its load half, after the operand reads.  MODE 1: in its compute half, right after
-    // the 18 MFMAs are issued -- X fetches stage t - 1 + R into the slot of stage t - 1 (read by everybody two halves ago), Y
-    // stage t + R into the slot of stage t -- so that a load half is the twelve ds_read_b128 and nothing else.
-    // Priorities: MODE 0 / 1 raise the wave for its MFMAs (as k_s3_syrk_fp4 does), MODE 2 never, MODE 3 for its load half.
-    constexpr bool CP = MODE <= 1, LP = MODE == 3;
     int slot = 0, slot_prev = R - 1;
     for (int t = 0; t < G; ++t) {
         const int slot1 = slot == R - 1 ? 0 : slot + 1;
         tcur = t;
         if (ROLE == 0) {
             stamp();
-            g_mfma<CP>(o0, active, acc);
-            g_mfma<CP>(o1, active, acc);
+            g_mfma(o0, active, acc);
+            g_mfma(o1, active, acc);
             __builtin_amdgcn_sched_barrier(0);
-            if (MODE == 1) {
-                dma(t > 0 ? t - 1 + R : G, slot_prev);     // t = 0: a dummy keeps the count
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NL) : "memory");
-                __builtin_amdgcn_sched_barrier(0);
-            }
             stamp();
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
             stamp();
-            if (LP) __builtin_amdgcn_s_setprio(1);
             const u32 sn = (u32)(t + 1 < G ? slot1 : slot) * G_STAGE_BYTES;            // past the end: a harmless re-read
             g_read<0>(o0, baseA + sn, baseB + sn);
             g_read<1>(o1, baseA + sn, baseB + sn);
-            if (MODE != 1) dma(t + R, slot);                                          // the slot of stage t is free now
+            dma(t + R, slot);                                          // the slot of stage t is free now
             g_wait_lds(o0);
             g_wait_lds(o1);
-            if (MODE != 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NL) : "memory");
-            if (LP) __builtin_amdgcn_s_setprio(0);
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NL) : "memory");
             __builtin_amdgcn_sched_barrier(0);
             stamp();
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
         } else {
             stamp();
-            if (LP) __builtin_amdgcn_s_setprio(1);
             const u32 so = (u32)slot * G_STAGE_BYTES;
             g_read<0>(o0, baseA + so, baseB + so);
             g_read<1>(o1, baseA + so, baseB + so);
-            if (MODE != 1) dma(t > 0 ? t - 1 + R : G, slot_prev);   // t = 0: stage R - 1 came with the prologue; a dummy keeps the count
+            dma(t > 0 ? t - 1 + R : G, slot_prev);   // t = 0: stage R - 1 came with the prologue; a dummy keeps the count
             g_wait_lds(o0);
             g_wait_lds(o1);
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NL) : "memory");
-            if (LP) __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
             stamp();
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
             stamp();
-            g_mfma<CP>(o0, active, acc);
-            g_mfma<CP>(o1, active, acc);
+            g_mfma(o0, active, acc);
+            g_mfma(o1, active, acc);
             __builtin_amdgcn_sched_barrier(0);
-            if (MODE == 1) {
-                dma(t + R, slot);
-                __builtin_amdgcn_sched_barrier(0);
-            }
             stamp();
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
@@ -447,7 +434,7 @@ __device__ __forceinline__ void g_pp_loop(v16f (&acc)[3][3], char* smem, char* s
     }
 }
 
-template <int R, int MODE, bool TRACE>
+template <int R, bool TRACE>
 __global__ __launch_bounds__(64 * G_NW, 2) void k_s3_syrk_pp(const char* __restrict__ E4, int NT, long nstages, long stages_per_split,
                                                         const int* __restrict__ tasks, int ntasks, int N, int S,
                                                         int* __restrict__ counts, int dbg, const int* __restrict__ gate, int want,
@@ -507,9 +494,9 @@ __global__ __launch_bounds__(64 * G_NW, 2) void k_s3_syrk_pp(const char* __restr
     __builtin_amdgcn_s_barrier();
     u32* trace = reinterpret_cast<u32*>(smem + g_lds_bytes(R)) + w * 256;           // TRACE: 1 KiB per wave past the ring
     if (role == 0)
-        g_pp_loop<R, 0, MODE, TRACE>(acc, smem, scrap, src0, stage_stride, soff, doff, baseA, baseB, G, active, dbg, trace);
+        g_pp_loop<R, 0, TRACE>(acc, smem, scrap, src0, stage_stride, soff, doff, baseA, baseB, G, active, dbg, trace);
     else
-        g_pp_loop<R, 1, MODE, TRACE>(acc, smem, scrap, src0, stage_stride, soff, doff, baseA, baseB, G, active, dbg, trace);
+        g_pp_loop<R, 1, TRACE>(acc, smem, scrap, src0, stage_stride, soff, doff, baseA, baseB, G, active, dbg, trace);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the tail's dummy loads
     __builtin_amdgcn_s_barrier();
     if (TRACE && blockIdx.x == 96 && blockIdx.y == 0 && lane == 0 && (w == 0 || w == 4)) {   // task (P 0, Q 3): all eight waves active
@@ -673,13 +660,9 @@ int hist_s3_gemm(const char* X, int64_t R, int32_t N, int64_t ldx, int32_t S, in
                                     g_lds_bytes(3)));
         EPG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_s3_syrk_fp4<4>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     g_lds_bytes(4)));
-#define EPG_PP_ATTR(MODE)                                                                                                             \
-    EPG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_s3_syrk_pp<4, MODE, false>), hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                g_lds_bytes(4)));                                                                                    \
-    EPG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_s3_syrk_pp<4, MODE, true>), hipFuncAttributeMaxDynamicSharedMemorySize,  \
-                                g_lds_bytes(4) + G_NW * 1024));
-        EPG_PP_ATTR(0) EPG_PP_ATTR(1) EPG_PP_ATTR(2) EPG_PP_ATTR(3)
-#undef EPG_PP_ATTR
+        EPG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_s3_syrk_pp<4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, g_lds_bytes(4)));
+        EPG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_s3_syrk_pp<4, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    g_lds_bytes(4) + G_NW * 1024));
         attr_set = true;
     }
     // chunk = as many bins of the operand as the caller's workspace holds (every chunk ends in one epilogue of ~2 atomics
@@ -768,26 +751,14 @@ static int hist_s3_gemm_run(const char* XT, long Rp, int N, int S, int32_t* coun
         const long nsplit = (nstages + per - 1) / per;
         // EPG_S3_RING=3|4: depth of the LDS ring the operand stages are prefetched into (A/B measurements)
         static const int ring = [] { const char* e = getenv("EPG_S3_RING"); const int r = e ? atoi(e) : G_RING_DEFAULT; return r == 3 || r == 4 ? r : G_RING_DEFAULT; }();
-        // EPG_S3_SYRK=pp: the ping-pong schedule (k_s3_syrk_pp), DMA pieces in the load halves, MFMAs at priority 1; pq: DMA pieces
-        // in the compute halves; pn: as pp without priorities; pl: as pp with the LOAD half at priority 1
-        static const int pp = [] {
-            const char* e = getenv("EPG_S3_SYRK");
-            return !e || e[0] != 'p' ? 0 : e[1] == 'q' ? 2 : e[1] == 'n' ? 3 : e[1] == 'l' ? 4 : 1;
-        }();
-        const bool tr = dbg_env & 32;
-        const size_t lds_pp = g_lds_bytes(4) + (tr ? G_NW * 1024 : 0);
-#define EPG_PP_LAUNCH(MODE, TR)                                                                                                      \
-    hipLaunchKernelGGL((k_s3_syrk_pp<4, MODE, TR>), dim3((unsigned)ntasks, (unsigned)nsplit), dim3(64 * G_NW), lds_pp, st, E4, NT, nstages, \
-                       per, tasks, ntasks, N, S, counts, dbg_env, gate, want, marg)
-#define EPG_PP_MODE(M)                                                                                                               \
-    if (tr) EPG_PP_LAUNCH(M, true);                                                                                                  \
-    else EPG_PP_LAUNCH(M, false)
-        if (pp == 1) { EPG_PP_MODE(0); }
-        else if (pp == 2) { EPG_PP_MODE(1); }
-        else if (pp == 3) { EPG_PP_MODE(2); }
-        else if (pp == 4) { EPG_PP_MODE(3); }
-#undef EPG_PP_MODE
-#undef EPG_PP_LAUNCH
+        // EPG_S3_SYRK=pp: the ping-pong schedule (k_s3_syrk_pp; EPG_S3_DBG & 32: with the segment trace of one workgroup)
+        static const bool pp = [] { const char* e = getenv("EPG_S3_SYRK"); return e && e[0] == 'p'; }();
+        if (pp && (dbg_env & 32))
+            hipLaunchKernelGGL((k_s3_syrk_pp<4, true>), dim3((unsigned)ntasks, (unsigned)nsplit), dim3(64 * G_NW), g_lds_bytes(4) + G_NW * 1024, st,
+                               E4, NT, nstages, per, tasks, ntasks, N, S, counts, dbg_env, gate, want, marg);
+        else if (pp)
+            hipLaunchKernelGGL((k_s3_syrk_pp<4, false>), dim3((unsigned)ntasks, (unsigned)nsplit), dim3(64 * G_NW), g_lds_bytes(4), st, E4, NT, nstages,
+                               per, tasks, ntasks, N, S, counts, dbg_env, gate, want, marg);
         else if (ring == 4)
             hipLaunchKernelGGL(k_s3_syrk_fp4<4>, dim3((unsigned)ntasks, (unsigned)nsplit), dim3(64 * G_NW), g_lds_bytes(4), st, E4, NT, nstages,
                                per, tasks, ntasks, N, S, counts, dbg_env, gate, want, marg);
