@@ -750,9 +750,12 @@ static int hist_s3_gemm_run(const char* XT, long Rp, int N, int S, int32_t* coun
         const long per = (nstages + splits - 1) / splits;
         const long nsplit = (nstages + per - 1) / per;
         // EPG_S3_RING=3|4: depth of the LDS ring the operand stages are prefetched into (A/B measurements)
-        static const int ring = [] { const char* e = getenv("EPG_S3_RING"); const int r = e ? atoi(e) : G_RING_DEFAULT; return r == 3 || r == 4 ? r : G_RING_DEFAULT; }();
+        // (read per call: the tests switch schedules inside one process)
+        const char* ring_env = getenv("EPG_S3_RING");
+        const int ring = ring_env && (atoi(ring_env) == 3 || atoi(ring_env) == 4) ? atoi(ring_env) : G_RING_DEFAULT;
         // EPG_S3_SYRK=pp: the ping-pong schedule (k_s3_syrk_pp; EPG_S3_DBG & 32: with the segment trace of one workgroup)
-        static const bool pp = [] { const char* e = getenv("EPG_S3_SYRK"); return e && e[0] == 'p'; }();
+        const char* syrk_env = getenv("EPG_S3_SYRK");
+        const bool pp = syrk_env && syrk_env[0] == 'p';
         if (pp && (dbg_env & 32))
             hipLaunchKernelGGL((k_s3_syrk_pp<4, true>), dim3((unsigned)ntasks, (unsigned)nsplit), dim3(64 * G_NW), g_lds_bytes(4) + G_NW * 1024, st,
                                E4, NT, nstages, per, tasks, ntasks, N, S, counts, dbg_env, gate, want, marg);

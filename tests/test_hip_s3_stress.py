@@ -49,9 +49,9 @@ def test_s3_score_kernels_random_shapes(monkeypatch):
 
 
 def test_s3_expected_kernels_random_shapes(monkeypatch):
-    """Random shapes through the three expected-count paths: the matrix-core contraction over all S states, the reduced one
-    (S - 1 states per biosample, the last state's cells re-derived from the marginals; EPG_S3_REDUCED=1 forces it below its
-    size threshold) and the LDS-counter kernel -- with and without bytes that are not states (which must switch the reduced
+    """Random shapes through the expected-count paths: the matrix-core contraction over all S states (in its three schedules:
+    ring of three, ring of four, ping-pong), the reduced one (S - 1 states per biosample, the last state's cells re-derived from
+    the marginals; EPG_S3_REDUCED=1 forces it below its size threshold) and the LDS-counter kernel -- with and without bytes that are not states (which must switch the reduced
     path off on the device), and accumulating into non-zero counts.  expected.py:183-200."""
     from epilogos_amd import engine
     engine.require_gpu()
@@ -74,6 +74,16 @@ def test_s3_expected_kernels_random_shapes(monkeypatch):
         monkeypatch.delenv("EPG_S3_REDUCED")
         lds = engine.hist_s3(X, N, S, use_workspace=False)
         assert torch.equal(red, full) and torch.equal(full, lds), (N, S, R, dirty)
+        # the other schedules of the contraction kernel: a ring of four stages, the ping-pong of the SIMD partners
+        monkeypatch.setenv("EPG_S3_RING", "4")
+        ring4 = engine.hist_s3(X, N, S)
+        monkeypatch.delenv("EPG_S3_RING")
+        monkeypatch.setenv("EPG_S3_SYRK", "pp")
+        monkeypatch.setenv("EPG_S3_REDUCED", "1" if case % 2 else "0")
+        pp = engine.hist_s3(X, N, S)
+        monkeypatch.delenv("EPG_S3_SYRK")
+        monkeypatch.delenv("EPG_S3_REDUCED")
+        assert torch.equal(ring4, full) and torch.equal(pp, full), (N, S, R, dirty)
         assert torch.equal(red2, 2 * full), (N, S, R, dirty)
         if not dirty and N * N * S * S * R < 4e8:                  # oracle-sized and clean: the reference's own counts
             assert np.array_equal(full.cpu().numpy().reshape(N, N, S, S), onp.expected_s3(x, S)), (N, S, R)
