@@ -7,6 +7,8 @@
 // depends only on (seed, row0 + row), never on the launch geometry or on which GPU owns the row.  gfx950 only.
 #include "epg_common.h"
 
+#include <stdlib.h>
+
 namespace epg {
 
 __device__ __forceinline__ void philox4x32_10(u32 (&c)[4], u32 k0, u32 k1) {
@@ -138,7 +140,7 @@ __device__ __forceinline__ void nh_stage_in(char* lds, const char* src, int nbyt
     for (int o = (nchunks << 4) + 2 * lane; o + 2 <= nbytes; o += 128) *reinterpret_cast<u16*>(lds + o) = *reinterpret_cast<const u16*>(src + o);
 }
 
-__global__ __launch_bounds__(256) void k_null_hist_h(const u16* __restrict__ HA, const u16* __restrict__ HB, long R, int S, int n_cols,
+__global__ __launch_bounds__(256) void k_null_hist_h_seq(const u16* __restrict__ HA, const u16* __restrict__ HB, long R, int S, int n_cols,
                                                       int ga, int gb, u64 seed, long row0, u16* __restrict__ OA, u16* __restrict__ OB, int TR) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -238,6 +240,144 @@ __global__ __launch_bounds__(256) void k_null_hist_h(const u16* __restrict__ HA,
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Round 3: the same sampler with the categories taken OUT of the draw loop.  Selection sampling does not look at what a
+// column holds -- the column at position d joins A with probability need_A / remaining whatever its state -- so with the
+// columns of a row laid out [non-modal states in order | columns without a state | modal state] the loop over the first
+// m = n - max h positions is the same for every row: one byte of Philox output, a multiply-add, two compares, and ONE BIT of
+// outcome per group appended to a per-lane bit string in LDS ([word][lane], flushed every 32 draws by all lanes at once).
+// The per-state counts are then range popcounts of that string between the prefix sums of the row's histogram.  The category
+// bookkeeping of k_null_hist_h_seq (an LDS store + load and a divergent inner loop whenever ANY lane of the wave crosses into
+// its next state, i.e. at nearly every draw) is gone from the loop; the law, the Philox counters (global row, call number,
+// tag) and the tie rule are the same, which draw lands in which state is not: same seed, different -- equally distributed --
+// null groups.  FULL (ga + gb == n, the command line without -g): a column that does not join A joins B, one bit string.
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ u32 nh_range_pop(const u32* __restrict__ bits, u32 o, u32 h) {    // ones in positions [o, o + h)
+    u32 cnt = 0, p = o;
+    const u32 e = o + h;
+    while (p < e) {
+        const u32 w = bits[(p >> 5) * 64], lo = p & 31u;
+        const u32 n = (32u - lo) < (e - p) ? (32u - lo) : (e - p);                           // 1 .. 32
+        cnt += __popc((w >> lo) << (32u - n));                                                 // the n bits from lo on
+        p += n;
+    }
+    return cnt;
+}
+
+template <bool FULL>
+__global__ __launch_bounds__(256) void k_null_hist_h(const u16* __restrict__ HA, const u16* __restrict__ HB, long R, int S, int n_cols,
+                                                      int ga, int gb, u64 seed, long row0, u16* __restrict__ OA, u16* __restrict__ OB, int TR,
+                                                      int NW) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int rowb = 2 * S;
+    const size_t per_wave = (size_t)2 * TR * rowb + (size_t)(FULL ? 1 : 2) * NW * 256;
+    char* sa = smem + (size_t)wave * per_wave;                    // the wave's TR rows of hA, later of the A group's counts
+    char* sb = sa + TR * rowb;
+    u32* bitsA = reinterpret_cast<u32*>(sb + TR * rowb) + lane;   // [word][lane]
+    u32* bitsB = bitsA + (FULL ? 0 : NW * 64);
+    const long ntiles = (R + TR - 1) / TR;
+    for (long tile = (long)blockIdx.x * 4 + wave; tile < ntiles; tile += (long)gridDim.x * 4) {
+        const long r0 = tile * TR;
+        const int rows = (int)(R - r0 < TR ? R - r0 : TR);
+        nh_stage_in(sa, reinterpret_cast<const char*>(HA + r0 * S), rows * rowb, lane);
+        nh_stage_in(sb, reinterpret_cast<const char*>(HB + r0 * S), rows * rowb, lane);
+        __builtin_amdgcn_wave_barrier();
+        if (lane < rows) {
+            u16* pa = reinterpret_cast<u16*>(sa + lane * rowb);
+            u16* pb = reinterpret_cast<u16*>(sb + lane * rowb);
+            u32 tot = 0, best = 0;
+            int modal = 0;
+            for (int s = 0; s < S; ++s) {
+                const u32 h = (u32)pa[s] + pb[s];
+                pa[s] = (u16)h;
+                tot += h;
+                if (h > best) { best = h; modal = s; }
+            }
+            u32 A256 = (u32)ga << 8, AB256 = (u32)(ga + gb) << 8;
+            const u32 m = (u32)n_cols - best;
+            const u64 grow = (u64)(row0 + r0 + lane);
+            u32 r0w = 0, r1w = 0, r2w = 0, r3w = 0, calls = 0;
+            u32 a0w = 0, a1w = 0, a2w = 0, a3w = 0, ahave = 0, acalls = 0;
+            u32 wA = 0, wB = 0;
+            // one draw at position d (rem = n - d is the same in every lane: scalar) from one byte of Philox output: with u in
+            // [byte, byte + 1) / 256 the column joins A if (byte + 1) rem <= 256 need_A, B if byte rem >= 256 need_A and (byte + 1)
+            // rem <= 256 (need_A + need_B), neither if byte rem >= 256 (need_A + need_B); in the ~2 of 256 other cases 32 more
+            // bits from a second stream decide -- the outcome is that of a 40-bit uniform number
+            auto draw = [&](u32 byte, u32 d) {
+                const u32 rem = (u32)n_cols - d;
+                const u32 hi = __umul24(byte, rem) + rem, t = hi - rem;                   // 24-bit operands: n <= 65535
+                bool a = hi <= A256;
+                bool b = FULL ? !a && t >= A256 : t >= A256 && hi <= AB256;
+                if (!(a || b || (!FULL && t >= AB256))) {
+                    if (ahave == 0) {
+                        u32 c[4] = {(u32)grow, (u32)(grow >> 32), acalls++, 0x74696573u};
+                        philox4x32_10(c, (u32)seed, (u32)(seed >> 32));
+                        a0w = c[0]; a1w = c[1]; a2w = c[2]; a3w = c[3];
+                        ahave = 4;
+                    }
+                    const u64 u40 = ((u64)byte << 32) | a0w;
+                    a0w = a1w; a1w = a2w; a2w = a3w;
+                    --ahave;
+                    const u32 pick = (u32)((u40 * rem) >> 40);                            // uniform in [0, rem)
+                    a = pick < (A256 >> 8);
+                    b = !a && (FULL || pick < (AB256 >> 8));
+                }
+                const u32 bit = 1u << (d & 31u);
+                wA |= a ? bit : 0u;
+                if (!FULL) wB |= b ? bit : 0u;
+                A256 -= a ? 256u : 0u;
+                if (!FULL) AB256 -= (a || b) ? 256u : 0u;
+            };
+            auto refill = [&]() {                                                         // 16 draws per call
+                u32 c[4] = {(u32)grow, (u32)(grow >> 32), calls++, 0x6e756c6cu};
+                philox4x32_10(c, (u32)seed, (u32)(seed >> 32));
+                r0w = c[0]; r1w = c[1]; r2w = c[2]; r3w = c[3];
+            };
+            // whole words of four draws, then the last one to three
+            u32 d = 0;
+            for (; d + 4 <= m; d += 4) {
+                if ((d & 15u) == 0) refill();
+                const u32 cur = r0w;
+                r0w = r1w; r1w = r2w; r2w = r3w;
+#pragma unroll
+                for (u32 k = 0; k < 4; ++k) draw((cur >> (8 * k)) & 0xffu, d + k);
+                if ((d & 31u) == 28u) {
+                    bitsA[(d >> 5) * 64] = wA;
+                    wA = 0;
+                    if (!FULL) { bitsB[(d >> 5) * 64] = wB; wB = 0; }
+                }
+            }
+            if (d < m) {
+                if ((d & 15u) == 0) refill();
+                u32 cur = r0w;
+                for (; d < m; ++d, cur >>= 8) draw(cur & 0xffu, d);
+            }
+            if (m & 31u) {
+                bitsA[(m >> 5) * 64] = wA;
+                if (!FULL) bitsB[(m >> 5) * 64] = wB;
+            }
+            // counts per state: range popcounts between the prefix sums of the histogram; the modal state takes what is missing
+            u32 o = 0;
+            for (int s = 0; s < S; ++s) {
+                const u32 h = s == modal ? 0u : (u32)pa[s];
+                const u32 ca = nh_range_pop(bitsA, o, h);
+                const u32 cb = FULL ? h - ca : nh_range_pop(bitsB, o, h);
+                pa[s] = (u16)ca;
+                pb[s] = (u16)cb;
+                o += h;
+            }
+            // positions o .. m - 1 are the columns without a state: drawn (they take places in the groups), not reported
+            pa[modal] = (u16)(A256 >> 8);                                                 // = ga - (A members among the m drawn)
+            pb[modal] = FULL ? (u16)(best - (A256 >> 8)) : (u16)((AB256 - A256) >> 8);
+        }
+        __builtin_amdgcn_wave_barrier();
+        store_staged(sa, reinterpret_cast<char*>(OA + r0 * S), rows * rowb, lane);
+        store_staged(sb, reinterpret_cast<char*>(OB + r0 * S), rows * rowb, lane);
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 int null_hist_from_binhist_impl(const uint16_t* HA, const uint16_t* HB, int64_t R, int32_t S, int32_t n_cols, int32_t ga, int32_t gb,
                                 uint64_t seed, int64_t row0, uint16_t* OA, uint16_t* OB, hipStream_t st) {
     if (R < 0 || S < 1 || S > 127 || n_cols < 1 || n_cols > 65535) return fail(EPG_ERR_INVALID_ARG, "null_hist_from_binhist: bad shape");
@@ -250,8 +390,31 @@ int null_hist_from_binhist_impl(const uint16_t* HA, const uint16_t* HB, int64_t 
     const int TR = tile_rows(2 * 2 * S);
     long blocks = ((R + TR - 1) / TR + 3) / 4;
     if (blocks > num_cus() * 8L) blocks = num_cus() * 8L;
+    // the bit-string kernel while a lane's string fits the wave's share of LDS; EPG_NULL_HIST=seq: the round-2 kernel (A/B)
+    const bool full = ga + gb == n_cols;
+    const int NW = (n_cols + 31) / 32;
+    const size_t bits_bytes = (size_t)(full ? 1 : 2) * NW * 256;
+    const char* env = getenv("EPG_NULL_HIST");
+    // (-g runs, ga + gb < n: two bit strings and a three-way decision per draw measured 5 % SLOWER than the round-2 kernel, which stays)
+    if (bits_bytes <= 24 * 1024 && !(env && env[0] == 's') && (full || (env && env[0] == 'b'))) {
+        const size_t shmem = 4 * ((size_t)2 * TR * 2 * S + bits_bytes);
+        static bool attr_set = false;
+        if (!attr_set) {
+            EPG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_null_hist_h<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            EPG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_null_hist_h<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            attr_set = true;
+        }
+        if (full)
+            hipLaunchKernelGGL(k_null_hist_h<true>, dim3((unsigned)blocks), dim3(256), shmem, st, HA, HB, (long)R, S, n_cols, ga, gb, (u64)seed,
+                               (long)row0, OA, OB, TR, NW);
+        else
+            hipLaunchKernelGGL(k_null_hist_h<false>, dim3((unsigned)blocks), dim3(256), shmem, st, HA, HB, (long)R, S, n_cols, ga, gb, (u64)seed,
+                               (long)row0, OA, OB, TR, NW);
+        EPG_LAUNCH_CHECK("k_null_hist_h");
+        return EPG_OK;
+    }
     const size_t shmem = (size_t)4 * 2 * TR * 2 * S;
-    hipLaunchKernelGGL(k_null_hist_h, dim3((unsigned)blocks), dim3(256), shmem, st, HA, HB, (long)R, S, n_cols, ga, gb, (u64)seed,
+    hipLaunchKernelGGL(k_null_hist_h_seq, dim3((unsigned)blocks), dim3(256), shmem, st, HA, HB, (long)R, S, n_cols, ga, gb, (u64)seed,
                        (long)row0, OA, OB, TR);
     EPG_LAUNCH_CHECK("k_null_hist_h");
     return EPG_OK;

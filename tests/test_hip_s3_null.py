@@ -346,3 +346,27 @@ def test_null_hist_from_binhist_large_categories_follow_the_hypergeometric_law(e
         want_ab = -ga * gb * (70 / M) * (1 - 70 / M) / (M - 1)
         assert abs(np.cov(oa[:, 17], ob[:, 17])[0, 1] - want_ab) < 0.06 * abs(want_ab)
         assert (oa.sum(axis=1) + (oa[:, :0].sum(axis=1)) <= ga).all() and (oa + ob <= np.bincount(base[base >= 0], minlength=S)).all()
+
+
+def test_null_hist_bit_string_kernel_equals_the_column_by_column_kernel(eng, monkeypatch):
+    """Round 3 took the state bookkeeping out of the histogram-based sampler's draw loop (one outcome bit per position, range
+    popcounts afterwards).  The draws themselves -- Philox counters, one byte per position, the tie rule -- are those of the
+    round-2 kernel (EPG_NULL_HIST=seq), so the same seed must give the SAME null groups: default group sizes, -g, columns
+    without a state, wide rows, narrow rows, rows of one state, a 31-state model."""
+    rng = np.random.default_rng(8)
+    for S_, R_, na, nb, ga, gb in ((S, 5000, 379, 342, 379, 342), (S, 3000, 379, 342, 100, 100), (15, 777, 65, 62, 65, 62),
+                                   (31, 300, 40, 41, 40, 41), (5, 130, 3, 3, 3, 3), (S, 600, 700, 690, 700, 690), (S, 64, 12, 9, 5, 7)):
+        ya = synth_states(R_, na, S=S_, seed=int(rng.integers(1 << 30)))
+        yb = synth_states(R_, nb, S=S_, seed=int(rng.integers(1 << 30)))
+        ya[R_ // 2, 0] = -1                                  # a column without a state
+        ya[R_ // 3, :] = 1                                   # a bin in which every column of A holds one state ...
+        yb[R_ // 3, :] = 1                                   # ... and of B too: nothing to draw
+        Ha, _ = eng.bin_hist(eng.states_to_device(ya), na, S_, want_counts=False)
+        Hb, _ = eng.bin_hist(eng.states_to_device(yb), nb, S_, want_counts=False)
+        monkeypatch.delenv("EPG_NULL_HIST", raising=False)
+        Oa, Ob = eng.null_hist_from_binhist(Ha, Hb, na + nb, S_, ga, gb, seed=77, row0=123456789012)
+        monkeypatch.setenv("EPG_NULL_HIST", "seq")
+        Qa, Qb = eng.null_hist_from_binhist(Ha, Hb, na + nb, S_, ga, gb, seed=77, row0=123456789012)
+        monkeypatch.delenv("EPG_NULL_HIST")
+        assert torch.equal(Oa, Qa) and torch.equal(Ob, Qb), (S_, R_, na, nb, ga, gb)
+        assert (eng.hist_to_numpy(Oa).astype(np.int64).sum(axis=1)[np.arange(R_) != R_ // 2] == ga).all()
