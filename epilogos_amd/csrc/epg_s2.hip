@@ -712,12 +712,15 @@ __global__ __launch_bounds__(256) void k_quiescent(const char* __restrict__ XA, 
 // lines through LDS; the tables (52 KB for 379 + 342 biosamples) are copied into LDS once per block.
 // ---------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float text_roundtrip_f5(float v);
-constexpr int PF_WAVES = 6;                          // 384 threads: 6 x 64 rows x (4 x 2 S + 4 S) bytes of staging next to the tables
+constexpr int PF_WAVES_MAX = 12;                     // waves per workgroup: as many 64-row staging areas as fit next to the tables
 
 // SC: the state count at compile time (the loops over the states unroll and their 4 S LDS reads overlap -- with a run-time S and
 // six waves per CU the kernel waited out every read: 2.2 ms for 15 M bins against 0.9); 0 = any S.
+// With the state count at compile time a lane first takes its 2 S counts of A and B into registers; the wave's 64 delta rows then
+// go where those histogram rows were (64 x 4 S bytes either way), so a wave stages 8 S instead of 12 S bytes per bin and twelve
+// waves instead of six fit next to 52 KB of tables -- the kernel is latency-bound, occupancy is what it lacks.
 template <int SC>
-__global__ __launch_bounds__(64 * PF_WAVES) void k_pair_fused_s1(const u16* __restrict__ HA, const u16* __restrict__ HB, const u16* __restrict__ HnA,
+__global__ __launch_bounds__(64 * PF_WAVES_MAX) void k_pair_fused_s1(const u16* __restrict__ HA, const u16* __restrict__ HB, const u16* __restrict__ HnA,
                                                                   const u16* __restrict__ HnB, long R, int S_, const float* __restrict__ TA,
                                                                   int entA, const float* __restrict__ TB, int entB, const float* __restrict__ TnA,
                                                                   int entnA, const float* __restrict__ TnB, int entnB, float* __restrict__ delta,
@@ -739,10 +742,11 @@ __global__ __launch_bounds__(64 * PF_WAVES) void k_pair_fused_s1(const u16* __re
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int hb = 2 * S, rowb = 4 * S;
     const size_t tab_bytes = ((size_t)(reinterpret_cast<char*>(tend) - smem) + 15) & ~(size_t)15;
-    char* stage = smem + tab_bytes + (size_t)wave * 64 * (4 * hb + rowb);
-    char* sA = stage, *sB = sA + 64 * hb, *snA = sB + 64 * hb, *snB = snA + 64 * hb, *sD = snB + 64 * hb;
+    const int nwaves = blockDim.x >> 6;
+    char* stage = smem + tab_bytes + (size_t)wave * 64 * (4 * hb + (SC ? 0 : rowb));
+    char* sA = stage, *sB = sA + 64 * hb, *snA = sB + 64 * hb, *snB = snA + 64 * hb, *sD = SC ? sA : snB + 64 * hb;
     const long ntiles = (R + 63) >> 6;
-    for (long tile = (long)blockIdx.x * PF_WAVES + wave; tile < ntiles; tile += (long)gridDim.x * PF_WAVES) {
+    for (long tile = (long)blockIdx.x * nwaves + wave; tile < ntiles; tile += (long)gridDim.x * nwaves) {
         const long row0 = tile * 64;
         const int rows = (int)(R - row0 < 64 ? R - row0 : 64);
         load_staged(sA, reinterpret_cast<const char*>(HA + row0 * S), rows * hb, lane);
@@ -758,12 +762,24 @@ __global__ __launch_bounds__(64 * PF_WAVES) void k_pair_fused_s1(const u16* __re
             float* pd = reinterpret_cast<float*>(sD + lane * rowb);
             // a score = the table entry of (count, state); count 0 scores 0 (k_score_s1_from_hist)
             auto sc = [S](const float* t, u32 c, int s) { return c ? t[(long)c * S + s] : 0.0f; };
+            // SC: the counts of A and B into registers before any lane's delta row overwrites them (every lane's reads are
+            // issued before the first write: a wave's LDS operations execute in order)
+            u32 ca[SC ? SC : 1], cb[SC ? SC : 1];
+            if (SC) {
+#pragma unroll
+                for (int s = 0; s < SC; ++s) {
+                    ca[s] = ha[s];
+                    cb[s] = hbq[s];
+                }
+                __builtin_amdgcn_wave_barrier();
+                asm volatile("" ::: "memory");
+            }
             // delta and STEP 4's reduction of it: ascending states, "%.5f" round trip, ties to the higher state (k_pair_metrics)
             float sq = 0.f, sd = 0.f, best = -1.f;
             int arg = S;
 #pragma unroll
             for (int s = 0; s < S; ++s) {
-                const float d0 = sc(tA, ha[s], s) - sc(tB, hbq[s], s);
+                const float d0 = sc(tA, SC ? ca[SC ? s : 0] : (u32)ha[s], s) - sc(tB, SC ? cb[SC ? s : 0] : (u32)hbq[s], s);
                 pd[s] = d0;
                 const float d = text_roundtrip_f5(d0);
                 sq = __fadd_rn(sq, sq_nofma(d));
@@ -831,11 +847,20 @@ int pair_scores_s1_impl(const uint16_t* HA, const uint16_t* HB, const uint16_t* 
     const int entA = (NA + 1) * S, entB = (NB + 1) * S, entnA = (ga + 1) * S, entnB = (gb + 1) * S;
     size_t tab = (size_t)(entA + entB + (TnA == TA ? 0 : entnA) + (TnB == TB ? 0 : entnB)) * 4;
     tab = (tab + 15) & ~(size_t)15;
-    const size_t shmem = tab + (size_t)PF_WAVES * 64 * (4 * 2 * S + 4 * S);
+    const bool sc = S == 18 || S == 15 || S == 25;                                   // the instantiations with S at compile time
+    const size_t per_wave = (size_t)64 * (4 * 2 * S + (sc ? 0 : 4 * S));
     // the tables of wide groups do not fit next to the staging areas: the caller takes the four score passes, pair_finish and
     // pair_metrics instead (same results)
-    if (shmem > 160 * 1024) return fail(EPG_ERR_UNSUPPORTED, "pair_scores_s1: %zu bytes of LDS needed for groups of %d / %d / %d / %d columns", shmem, NA, NB, ga, gb);
-    long blocks = ((R + 63) / 64 + PF_WAVES - 1) / PF_WAVES;
+    if (tab + 4 * per_wave > 160 * 1024)
+        return fail(EPG_ERR_UNSUPPORTED, "pair_scores_s1: %zu bytes of LDS needed for groups of %d / %d / %d / %d columns", tab + 4 * per_wave, NA, NB, ga, gb);
+    int waves = (int)((160 * 1024 - tab) / per_wave);
+    if (waves > PF_WAVES_MAX) waves = PF_WAVES_MAX;
+    {
+        const char* e = getenv("EPG_PAIR_WAVES");                                     // A/B measurements
+        if (e && atoi(e) >= 1 && atoi(e) < waves) waves = atoi(e);
+    }
+    const size_t shmem = tab + (size_t)waves * per_wave;
+    long blocks = ((R + 63) / 64 + waves - 1) / waves;
     if (blocks > num_cus()) blocks = num_cus();
 #define PF_LAUNCH(SC)                                                                                                            \
     do {                                                                                                                         \
@@ -844,7 +869,7 @@ int pair_scores_s1_impl(const uint16_t* HA, const uint16_t* HB, const uint16_t* 
             EPG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pair_fused_s1<SC>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
             attr_set = true;                                                                                                     \
         }                                                                                                                        \
-        hipLaunchKernelGGL(k_pair_fused_s1<SC>, dim3((unsigned)blocks), dim3(64 * PF_WAVES), shmem, st, HA, HB, HnA, HnB, (long)R, S, TA, entA, TB, \
+        hipLaunchKernelGGL(k_pair_fused_s1<SC>, dim3((unsigned)blocks), dim3(64 * waves), shmem, st, HA, HB, HnA, HnB, (long)R, S, TA, entA, TB, \
                            entB, TnA, entnA, TnB, entnB, delta, ndist, rdist, maxdiff);                                          \
     } while (0)
     if (S == 18) PF_LAUNCH(18);
