@@ -23,7 +23,6 @@
 #include "epg_common.h"
 
 #include <stdlib.h>
-#include <utility>
 
 namespace epg {
 
@@ -58,21 +57,7 @@ constexpr long G_KC_MAX = 1048576;                      // bins per chunk the wo
 constexpr long G_KC_MIN = 16384;
 constexpr long G_REDUCED_MIN_BINS = 262144;             // calls shorter than this take the full contraction (see hist_s3_gemm)
 
-// Two workgroup geometries share the host code: 0 = 2 x 4 waves of 3 x 3 tiles (k_s3_syrk_fp4, k_s3_syrk_pp), 1 = 2 x 2 waves of
-// 4 x 4 tiles, one wave per SIMD (k_s3_syrk_w4).  A geometry fixes the padding of the operand's rows, the task grid and its patches.
-struct GGeo {
-    int wm, wn, t, patch_p, patch_q;
-    __host__ __device__ int bm() const { return wm * t * 32; }
-    __host__ __device__ int bn() const { return wn * t * 32; }
-    __host__ __device__ int rows_padded(int NS) const { return (NS + bn() - 1) / bn() * bn(); }   // bn is a multiple of bm
-    __host__ __device__ int pmax(int Q) const { return (wn * Q + wn - 1) / wm; }                   // tasks (P, Q) with some bm <= bn
-    __host__ __device__ int ntasks(int NQ) const {
-        int n = 0;
-        for (int Q = 0; Q < NQ; ++Q) n += pmax(Q) + 1;
-        return n;
-    }
-};
-constexpr GGeo GEO33 = {G_WM, G_WN, 3, G_PATCH_P, G_PATCH_Q}, GEO44 = {2, 2, 4, 4, 8};
+__host__ __device__ inline int g_rows_padded(int NS) { return (NS + G_BN - 1) / G_BN * G_BN; }
 
 // SWAR one-hot of 32 state bytes (two uint4) against the lane's state: fp4 nibbles, 0b0010 where equal (see
 // epg_s3_mfma.hip: both operands come from this routine, so which bin lands in which nibble does not matter)
@@ -103,14 +88,23 @@ __global__ __launch_bounds__(256) void k_s3_onehot_fp4(const char* __restrict__ 
     }
 }
 
-// Workgroup tasks (P = tuple of A blocks, Q = tuple of B blocks; needed when some bm <= bn, i.e. P <= pmax(Q)), patch by patch.
-__global__ void k_s3_tasks(GGeo geo, int NQ, int* __restrict__ tasks) {
+// Workgroup tasks (P = G_WM-tuple of A blocks, Q = G_WN-tuple of B blocks; needed when some bm <= bn, i.e. P <= g_pmax(Q)),
+// patch by patch.
+__host__ __device__ inline int g_pmax(int Q) { return (G_WN * Q + G_WN - 1) / G_WM; }
+
+static int g_ntasks(int NQ) {
+    int n = 0;
+    for (int Q = 0; Q < NQ; ++Q) n += g_pmax(Q) + 1;
+    return n;
+}
+
+__global__ void k_s3_tasks(int NQ, int* __restrict__ tasks) {
     if (threadIdx.x || blockIdx.x) return;
     int n = 0;
-    for (int qq = 0; qq * geo.patch_q < NQ; ++qq)
-        for (int pp = 0; pp * geo.patch_p <= geo.pmax(qq * geo.patch_q + geo.patch_q - 1); ++pp)
-            for (int Q = qq * geo.patch_q; Q < qq * geo.patch_q + geo.patch_q && Q < NQ; ++Q)
-                for (int P = pp * geo.patch_p; P < pp * geo.patch_p + geo.patch_p && P <= geo.pmax(Q); ++P) tasks[n++] = P | (Q << 16);
+    for (int qq = 0; qq * G_PATCH_Q < NQ; ++qq)
+        for (int pp = 0; pp * G_PATCH_P <= g_pmax(qq * G_PATCH_Q + G_PATCH_Q - 1); ++pp)
+            for (int Q = qq * G_PATCH_Q; Q < qq * G_PATCH_Q + G_PATCH_Q && Q < NQ; ++Q)
+                for (int P = pp * G_PATCH_P; P < pp * G_PATCH_P + G_PATCH_P && P <= g_pmax(Q); ++P) tasks[n++] = P | (Q << 16);
 }
 
 // the six operand tiles of one k-step: issued as a batch, consumed one batch of nine MFMAs later
@@ -183,18 +177,17 @@ __device__ __forceinline__ void g_mfma_loads(const GOps& o, bool active, v16f (&
 // lanes along m: the tile goes through a padded 32 x 33 LDS scratch (the ring is free once every wave has passed the
 // barrier below) and comes back transposed.  With lanes along n the mirrored atomics touched 32 lines per instruction
 // and an epilogue cost ~1.8 ms per launch (3.5-3.9 ms per chunk with the two K splits).
-template <int T>   // T x T tiles of 32 x 32 per wave; bm, bn: the wave's block row / column in units of 32 T rows
-__device__ __forceinline__ void g_epilogue(v16f (&acc)[T][T], char* smem, int w, int lane, int bm, int bn, int N, int S,
+__device__ __forceinline__ void g_epilogue(v16f (&acc)[3][3], char* smem, int w, int lane, int bm, int bn, int N, int S,
                                            int* __restrict__ counts, int* __restrict__ marg) {
     const int NS = N * S;
     const long SS = (long)S * S;
     float* scr = reinterpret_cast<float*>(smem) + w * (32 * 33);
     const int lm = lane & 31, lh = lane >> 5;
 #pragma unroll
-    for (int ta = 0; ta < T; ++ta)
+    for (int ta = 0; ta < 3; ++ta)
 #pragma unroll
-        for (int tb = 0; tb < T; ++tb) {
-            const int m0 = (bm * T + ta) * 32, n0 = (bn * T + tb) * 32;
+        for (int tb = 0; tb < 3; ++tb) {
+            const int m0 = (bm * 3 + ta) * 32, n0 = (bn * 3 + tb) * 32;
             {
                 const int n = n0 + lm;
                 const int b = n / S, j = n - b * S;
@@ -339,7 +332,7 @@ __global__ __launch_bounds__(64 * G_NW, 2) void k_s3_syrk_fp4(const char* __rest
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the tail's dummy loads
     __builtin_amdgcn_s_barrier();
     if (!active || (dbg & 2)) return;                     // dbg 2: no epilogue (measurements only)
-    g_epilogue<3>(acc, smem, w, lane, bm, bn, N, S, counts, marg);
+    g_epilogue(acc, smem, w, lane, bm, bn, N, S, counts, marg);
 }
 
 // ---- the same contraction with the two waves of a SIMD in opposite phases ("ping-pong", round 3; EPG_S3_SYRK=pp) -----------
@@ -514,165 +507,7 @@ __global__ __launch_bounds__(64 * G_NW, 2) void k_s3_syrk_pp(const char* __restr
                    trace[i + 4] - trace[i + 3]);
     }
     if (!active || (dbg & 2)) return;
-    g_epilogue<3>(acc, smem, w, lane, bm, bn, N, S, counts, marg);
-}
-
-// ---- one wave per SIMD, 4 x 4 tiles per wave (round 3, last; EPG_S3_SYRK=w4) ---------------------------------------------------
-// tools/ubench/syrk_shape.hip runs the instruction streams of candidate workgroup shapes on L2-hot data: 2 x 4 waves of 3 x 3
-// tiles (the kernels above) reach 7.95 PFLOP/s-equivalent, 2 x 2 waves of 4 x 4 tiles -- 256 accumulator registers per wave, which
-// the compiler places in the AGPR half of a 512-register budget, one wave per SIMD -- 8.94: per MFMA the wave issues 0.5 instead
-// of 0.67 ds_read_b128 (8 operand tiles feed 16 MFMAs instead of 6 feeding 9) and the same 0.25 DMA pieces, and with nobody
-// else on the SIMD each of them issues in the shadow of the wave's own running MFMA.  Workgroup = 256 x 256 cells of C, 16 operand
-// tiles per k-step, a stage of two k-steps is 32 KiB = eight 1 KiB pieces per wave and no surplus, ring of four stages.  Same
-// pipeline as k_s3_syrk_fp4 (one barrier per stage, DMA two to three stages ahead, the reads of a k-step issued during the MFMAs
-// of the previous one), but reads and pieces go out one per MFMA slot instead of in batches.
-constexpr int W4_T = 4, W4_NW = 4, W4_TA = 8, W4_TB = 8, W4_LOADS = 8, W4_LA = 4, W4_RING = 4;
-constexpr int W4_STAGE_BYTES = 2 * (W4_TA + W4_TB) * 1024;
-constexpr int W4_LDS_BYTES = W4_RING * W4_STAGE_BYTES + W4_NW * 1024;
-
-struct W4Ops {
-    v4i a[4], b[4];
-};
-
-template <int KS_IMM, int I>
-__device__ __forceinline__ void w4_read1(W4Ops& o, u32 aA, u32 aB) {
-    if constexpr (I < 4)
-        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(o.a[I]) : "v"(aA), "n"((KS_IMM * (W4_TA + W4_TB) + I) * 1024) : "memory");
-    else
-        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(o.b[I - 4]) : "v"(aB), "n"((KS_IMM * (W4_TA + W4_TB) + I - 4) * 1024) : "memory");
-}
-
-__device__ __forceinline__ void w4_wait_lds(W4Ops& o) {
-    asm volatile("s_waitcnt lgkmcnt(0)"
-                 : "+v"(o.a[0]), "+v"(o.a[1]), "+v"(o.a[2]), "+v"(o.a[3]), "+v"(o.b[0]), "+v"(o.b[1]), "+v"(o.b[2]), "+v"(o.b[3])::"memory");
-}
-
-// slot I of a k-step: MFMA I on the current operands, then ONE other instruction: slots 0-7 the reads of the next k-step's tiles
-// (KS_NEXT: which k-step of the stage at aA / aB), slots 8, 10, 12, 14 the wave's DMA pieces J0 .. J0 + 3
-template <bool ACTIVE, int KS_NEXT, int J0, int I, typename Load>
-__device__ __forceinline__ void w4_slot(const W4Ops& cur, W4Ops& nxt, u32 aA, u32 aB, v16f (&acc)[4][4], Load& load) {
-    constexpr int a = I / 4, b = I % 4;
-    if constexpr (ACTIVE)
-        acc[a][b] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(__builtin_shufflevector(cur.a[a], cur.a[a], 0, 1, 2, 3, -1, -1, -1, -1),
-                                                                    __builtin_shufflevector(cur.b[b], cur.b[b], 0, 1, 2, 3, -1, -1, -1, -1),
-                                                                    acc[a][b], 4, 4, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
-    __builtin_amdgcn_sched_barrier(0);
-    if constexpr (I < 8) {
-        w4_read1<KS_NEXT, I>(nxt, aA, aB);
-    } else if constexpr ((I & 1) == 0) {
-        load(J0 + (I - 8) / 2);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-}
-
-// (a wave without a block pair of its own -- bm > bn on a diagonal workgroup -- runs the same reads and pieces without the MFMAs:
-// one wave-uniform branch per k-step, not per slot, so that the accumulators never pass through a join)
-template <int KS_NEXT, int J0, typename Load, int... I>
-__device__ __forceinline__ void w4_kstep(const W4Ops& cur, W4Ops& nxt, bool active, u32 aA, u32 aB, v16f (&acc)[4][4], Load&& load,
-                                         std::integer_sequence<int, I...>) {
-    if (active)
-        (w4_slot<true, KS_NEXT, J0, I>(cur, nxt, aA, aB, acc, load), ...);
-    else
-        (w4_slot<false, KS_NEXT, J0, I>(cur, nxt, aA, aB, acc, load), ...);
-}
-
-__global__ __launch_bounds__(64 * W4_NW, 1) void k_s3_syrk_w4(const char* __restrict__ E4, int NT, long nstages, long stages_per_split,
-                                                            const int* __restrict__ tasks, int ntasks, int N, int S,
-                                                            int* __restrict__ counts, int dbg, const int* __restrict__ gate, int want,
-                                                            int* __restrict__ marg) {
-    if (gate && *gate != want) return;
-    extern __shared__ __attribute__((aligned(1024))) char smem[];
-    const int lane = threadIdx.x & 63;
-    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int wm = w >> 1, wn = w & 1;
-    const int xcd = blockIdx.x & 7, q8 = ntasks >> 3, r8 = ntasks & 7;
-    const int tix = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (blockIdx.x >> 3);
-    const int task = tasks[tix];
-    const int P = task & 0xffff, Q = task >> 16;
-    const int bm = 2 * P + wm, bn = 2 * Q + wn;
-    const bool active = bm <= bn && !(dbg & 8);
-    const long g0 = (long)blockIdx.y * stages_per_split;
-    const int G = (int)(nstages - g0 < stages_per_split ? nstages - g0 : stages_per_split);
-    if (G <= 0) return;
-
-    // this wave's eight pieces of a stage: slot = w + 4 j -> (k-step, tile) -> byte offset inside the stage's two k-steps
-    u32 soff[W4_LOADS], doff[W4_LOADS];
-    char* const scrap = smem + W4_RING * W4_STAGE_BYTES + w * 1024;
-#pragma unroll
-    for (int j = 0; j < W4_LOADS; ++j) {
-        const int sl = w + W4_NW * j;
-        const int ks = sl / (W4_TA + W4_TB), t = sl - ks * (W4_TA + W4_TB);
-        const int gt = (dbg & 1) ? t : (t < W4_TA ? P * W4_TA + t : Q * W4_TB + (t - W4_TA));
-        soff[j] = (u32)(ks * NT + gt) * 1024u + (u32)lane * 16u;
-        doff[j] = (u32)sl * 1024;
-    }
-    const char* src0 = E4 + g0 * 2 * (long)NT * 1024;
-    const long stage_stride = 2L * NT * 1024;
-    auto loads_for = [&](int gs, int into_slot) {
-        const bool real = gs < G && !(dbg & 16);
-        const char* lsrc = src0 + (real ? (long)gs * stage_stride : 0L);
-        char* ldst = smem + into_slot * W4_STAGE_BYTES;
-        return [=, &soff, &doff](int j) {
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(lsrc + soff[j]),
-                                             (__attribute__((address_space(3))) void*)(real ? ldst + doff[j] : scrap), 16, 0, 0);
-        };
-    };
-
-    v16f acc[4][4];
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int b = 0; b < 4; ++b)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-
-    const u32 lds0 = (u32)(uintptr_t)smem + (u32)lane * 16;
-    const u32 baseA = lds0 + (u32)(wm * 4) * 1024, baseB = lds0 + (u32)(W4_TA + wn * 4) * 1024;
-    // prologue: stages 0 .. RING - 2 whole, the second half of stage RING - 1's pieces (its first half goes out in the first turn)
-#pragma unroll
-    for (int st = 0; st < W4_RING - 1; ++st) {
-        auto ld = loads_for(st, st);
-#pragma unroll
-        for (int j = 0; j < W4_LOADS; ++j) ld(j);
-    }
-    {
-        auto ld = loads_for(W4_RING - 1, W4_RING - 1);
-#pragma unroll
-        for (int j = W4_LA; j < W4_LOADS; ++j) ld(j);
-    }
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((W4_RING - 2) * W4_LOADS + (W4_LOADS - W4_LA)) : "memory");
-    __builtin_amdgcn_s_barrier();
-    W4Ops o0, o1;
-    w4_read1<0, 0>(o0, baseA, baseB); w4_read1<0, 1>(o0, baseA, baseB); w4_read1<0, 2>(o0, baseA, baseB); w4_read1<0, 3>(o0, baseA, baseB);
-    w4_read1<0, 4>(o0, baseA, baseB); w4_read1<0, 5>(o0, baseA, baseB); w4_read1<0, 6>(o0, baseA, baseB); w4_read1<0, 7>(o0, baseA, baseB);
-    w4_wait_lds(o0);
-    constexpr auto seq = std::make_integer_sequence<int, 16>{};
-    int slot = 0, slot_prev = W4_RING - 1;
-    for (int g = 0; g < G; ++g) {
-        const u32 so = (u32)slot * W4_STAGE_BYTES;
-        const int slot1 = slot == W4_RING - 1 ? 0 : slot + 1;
-        // k-step 0 of stage g; meanwhile: the tiles of its k-step 1, pieces 0-3 of stage g + RING - 1 into the slot of stage g - 1
-        w4_kstep<1, 0>(o0, o1, active, baseA + so, baseB + so, acc, loads_for(g + W4_RING - 1, slot_prev), seq);
-        w4_wait_lds(o1);
-        const bool more = g + 1 < G;
-        if (more) {
-            // stage g + 1: this wave's pieces have landed (two younger batches stay in flight); after the barrier everybody's, and
-            // every wave holds its last operands of stage g in registers: the slot is free
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((W4_RING - 2) * W4_LOADS) : "memory");
-            __builtin_amdgcn_s_barrier();
-        }
-        const u32 sn = (u32)slot1 * W4_STAGE_BYTES;
-        // k-step 1; meanwhile: the tiles of stage g + 1's k-step 0 (past the last stage: whatever the next slot holds, never
-        // used), pieces 4-7 of stage g + RING into the slot of stage g
-        w4_kstep<0, W4_LA>(o1, o0, active, baseA + sn, baseB + sn, acc, loads_for(g + W4_RING, slot), seq);
-        w4_wait_lds(o0);
-        slot_prev = slot;
-        slot = slot1;
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    if (!active || (dbg & 2)) return;
-    g_epilogue<4>(acc, smem, w, lane, bm, bn, N, S, counts, marg);
+    g_epilogue(acc, smem, w, lane, bm, bn, N, S, counts, marg);
 }
 
 int transpose_states(const char* X, int64_t R, int32_t N, int64_t ldx, int32_t S, char* XT, int64_t Rp, int shift, hipStream_t st);
@@ -680,35 +515,24 @@ int transpose_states(const char* X, int64_t R, int32_t N, int64_t ldx, int32_t S
 static long g_chunk_bins(long Rp) { return Rp < G_KC_MAX ? Rp : G_KC_MAX; }
 static int64_t g_reduced_bytes(int N, int S);
 
-// geometry of a call: EPG_S3_SYRK=w4 selects the one-wave-per-SIMD kernel (read per call)
-static const GGeo& g_geo() {
-    const char* e = getenv("EPG_S3_SYRK");
-    return e && e[0] == 'w' ? GEO44 : GEO33;
-}
-// transposed matrix | task list (sized for either geometry); NS = rows of the operand
-static int64_t g_fixed_bytes(long Rp, int N, int NS) {
-    const int n33 = GEO33.ntasks(GEO33.rows_padded(NS) / GEO33.bn()), n44 = GEO44.ntasks(GEO44.rows_padded(NS) / GEO44.bn());
-    return align_up((int64_t)N * Rp + 64, 1024) + align_up((int64_t)(n33 > n44 ? n33 : n44) * 4, 1024);
-}
-static int g_nt_max(int NS) {                          // operand tiles per k-step, the larger padding of the two geometries
-    const int a = GEO33.rows_padded(NS) / 32, b = GEO44.rows_padded(NS) / 32;
-    return a > b ? a : b;
+static int64_t g_fixed_bytes(long Rp, int N, int NQ) {
+    return align_up((int64_t)N * Rp + 64, 1024) + align_up((int64_t)g_ntasks(NQ) * 4, 1024);
 }
 
 // smallest workspace the kernel can run with (a 16 K-bin chunk of the operand) -- less than that and the caller's
 // buffer goes to the build-in-kernel variant instead
 int64_t s3_gemm_ws_min_bytes(int64_t R, int N, int S) {
     const long Rp = align_up(R, 512);
-    const int NT = g_nt_max(N * S);
+    const int NSP = g_rows_padded(N * S), NT = NSP / 32, NQ = NSP / G_BN;
     const long kc = Rp < G_KC_MIN ? Rp : G_KC_MIN;
-    return g_fixed_bytes(Rp, N, N * S) + (int64_t)NT * 1024 * (kc / 64);
+    return g_fixed_bytes(Rp, N, NQ) + (int64_t)NT * 1024 * (kc / 64);
 }
 
 // workspace: XT | task list | E4 chunk
 int64_t s3_gemm_ws_bytes(int64_t R, int N, int S) {
     const long Rp = align_up(R, 512);
-    const int NT = g_nt_max(N * S);
-    return g_fixed_bytes(Rp, N, N * S) + (int64_t)NT * 1024 * (g_chunk_bins(Rp) / 64) + (S >= 3 ? g_reduced_bytes(N, S) : 0);
+    const int NSP = g_rows_padded(N * S), NT = NSP / 32, NQ = NSP / G_BN;
+    return g_fixed_bytes(Rp, N, NQ) + (int64_t)NT * 1024 * (g_chunk_bins(Rp) / 64) + (S >= 3 ? g_reduced_bytes(N, S) : 0);
 }
 
 int transpose_states_flag(const char* X, int64_t R, int32_t N, int64_t ldx, int32_t S, char* XT, int64_t Rp, int shift, int bad, int* dirty,
@@ -819,11 +643,11 @@ int hist_s3_gemm(const char* X, int64_t R, int32_t N, int64_t ldx, int32_t S, in
     const char* red_env = getenv("EPG_S3_REDUCED");
     const bool no_reduced = red_env ? red_env[0] == '0' : R < G_REDUCED_MIN_BINS;
     const long Rp = align_up(R, 512);                  // whole stages; padded bins hold 31, which matches no row
-    const GGeo geo = g_geo();
-    const int NS = N * S, NSP = geo.rows_padded(NS), NT = NSP / 32, NQ = NSP / geo.bn();
+    const int NS = N * S, NSP = g_rows_padded(NS), NT = NSP / 32, NQ = NSP / G_BN;
+    const int ntasks = g_ntasks(NQ);
     char* XT = reinterpret_cast<char*>(ws);
     int* tasks = reinterpret_cast<int*>(XT + align_up((int64_t)N * Rp + 64, 1024));
-    char* E4 = XT + g_fixed_bytes(Rp, N, NS);
+    char* E4 = reinterpret_cast<char*>(tasks) + align_up((int64_t)ntasks * 4, 1024);
     static bool attr_set = false;
     if (dbg_env & 4) {
         int nblk = -1;
@@ -836,7 +660,6 @@ int hist_s3_gemm(const char* X, int64_t R, int32_t N, int64_t ldx, int32_t S, in
                                     g_lds_bytes(3)));
         EPG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_s3_syrk_fp4<4>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     g_lds_bytes(4)));
-        EPG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_s3_syrk_w4), hipFuncAttributeMaxDynamicSharedMemorySize, W4_LDS_BYTES));
         EPG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_s3_syrk_pp<4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, g_lds_bytes(4)));
         EPG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_s3_syrk_pp<4, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     g_lds_bytes(4) + G_NW * 1024));
@@ -852,7 +675,7 @@ int hist_s3_gemm(const char* X, int64_t R, int32_t N, int64_t ldx, int32_t S, in
         if (KC > (1L << 24) - 512) KC = (1L << 24) - 512;   // float32 accumulators hold exact integers
         return KC;
     };
-    const int64_t fixed = g_fixed_bytes(Rp, N, NS);
+    const int64_t fixed = g_fixed_bytes(Rp, N, NQ);
     // the reduced path when the workspace also holds its count array and still a 16 K-bin chunk of the operand
     const int64_t red = g_reduced_bytes(N, S);
     const bool reduced = !no_reduced && S >= 3 && ws_bytes - fixed - red >= (int64_t)NT * 1024 * (G_KC_MIN / 64 < Rp / 64 ? G_KC_MIN / 64 : Rp / 64);
@@ -861,7 +684,7 @@ int hist_s3_gemm(const char* X, int64_t R, int32_t N, int64_t ldx, int32_t S, in
         if (KC < 512) return fail(EPG_ERR_WORKSPACE, "hist_s3: workspace too small for the precomputed-operand kernel");
         int rc = transpose_states(X, R, N, ldx, S, XT, Rp, 0, st);
         if (rc) return rc;
-        hipLaunchKernelGGL(k_s3_tasks, dim3(1), dim3(1), 0, st, geo, NQ, tasks);
+        hipLaunchKernelGGL(k_s3_tasks, dim3(1), dim3(1), 0, st, NQ, tasks);
         EPG_LAUNCH_CHECK("k_s3_tasks");
         return hist_s3_gemm_run(XT, Rp, N, S, counts, tasks, E4, KC, dbg_env, nullptr, 0, nullptr, st);
     }
@@ -875,9 +698,9 @@ int hist_s3_gemm(const char* X, int64_t R, int32_t N, int64_t ldx, int32_t S, in
     int rc = transpose_states_flag(X, R, N, ldx, S, XT, Rp, 0, 31, dirty, st);
     if (rc) return rc;
     // clean call: the contraction without state S - 1 (same XT: a byte S - 1 matches none of the N (S - 1) rows), then the rest
-    const int NQ1 = geo.rows_padded(N * (S - 1)) / geo.bn();
+    const int NQ1 = g_rows_padded(N * (S - 1)) / G_BN;
     int* tasks1 = tasks;                                                   // the reduced task list is a prefix-compatible rebuild
-    hipLaunchKernelGGL(k_s3_tasks, dim3(1), dim3(1), 0, st, geo, NQ1, tasks1);
+    hipLaunchKernelGGL(k_s3_tasks, dim3(1), dim3(1), 0, st, NQ1, tasks1);
     EPG_LAUNCH_CHECK("k_s3_tasks");
     rc = hist_s3_gemm_run(XT, Rp, N, S - 1, Cr, tasks1, E4, KC, dbg_env, dirty, 0, marg, st);
     if (rc) return rc;
@@ -890,7 +713,7 @@ int hist_s3_gemm(const char* X, int64_t R, int32_t N, int64_t ldx, int32_t S, in
         EPG_LAUNCH_CHECK("k_s3_reconstruct");
     }
     // a call with a "not a state" byte: the full contraction (its launches return at once on a clean call)
-    hipLaunchKernelGGL(k_s3_tasks, dim3(1), dim3(1), 0, st, geo, NQ, tasks);
+    hipLaunchKernelGGL(k_s3_tasks, dim3(1), dim3(1), 0, st, NQ, tasks);
     EPG_LAUNCH_CHECK("k_s3_tasks");
     return hist_s3_gemm_run(XT, Rp, N, S, counts, tasks, E4, KC, dbg_env, dirty, 1, nullptr, st);
 }
@@ -898,10 +721,8 @@ int hist_s3_gemm(const char* X, int64_t R, int32_t N, int64_t ldx, int32_t S, in
 // the chunk loop of one contraction over the transposed matrix: one-hot operand of a chunk, then the SYRK kernel
 static int hist_s3_gemm_run(const char* XT, long Rp, int N, int S, int32_t* counts, int* tasks, char* E4, long KC, int dbg_env,
                             const int* gate, int want, int* marg, hipStream_t st) {
-    const GGeo geo = g_geo();
-    const bool w4 = geo.t == 4;
-    const int NS = N * S, NSP = geo.rows_padded(NS), NT = NSP / 32, NQ = NSP / geo.bn();
-    const int ntasks = geo.ntasks(NQ);
+    const int NS = N * S, NSP = g_rows_padded(NS), NT = NSP / 32, NQ = NSP / G_BN;
+    const int ntasks = g_ntasks(NQ);
     for (long k0 = 0; k0 < Rp; k0 += KC) {
         const long kc = Rp - k0 < KC ? Rp - k0 : KC;   // multiple of 512
         const long nksteps = kc / 64, nstages = nksteps / G_KS;
@@ -923,7 +744,6 @@ static int hist_s3_gemm_run(const char* XT, long Rp, int N, int S, int32_t* coun
             if (waste < best_waste - 0.01) { best_waste = waste; best = sp; }
         }
         splits = best;
-        if (const char* e = getenv("EPG_S3_SPLITS")) if (atol(e) > 0) splits = atol(e);        // measurements
         if (splits > nstages) splits = nstages;
         if (splits < 1) splits = 1;
         if (splits > 65535) splits = 65535;
@@ -936,10 +756,7 @@ static int hist_s3_gemm_run(const char* XT, long Rp, int N, int S, int32_t* coun
         // EPG_S3_SYRK=pp: the ping-pong schedule (k_s3_syrk_pp; EPG_S3_DBG & 32: with the segment trace of one workgroup)
         const char* syrk_env = getenv("EPG_S3_SYRK");
         const bool pp = syrk_env && syrk_env[0] == 'p';
-        if (w4)
-            hipLaunchKernelGGL(k_s3_syrk_w4, dim3((unsigned)ntasks, (unsigned)nsplit), dim3(64 * W4_NW), W4_LDS_BYTES, st, E4, NT, nstages, per, tasks,
-                               ntasks, N, S, counts, dbg_env, gate, want, marg);
-        else if (pp && (dbg_env & 32))
+        if (pp && (dbg_env & 32))
             hipLaunchKernelGGL((k_s3_syrk_pp<4, true>), dim3((unsigned)ntasks, (unsigned)nsplit), dim3(64 * G_NW), g_lds_bytes(4) + G_NW * 1024, st,
                                E4, NT, nstages, per, tasks, ntasks, N, S, counts, dbg_env, gate, want, marg);
         else if (pp)

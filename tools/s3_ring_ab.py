@@ -30,7 +30,7 @@ def child(bins, reps):
         e0.record(); engine.hist_s3(X, N, S, counts=c3); e1.record(); torch.cuda.synchronize()
         ts.append(e0.elapsed_time(e1))
     w = (torch.arange(c3.numel(), device="cuda", dtype=torch.int64) % 1000003) + 1
-    print("ring %s syrk %s dbg %s splits %s: %.3f ms (all: %s) checksum %d total %d" % (os.environ.get("EPG_S3_RING", "default"), os.environ.get("EPG_S3_SYRK", "") or "default", os.environ.get("EPG_S3_DBG", "0"), os.environ.get("EPG_S3_SPLITS", "0"), float(np.median(ts[1:])),
+    print("ring %s syrk %s dbg %s: %.3f ms (all: %s) checksum %d total %d" % (os.environ.get("EPG_S3_RING", "default"), os.environ.get("EPG_S3_SYRK", "") or "default", os.environ.get("EPG_S3_DBG", "0"), float(np.median(ts[1:])),
           " ".join("%.2f" % t for t in ts), int((c3.long() * w).sum().item()), int(c3.long().sum().item())), flush=True)
 
 
@@ -39,12 +39,12 @@ if __name__ == "__main__":
     ap.add_argument("--bins", type=int, default=1 << 20)
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--child", action="store_true")
-    ap.add_argument("--variants", default="3::,4::,4:pp:,3::,4::,4:pp:", help="comma list of ring:syrk:dbg:splits (EPG_S3_RING, EPG_S3_SYRK, EPG_S3_DBG, EPG_S3_SPLITS)")
+    ap.add_argument("--variants", default="3::,4::,4:pp:,3::,4::,4:pp:", help="comma list of ring:syrk:dbg (EPG_S3_RING, EPG_S3_SYRK, EPG_S3_DBG)")
     a = ap.parse_args()
     if a.child:
         child(a.bins, a.reps)
     else:
         for v in a.variants.split(","):
-            ring, syrk, dbg, splits = (v.split(":") + ["", "", ""])[:4]
-            env = dict(os.environ, EPG_S3_RING=ring or "3", EPG_S3_SYRK=syrk, EPG_S3_DBG=dbg or "0", EPG_S3_SPLITS=splits or "0")
+            ring, syrk, dbg = (v.split(":") + ["", ""])[:3]
+            env = dict(os.environ, EPG_S3_RING=ring or "3", EPG_S3_SYRK=syrk, EPG_S3_DBG=dbg or "0")
             subprocess.run([sys.executable, __file__, "--child", "--bins", str(a.bins), "--reps", str(a.reps)], env=env, check=False)
