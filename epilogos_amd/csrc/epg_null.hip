@@ -286,12 +286,11 @@ __global__ __launch_bounds__(256) void k_null_hist_h(const u16* __restrict__ HA,
         if (lane < rows) {
             u16* pa = reinterpret_cast<u16*>(sa + lane * rowb);
             u16* pb = reinterpret_cast<u16*>(sb + lane * rowb);
-            u32 tot = 0, best = 0;
+            u32 best = 0;
             int modal = 0;
             for (int s = 0; s < S; ++s) {
                 const u32 h = (u32)pa[s] + pb[s];
                 pa[s] = (u16)h;
-                tot += h;
                 if (h > best) { best = h; modal = s; }
             }
             u32 A256 = (u32)ga << 8, AB256 = (u32)(ga + gb) << 8;
