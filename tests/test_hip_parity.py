@@ -350,7 +350,9 @@ def test_paired_scores_golden(eng, golden_pair):
         np.testing.assert_allclose(_np(o32), g["s2_" + key], rtol=3e-7, atol=ATOL)
 
 
-@pytest.mark.parametrize("NA,NB,ga,gb,R", [(379, 342, 379, 342, 5000), (5, 5, 5, 5, 2048), (40, 33, 20, 20, 3001), (7, 9, 9, 7, 64), (12, 12, 12, 12, 1)])
+@pytest.mark.parametrize("NA,NB,ga,gb,R", [(379, 342, 379, 342, 5000), (5, 5, 5, 5, 2048), (40, 33, 20, 20, 3001), (7, 9, 9, 7, 64), (12, 12, 12, 12, 1),
+                                           # wider groups: larger tables leave room for 7 / 5 waves' staging areas instead of 12
+                                           (620, 600, 620, 600, 1500), (833, 700, 833, 700, 700), (500, 480, 100, 100, 1111)])
 def test_paired_s1_in_one_pass_equals_the_separate_passes(eng, NA, NB, ga, gb, R):
     """epg_pair_scores_s1_from_binhist (scores of A, B and the null groups as table gathers, delta, null distance, STEP 4's
     reduction, one pass over the four histograms) against four epg_score_s1_from_binhist_table + two epg_pair_finish +
@@ -381,3 +383,19 @@ def test_paired_s1_in_one_pass_equals_the_separate_passes(eng, NA, NB, ga, gb, R
     assert np.array_equal(_np(delta), rd)
     wd, wx = onp.pair_metrics(rd, True)
     assert np.array_equal(_np(dist), wd) and np.array_equal(_np(mdiff), wx)
+
+
+def test_paired_s1_in_one_pass_says_when_the_tables_do_not_fit(eng):
+    """Groups so wide that the S1 tables leave no room for four waves' staging areas in a CU's LDS: EPG_ERR_UNSUPPORTED (-2), which
+    backend._HipPairedSession answers with the separate passes."""
+    from epilogos_amd.scores import s1ScoreTable
+    NA, NB, R = 900, 880, 128
+    xa, xb = synth_states(R, NA, seed=1), synth_states(R, NB, seed=2)
+    HA, cA = eng.bin_hist(eng.states_to_device(xa), NA, S)
+    HB, _ = eng.bin_hist(eng.states_to_device(xb), NB, S, counts=cA)
+    q = eng.normalise(cA).cpu().numpy()
+    HnA, HnB = eng.null_hist_from_binhist(HA, HB, NA + NB, S, NA, NB, seed=3)
+    tA, tB = (torch.from_numpy(s1ScoreTable(q, n)[1]).cuda() for n in (NA, NB))
+    with pytest.raises(eng.EpilogosHipError) as e:
+        eng.pair_scores_s1_from_binhist(HA, HB, HnA, HnB, S, NA, NB, NA, NB, tA, tB, tA, tB)
+    assert e.value.code == -2

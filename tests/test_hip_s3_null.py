@@ -370,3 +370,22 @@ def test_null_hist_bit_string_kernel_equals_the_column_by_column_kernel(eng, mon
         monkeypatch.delenv("EPG_NULL_HIST")
         assert torch.equal(Oa, Qa) and torch.equal(Ob, Qb), (S_, R_, na, nb, ga, gb)
         assert (eng.hist_to_numpy(Oa).astype(np.int64).sum(axis=1)[np.arange(R_) != R_ // 2] == ga).all()
+
+
+@pytest.mark.parametrize("na,nb", [(16, 16), (17, 16), (1500, 1572), (1600, 1600), (3000, 3001)])
+def test_null_hist_from_binhist_row_widths_around_the_kernel_switch(eng, monkeypatch, na, nb):
+    """Row widths at the word boundaries of the bit string (32, 33 columns), at the widest row the bit-string kernel takes
+    (3072 columns: 24 KB of outcome bits per wave) and beyond it, where the call goes to the column-by-column kernel by itself:
+    a permutation's bookkeeping in every case, and the same groups from both kernels wherever both apply."""
+    R_ = 200
+    ya = synth_states(R_, na, seed=na)
+    yb = synth_states(R_, nb, seed=nb + 7)
+    Ha, _ = eng.bin_hist(eng.states_to_device(ya), na, S, want_counts=False)
+    Hb, _ = eng.bin_hist(eng.states_to_device(yb), nb, S, want_counts=False)
+    tot = eng.hist_to_numpy(Ha).astype(np.int64) + eng.hist_to_numpy(Hb).astype(np.int64)
+    Oa, Ob = eng.null_hist_from_binhist(Ha, Hb, na + nb, S, na, nb, seed=5)
+    oa, ob = eng.hist_to_numpy(Oa).astype(np.int64), eng.hist_to_numpy(Ob).astype(np.int64)
+    assert np.array_equal(oa + ob, tot) and (oa.sum(axis=1) == na).all() and (ob.sum(axis=1) == nb).all()
+    monkeypatch.setenv("EPG_NULL_HIST", "seq")
+    Qa, Qb = eng.null_hist_from_binhist(Ha, Hb, na + nb, S, na, nb, seed=5)
+    assert torch.equal(Oa, Qa) and torch.equal(Ob, Qb)
