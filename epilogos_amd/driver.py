@@ -408,7 +408,7 @@ def run_single_group(files, numStates, saliency, outputDir, fileTag, verbose=Fal
     pids, locs, N = [None] * len(my_parts), [None] * len(my_parts), None
     with closing(_stream_parts([(files[fi], lo, hi) for fi, lo, hi in my_parts], sess, numStates)) as stream:
         for t, arr, n, loc in stream:                  # in order of completion; t = index in my_parts
-            N = n
+            N = max(N or 0, n)                         # an empty file has no width: it must not be the one that is remembered
             pids[t] = sess.add_part(arr, n, t)
             locs[t] = loc
     if mode == "whole":
@@ -509,9 +509,9 @@ def run_paired_groups(files1, files2, numStates, saliency, outputDir, fileTag, q
         for t, x, n, loc in stream:                    # in order of completion; jobs 2k and 2k + 1 are part k
             k, second = t // 2, t % 2
             if second:
-                NB = n
+                NB = max(NB or 0, n)                   # (an empty file has no width)
             else:
-                NA, locs[k] = n, loc
+                NA, locs[k] = max(NA or 0, n), loc
             staged = (sess.stage(x, n, t), n, x.shape[0])
             if k not in halves:
                 halves[k] = (second, staged)
