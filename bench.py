@@ -296,6 +296,29 @@ def bench_paired(torch, be, d, R, R_global, bin0, S, world, reps, fence, dev, di
             "path": "backend._HipPairedSession (the command line's session), device-resident"}
 
 
+def launch_command(gpus, argv, port):
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus),
+            "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve())] + list(argv)
+
+
+def launch_ranks(gpus, argv):
+    """One process per GPU under torch.distributed.run, as a child of this (GPU-free) process; -> its exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # dmabuf IPC: what RCCL needs on this driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, host_cores()[0] // gpus)))
+    cmd = launch_command(gpus, argv, port)
+    if os.environ.get("EPILOGOS_LAUNCH_DRYRUN"):
+        print(" ".join(cmd))
+        return 0
+    sys.stdout.flush()
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -317,18 +340,28 @@ def main():
                          "prints the line without the rest and every rank exits; 0 = no limit")
     ap.add_argument("--graph", action="store_true", help="capture the step (K1, all-reduce, combine, score) in a hipGraph and replay it "
                                                          "(kernels_ms then comes from an un-captured probe after the timed region)")
+    ap.add_argument("--path", choices=["session", "engine"], default="session",
+                    help="what a headline step runs: session = backend._HipSingleSession, the command line's own sequence of calls "
+                         "(add_device -> all_reduce -> finish_device -> scores_device; per-step allocations like the product's); "
+                         "engine = the bare ABI calls on preallocated buffers (always used by --graph)")
+    ap.add_argument("--shard-bins", type=int, default=1_875_000, help="one GPU: both paths are also timed on a shard of this "
+                                                                        "many bins (an eighth of the genome: the 8-GPU share); 0 = skip")
     ap.add_argument("--pg", action="store_true", help="one GPU: still join a one-rank RCCL process group, so that the step contains the all-reduce")
     ap.add_argument("--placement-experiment", type=int, default=1, help="0: skip the histogram-placement experiment after the timed region")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to test the "
                                                       "multi-rank path on a box with one GPU, ranks then share cuda:0)")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # a plain start with --gpus N: this process becomes the launcher (the reference's one command submits its own
+        # workers, run.py:190-279,454-505) -- it has not imported torch or touched a GPU, starts
+        # `python -m torch.distributed.run ... bench.py <same arguments>` as a CHILD (never exec), lets rank 0's one JSON
+        # line through on the inherited stdout and leaves with the child's exit code
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
         raise SystemExit("WORLD_SIZE=%d does not match --gpus %d" % (world, args.gpus))
     scaling = args.scaling or "strong"              # one GPU: the two coincide
     N, S = args.biosamples, args.states
@@ -362,10 +395,12 @@ def main():
             os.environ.setdefault("MASTER_PORT", str(29500 + os.getpid() % 2000))
             os.environ.setdefault("RANK", "0")
             os.environ.setdefault("WORLD_SIZE", "1")
+        import datetime
+        limit = datetime.timedelta(seconds=max(600, 2 * args.extras_deadline))     # a lost rank ends the run instead of hanging it
         if args.backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=dev)
+            dist.init_process_group(backend="nccl", device_id=dev, timeout=limit)
         else:
-            dist.init_process_group(backend=args.backend)
+            dist.init_process_group(backend=args.backend, timeout=limit)
 
     # ---- resident inputs and preallocated outputs: plain allocations, like the sessions of the command line
     if args.packed:
@@ -381,10 +416,18 @@ def main():
     H = torch.empty((R, S), dtype=torch.int16, device=dev)
     last_counts = torch.zeros(S, dtype=torch.int64, device=dev)
 
-    def step(H, e=None, keep=False):
+    from epilogos_amd import backend as _backend
+    from epilogos_amd.driver import _Dist
+    be = _backend.HipBackend(device=dev)
+    d = _Dist()
+    use_session = args.path == "session" and not args.graph
+    last = {}
+
+    def step_engine(Xs, Hs, outs, e=None, keep=False):
+        """The bare ABI sequence on preallocated buffers."""
         if e is not None:
             e[0].record()
-        engine.bin_hist(X, N, S, counts=counts, H=H)                       # STEP 1: expected pass (counts start zeroed)
+        engine.bin_hist(Xs, N, S, counts=counts, H=Hs)                     # STEP 1: expected pass (counts start zeroed)
         if e is not None:
             e[1].record()
         if use_pg:
@@ -394,9 +437,28 @@ def main():
         if keep:
             last_counts.copy_(counts)                                      # outside the timed steps: for the sanity check
         # STEP 2 + STEP 3: normalise + table in one kernel (it leaves counts zeroed for the next job), score pass
-        engine.combine_score_s1(counts, H, N, S, q=q, out32=out32, ws=ws_s1, rezero=True)
+        engine.combine_score_s1(counts, Hs, N, S, q=q, out32=outs, ws=ws_s1, rezero=True)
         if e is not None:
             e[3].record()
+
+    def step_session(Xs, e=None):
+        """One whole S1 job the way the command line runs it: a fresh session per job, the histogram cache, the count vector,
+        the tables and the scores allocated by the session (torch's caching allocator hands the previous job's blocks back)."""
+        sess = be.open_single(S, 1)
+        if e is not None:
+            e[0].record()
+        pid = sess.add_device(Xs, N)                                       # STEP 1: k_bin_hist (+ counts)
+        if e is not None:
+            e[1].record()
+        sess.ensure_acc(N)
+        sess.all_reduce(d)                                                 # the single collective (144 bytes)
+        if e is not None:
+            e[2].record()
+        sess.finish_device(R_global, N)                                    # STEP 2 + the S1 table: k_s1_combine, no host sync
+        last["out"] = sess.scores_device(pid)                              # STEP 3
+        if e is not None:
+            e[3].record()
+        last["sess"] = sess
 
     def fence():
         torch.cuda.synchronize()
@@ -404,9 +466,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def timed_steps(H, steps, warmup, graph=False, events=True):
-        """-> (wall seconds of `steps` steps, per-step event tuples or [], host enqueue times)."""
+    def timed_steps(Xs, Hs, outs, steps, warmup, graph=False, events=True, session=False):
+        """-> (wall seconds of `steps` steps, per-step event tuples or [], host enqueue times, this rank's own seconds:
+        from the common start to the moment ITS last step was over, before the closing barrier)."""
         ev = [tuple(torch.cuda.Event(enable_timing=True) for _ in range(4)) for _ in range(steps)] if (events and not graph) else []
+        one = (lambda e=None: step_session(Xs, e)) if session else (lambda e=None: step_engine(Xs, Hs, outs, e))
         g = None
         if graph:
             # the whole step as ONE hipGraph launch: on a 1.9 M-bin shard the step is ~0.35 ms and the host side of three
@@ -415,14 +479,14 @@ def main():
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
                 for _ in range(3):
-                    step(H)
+                    one()
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
-                step(H)
+                one()
         for _ in range(warmup):
-            g.replay() if g is not None else step(H)
+            g.replay() if g is not None else one()
         fence()
         t0 = time.perf_counter()
         host_t = []
@@ -430,33 +494,86 @@ def main():
             if g is not None:
                 g.replay()
             else:
-                step(H, ev[k] if ev else None)
+                one(ev[k] if ev else None)
             host_t.append(time.perf_counter() - t0)
+        torch.cuda.synchronize()
+        own = time.perf_counter() - t0
         fence()
-        return time.perf_counter() - t0, ev, host_t
+        return time.perf_counter() - t0, ev, host_t, own
 
-    step(H, keep=True)                                                     # untimed: sanity of one whole job
-    dt, ev, host_t = timed_steps(H, args.steps, args.warmup, graph=args.graph,
-                                 events=not os.environ.get("EPG_BENCH_NOEVENTS"))
+    if use_session:
+        step_session(X)                                                    # untimed: sanity of one whole job
+    else:
+        step_engine(X, H, out32, keep=True)
+    dt, ev, host_t, own_dt = timed_steps(X, H, out32, args.steps, args.warmup, graph=args.graph,
+                                         events=not os.environ.get("EPG_BENCH_NOEVENTS"), session=use_session)
 
     # sanity of the last step (cheap, outside the timed region): every state byte counted, scores finite
-    total = int(last_counts.sum().item())
-    assert total == R_global * N, "state counts %d != bins*biosamples %d" % (total, R_global * N)
-    assert int(counts.abs().sum().item()) == 0                             # every job left the accumulator zeroed
-    assert bool(torch.isfinite(out32[:: max(R // 4096, 1)]).all())
+    table_note = None
+    if use_session:
+        sess = last["sess"]
+        sess.check()                                                       # the deferred count check: sum == bins * biosamples
+        patched = sess.verify_tables()
+        table_note = {"built_on": "device (k_s1_combine, in the launch that normalises)",
+                      "float32_table_equals_numpy_reference_table": patched == 0}
+        res = last["out"]
+    else:
+        total = int(last_counts.sum().item())
+        assert total == R_global * N, "state counts %d != bins*biosamples %d" % (total, R_global * N)
+        assert int(counts.abs().sum().item()) == 0                         # every job left the accumulator zeroed
+        res = out32
+    assert bool(torch.isfinite(res[:: max(R // 4096, 1)]).all())
+    del res
 
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
     if not ev:                                                             # graph replay / no events: per-kernel times from a probe
-        _, ev, _ = timed_steps(H, min(args.steps, 10), 1)
+        _, ev, _, _ = timed_steps(X, H, out32, min(args.steps, 10), 1, session=use_session)
     if os.environ.get("EPG_BENCH_TRACE") and rank == 0:      # per-step k_bin_hist times (clock ramps, box variance)
         print("k_bin_hist ms per step:", " ".join("%.3f" % e[0].elapsed_time(e[1]) for e in ev), file=sys.stderr, flush=True)
         print("host enqueue done at ms:", " ".join("%.1f" % (t * 1e3) for t in host_t), file=sys.stderr, flush=True)
     hist_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))
     ar_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in ev]))
     rest_ms = float(np.mean([e[2].elapsed_time(e[3]) for e in ev]))
+
+    # ---- several ranks: what every rank saw (K1 per launch, its own time for the K steps), gathered on rank 0
+    per_rank = None
+    if world > 1:
+        mine = torch.tensor([hist_ms, own_dt * 1e3 / args.steps, ar_ms, rest_ms], dtype=torch.float64, device=dev)
+        allv = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allv, mine)
+        allv = np.array([v.cpu().numpy() for v in allv])
+        per_rank = {"k_bin_hist_ms": [round(float(v), 4) for v in allv[:, 0]],
+                    "k_bin_hist_ms_min_max": [round(float(allv[:, 0].min()), 4), round(float(allv[:, 0].max()), 4)],
+                    "own_ms_per_step": [round(float(v), 4) for v in allv[:, 1]],
+                    "skew_ms_per_step": round(float(allv[:, 1].max() - allv[:, 1].min()), 4),
+                    "allreduce_ms": [round(float(v), 4) for v in allv[:, 2]],
+                    "combine+score_ms": [round(float(v), 4) for v in allv[:, 3]],
+                    "what": "own_ms_per_step = a rank's wall time from the common start until ITS last step had drained, over the "
+                            "steps (the closing barrier excluded); skew = slowest - fastest rank"}
+
+    # ---- one GPU: the other path on the same genome, and both paths on an eighth of it (the share of one of 8 GPUs)
+    s1_paths = None
+    if world == 1 and not args.graph:
+        k = min(args.steps, 10)
+
+        def both(Xs, Hs, outs):
+            r = {}
+            for name, sessn in (("session", True), ("engine", False)):
+                t, evs, _, _ = timed_steps(Xs, Hs, outs, k, 2, session=sessn)
+                r[name + "_ms_per_step"] = round(t / k * 1e3, 4)
+                r[name + "_k_bin_hist_ms"] = round(float(np.mean([e[0].elapsed_time(e[1]) for e in evs])), 4)
+            r["session_over_engine"] = round(r["session_ms_per_step"] / r["engine_ms_per_step"], 4)
+            return r
+        s1_paths = {"steps": k, "what": "session = backend._HipSingleSession per job (the command line's calls and allocations); "
+                                         "engine = bare ABI calls on preallocated buffers, counts re-zeroed by the score launch",
+                    "genome_%d_bins" % R: both(X, H, out32)}
+        rs = min(args.shard_bins, R)
+        if 0 < rs < R:
+            s1_paths["shard_%d_bins" % rs] = both(X[:rs], H[:rs], out32[:rs])
+        last.clear()
 
     # ---- the all-reduce by itself (device time between events, host time of the call), when there is a process group
     allreduce_probe = None
@@ -481,7 +598,8 @@ def main():
     # configs 3-5) fills `placement` and `configs` in.  A watchdog on every rank bounds those extras: past --extras-deadline
     # seconds rank 0 prints the line with what it has and every rank leaves, so that a collective that never completes in a
     # secondary measurement cannot take the headline of a multi-GPU run with it.
-    placement = {"headline": "plain torch allocations for X, H and the scores -- the same code path as backend._HipSession"}
+    placement = {"headline": ("a fresh backend._HipSingleSession per step: the command line's own calls and allocations (torch's caching allocator)"
+                              if use_session else "bare ABI calls on preallocated plain torch allocations (--path engine / --graph)")}
     configs = {}
     line = None
     if rank == 0:
@@ -514,6 +632,7 @@ def main():
                        "state_distribution": args.dist,
                        "row_pitch_bytes": int(X.stride(0)),
                        "step_launch": "hipGraph replay" if args.graph else "three launches + collective per step",
+                       "step_path": "session" if use_session else "engine",
                        "partition": "contiguous bin ranges per GPU (helpers.splitRows rule), one RCCL all-reduce of int64[%d]" % S},
             "roofline": {"bound": "hbm", "kernel": "k_bin_hist", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": traffic_note,
@@ -524,6 +643,9 @@ def main():
             "kernels_ms": {"k_bin_hist": round(hist_ms, 4), "allreduce": round(ar_ms, 4),
                            "combine(normalise,table)+score_from_hist": round(rest_ms, 4)},
             "allreduce_probe": allreduce_probe,
+            "per_rank": per_rank,
+            "s1_paths": s1_paths,
+            "s1_table": table_note,
             "placement": placement,
             "configs": configs,
             "cpu_baseline": cpu,
@@ -532,12 +654,15 @@ def main():
 
     def emit():
         if rank == 0 and emitted.acquire(blocking=False):
-            for attempt in range(5):                       # the watchdog may serialise while the main thread adds a config
+            text = None
+            for attempt in range(50):                      # the watchdog may serialise while the main thread adds a config
                 try:
                     text = json.dumps(line)
                     break
                 except RuntimeError:
                     time.sleep(0.01)
+            if text is None:                               # never leave without the headline: drop what is still being filled in
+                text = json.dumps(dict(line, configs={"deadline": "extras dropped"}, placement=None))
             print(text, flush=True)
 
     def bail():
@@ -556,7 +681,7 @@ def main():
     if args.placement_experiment and world == 1 and R * X.stride(0) >= (1 << 30) and not args.packed:   # a single-GPU experiment
         try:
             Hp, rep = engine.place_hist(X, N, S, park=True)
-            dtp, evp, _ = timed_steps(Hp, min(args.steps, 10), 2)
+            dtp, evp, _, _ = timed_steps(X, Hp, out32, min(args.steps, 10), 2)
             rep["k_bin_hist_ms"] = round(float(np.mean([e[0].elapsed_time(e[1]) for e in evp])), 4)
             rep["frac"] = round(R * N / (rep["k_bin_hist_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)
             rep["ms_per_step"] = round(dtp / min(args.steps, 10) * 1e3, 4)
@@ -569,10 +694,6 @@ def main():
     # ---- BASELINE configs 3-5 through the product's sessions
     want = [] if args.configs in ("none", "") else [c.strip() for c in args.configs.split(",") if c.strip()]
     if want:
-        from epilogos_amd import backend as _backend
-        from epilogos_amd.driver import _Dist
-        be = _backend.HipBackend(device=dev)
-        d = _Dist()
         for name in want:
             try:
                 if name == "s2":

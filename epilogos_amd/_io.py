@@ -18,7 +18,8 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    path = _build.IO_LIB_PATH
+    # EPILOGOS_IO_LIB: another build of the same source (tools/asan_io.sh points it at the AddressSanitizer build)
+    path = _build.IO_LIB_PATH if not os.environ.get("EPILOGOS_IO_LIB") else __import__("pathlib").Path(os.environ["EPILOGOS_IO_LIB"])
     if not path.exists():
         raise EpilogosIOError("%s is missing: build it with `python -m epilogos_amd.build`" % path)
     lib = C.CDLL(str(path))
@@ -58,12 +59,80 @@ def load():
     lib.epgio_row_sums_f32.argtypes = [p, i64, C.c_int32, i64, p, C.c_int32]
     lib.epgio_rolling_max_f64.restype = C.c_int
     lib.epgio_rolling_max_f64.argtypes = [p, i64, C.c_int32, p, C.c_int32]
+    lib.epgio_inflate_mem.restype = i64
+    lib.epgio_inflate_mem.argtypes = [p, i64, p, i64, i32]
+    lib.epgio_default_threads.restype = i32
+    lib.epgio_default_threads.argtypes = []
+    lib.epgio_thread_census.restype = None
+    lib.epgio_thread_census.argtypes = [C.POINTER(i32), C.POINTER(i32), i32]
     _lib = lib
     return lib
 
 
 def _err():
     return load().epgio_last_error().decode(errors="replace")
+
+
+def node_cores():
+    """Cores the processes of this job may run on at once: the scheduler affinity capped by the cgroup CPU quota (a GPU box
+    shows a container 256 hardware threads and lets it run 16 at a time)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 8)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = max(1, min(n, int(int(quota) / int(period) + 0.5)))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+def host_budget():
+    """Native threads THIS rank may keep busy: the node's cores (node_cores), capped by the reference's -c/--num-cores when the
+    user gave one (EPILOGOS_NUM_CORES; run.py:36,148 -- there it sizes the worker pool), divided by the ranks that share the
+    node (LOCAL_WORLD_SIZE, set by torch.distributed.run), at least 1.  Exported as EPILOGOS_HOST_THREADS, which is what the
+    native library uses wherever its `threads` argument is 0 (parser, writers, STEP 4 helpers)."""
+    n = node_cores()
+    try:
+        cap = int(os.environ.get("EPILOGOS_NUM_CORES", "0"))
+    except ValueError:
+        cap = 0
+    if cap > 0:
+        n = min(n, cap)
+    try:
+        local_world = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1")))
+    except ValueError:
+        local_world = 1
+    b = max(1, n // local_world)
+    os.environ["EPILOGOS_HOST_THREADS"] = str(b)
+    return b
+
+
+def inflate_mem(blob, own=True, cap=None):
+    """Inflate a gzip stream held in memory with the library's own inflate (own=True) or zlib's; -> bytes, or None when the
+    stream is declined / corrupt.  For tests and the fuzz harness."""
+    blob = bytes(blob)
+    cap = cap if cap is not None else max(1 << 16, 64 * len(blob))
+    out = C.create_string_buffer(cap)
+    n = load().epgio_inflate_mem(blob, len(blob), out, cap, 1 if own else 0)
+    return None if n < 0 else out.raw[:n]
+
+
+def thread_census(reset=False):
+    """(library threads runnable right now, their peak since the last reset)."""
+    live, peak = C.c_int32(0), C.c_int32(0)
+    load().epgio_thread_census(C.byref(live), C.byref(peak), 1 if reset else 0)
+    return int(live.value), int(peak.value)
+
+
+def log_thread_census(tag=""):
+    """EPILOGOS_THREAD_LOG=<file>: one line per rank -- pid, peak of runnable library threads, this rank's budget, the node's
+    cores, LOCAL_WORLD_SIZE -- appended when a driver run ends (the multi-rank tests and profiles/ add the ranks up)."""
+    log = os.environ.get("EPILOGOS_THREAD_LOG")
+    if log:
+        _live, peak = thread_census()
+        with open(log, "a") as f:
+            f.write("%d\t%d\t%s\t%d\t%s\t%s\n" % (os.getpid(), peak, os.environ.get("EPILOGOS_HOST_THREADS", "-"), node_cores(),
+                                                  os.environ.get("LOCAL_WORLD_SIZE", "1"), tag))
 
 
 _state_limit = 31

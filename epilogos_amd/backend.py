@@ -153,6 +153,14 @@ class HipBackend:
         return _HipPairedSession(self, S, saliency, quiescentState, groupSize, seed)
 
 
+def _aligned_rows(T, lo, hi):
+    """Rows [lo, hi) of a resident part as the kernels want them: the score entry points take 16-byte aligned bases
+    (epg_s1.hip check_score_from_hist_args, epg_null.hip, epg_s2.hip), and a row slice of an [R, S] uint16 array starts at
+    lo * S * 2 bytes -- a view only when that is a multiple of 16, else a copy of just these rows."""
+    t = T[lo:hi]
+    return t if t.data_ptr() % 16 == 0 else t.clone()
+
+
 class _HipSession:
     """Shared plumbing: pinned staging, one asynchronous upload per matrix, the count accumulator."""
 
@@ -161,7 +169,10 @@ class _HipSession:
         self.torch, self.eng, self.device = be.torch, be.engine, be.device
         # staging buffers in flight; paired mode holds a part's A and B at once, so never fewer than two
         # (first come, first served: the driver takes the parts as their parsers finish)
-        self.pool = be.engine.PinnedPool(max(2, int(__import__("os").environ.get("EPILOGOS_PINNED_BUFFERS", "4"))), in_order=False)
+        # (no more of them than parser threads this rank may run: every buffer is ~1 GB of page-locked memory per rank)
+        from . import _io
+        self.pool = be.engine.PinnedPool(max(2, int(__import__("os").environ.get("EPILOGOS_PINNED_BUFFERS", min(4, _io.host_budget())))),
+                                         in_order=False)
         self.copy_stream = self.torch.cuda.Stream(device=self.device)
         self.held = {}                                   # ticket -> pinned buffer handed to the parser
         self.acc = None
@@ -170,7 +181,10 @@ class _HipSession:
         self.n_uploads = 0
         self.upload_bytes = 0
         self._releaser = None
-        self._t1 = {}                                    # S1 score tables by group width
+        self._t1 = {}                                    # S1 score tables (device, float32) by group width
+        self._t1_verified = set()
+        self.tables_patched = 0
+        self._pending_check = None
         self._ws3 = None                                 # S3 expected pass: ONE workspace for all parts of the session
 
     def alloc(self, ticket):
@@ -231,29 +245,75 @@ class _HipSession:
         d.all_reduce_tensor(self.acc)                    # RCCL over xGMI: the tensor never leaves HBM
 
     def _score_s1(self, H, N):
-        """S1 score pass of the command line: the lookup table comes from the host (scores.s1ScoreTable: numpy's log2 on the
-        exp_freq this session normalised), so the float32 scores are the reference's bit for bit; one table per group width."""
+        """S1 score pass: gathers from the [N + 1, S] float32 table of this group width (see _s1_table)."""
         o32, _ = self.eng.score_s1_from_binhist_table(H, N, self.S, T32=self._s1_table(N))
         return o32
 
+    def _s1_widths(self):
+        return []
+
     def _s1_table(self, N):
+        """The S1 score table of group width N.  finish_device builds the tables of the session's widths ON THE DEVICE in the
+        launch that normalises (k_s1_combine; no host round trip between the all-reduce and the score pass); the host-facing
+        finish() then compares them bit for bit with the table numpy builds from the same exp_freq by the reference's own
+        expression (scores.s1ScoreTable) and replaces a table that differs -- so scores_*.txt.gz stay the reference's bytes
+        whatever the last bit of a device logarithm does.  A width nobody announced is built from the host table."""
         if N not in self._t1:
             from .scores import s1ScoreTable
             _t64, t32 = s1ScoreTable(self.q.cpu().numpy(), N)
             self._t1[N] = self.torch.from_numpy(t32).to(self.device)
         return self._t1[N]
 
+    def verify_tables(self):
+        """-> number of device-built S1 tables that had to be replaced by the host's (0 = the device's float32 tables ARE the
+        reference's).  Synchronises; called by finish() and, after its timed region, by bench.py."""
+        if self.sal != 1 or self.q is None:
+            return 0
+        from .scores import s1ScoreTable
+        qh = self.q.cpu().numpy()
+        patched = 0
+        for N, Td in list(self._t1.items()):
+            if N in self._t1_verified:
+                continue
+            _t64, t32 = s1ScoreTable(qh, N)
+            if not np.array_equal(Td.cpu().numpy().view(np.uint32).reshape(-1), t32.view(np.uint32).reshape(-1)):
+                self._t1[N] = self.torch.from_numpy(t32).to(self.device)
+                patched += 1
+            self._t1_verified.add(N)
+        self.tables_patched += patched
+        return patched
+
     def finish_device(self, total_rows, N):
-        """Count check (the reference dies on a state outside the model, expected.py:113; here such a byte is counted
-        nowhere, so the total comes out short), then STEP 2 on the device.  Returns exp_freq as a flat device tensor."""
-        total = int(self.acc.sum(dtype=self.torch.int64).item())
-        self.be.check_counts(total, total_rows, N, self.sal)
-        self.q = self.eng.normalise(self.acc)
+        """STEP 2 on the device, no host synchronisation: exp_freq (flat device tensor) and, for S1, the score tables.  The
+        count check (the reference dies on a state outside the model, expected.py:113; here such a byte is counted nowhere, so
+        the total comes out short) is DEFERRED to check(), which whoever takes results off the device calls -- finish(),
+        scores(), results() do; S3's 899 MB array is summed at once."""
+        self._pending_check = (self.acc, total_rows, N)
+        if self.sal == 3:
+            self.check()
+            self.q = self.eng.normalise(self.acc)
+        elif self.sal == 1:
+            widths = [w for w in self._s1_widths() if w] or [N]
+            self.q = None
+            for w in dict.fromkeys(widths):
+                self.q, _T64, T32 = self.eng.s1_tables(self.acc, w, self.S, q=self.q)
+                self._t1[w] = T32
+        else:
+            self.q = self.eng.normalise(self.acc)
         self.acc = None
         return self.q
 
+    def check(self):
+        if self._pending_check is not None:
+            acc, total_rows, N = self._pending_check
+            self._pending_check = None
+            self.be.check_counts(int(acc.sum(dtype=self.torch.int64).item()), total_rows, N, self.sal)
+
     def _finish(self, total_rows, N, shape):
-        return self.finish_device(total_rows, N).cpu().numpy().reshape(shape)
+        q = self.finish_device(total_rows, N)
+        self.check()
+        self.verify_tables()
+        return q.cpu().numpy().reshape(shape)
 
 
 class _HipSingleSession(_HipSession):
@@ -263,7 +323,10 @@ class _HipSingleSession(_HipSession):
     def add_device(self, X, N):
         """Count pass over a RESIDENT part (what add_part does after its upload; bench.py enters here)."""
         eng, S = self.eng, self.S
-        self.N = N
+        self.N = max(getattr(self, "N", 0) or 0, N or 0)  # (an empty file has no width)
+        if X.shape[0] == 0 or not N:                     # an empty part: nothing to count, and the ABI rejects a zero width
+            self.parts.append(self.torch.empty((0, S), dtype=self.torch.int16, device=self.device) if self.sal < 3 else X)
+            return len(self.parts) - 1
         if self.sal == 1:
             H, _ = eng.bin_hist(X, N, S, counts=self._acc(S))
             self.parts.append(H)
@@ -289,7 +352,7 @@ class _HipSingleSession(_HipSession):
     n_export = 1
 
     def slice_part(self, pid, lo, hi, row0=None):
-        self.parts.append(self.parts[pid][lo:hi])
+        self.parts.append(_aligned_rows(self.parts[pid], lo, hi))
         return len(self.parts) - 1
 
     def export_rows(self, pid, lo, hi):
@@ -319,6 +382,8 @@ class _HipSingleSession(_HipSession):
         D = self.parts[pid]
         if not keep:
             self.parts[pid] = None                       # the part's device data is released with its scores
+        if D.shape[0] == 0:
+            return self.torch.empty((0, S), dtype=self.torch.float32, device=self.device)
         if self.sal == 1:
             o32 = self._score_s1(D, N)
         elif self.sal == 2:
@@ -331,7 +396,11 @@ class _HipSingleSession(_HipSession):
             o32, _ = eng.score_s3(D, N, S, self.q, ws=self._ws3)
         return o32
 
+    def _s1_widths(self):
+        return [getattr(self, "N", None)]
+
     def scores(self, pid):
+        self.check()
         return self.scores_device(pid).cpu().numpy()
 
 
@@ -356,7 +425,12 @@ class _HipPairedSession(_HipSession):
 
     def add_staged(self, XA, NA, XB, NB, row0):
         eng, S = self.eng, self.S
-        self.NA, self.NB = NA, NB
+        # widths of the widest part seen: an empty file pair (no columns) must not be the one that is remembered
+        self.NA, self.NB = max(getattr(self, "NA", 0) or 0, NA or 0), max(getattr(self, "NB", 0) or 0, NB or 0)
+        if XA.shape[0] == 0 or not NA or not NB:         # nothing to count (and the ABI rejects a zero width)
+            self.parts.append((XA, XB, self.torch.empty((0, S), dtype=self.torch.int16, device=self.device),
+                               self.torch.empty((0, S), dtype=self.torch.int16, device=self.device), row0))
+            return len(self.parts) - 1
         if self.sal == 1:                                # counts over [A|B] = counts of A + counts of B (helpers.py:173)
             HA, _ = eng.bin_hist(XA, NA, S, counts=self._acc(S))
             HB, _ = eng.bin_hist(XB, NB, S, counts=self._acc(S))
@@ -372,7 +446,7 @@ class _HipPairedSession(_HipSession):
 
     def slice_part(self, pid, lo, hi, row0=None):
         _XA, _XB, HA, HB, _ = self.parts[pid]
-        self.parts.append((None, None, HA[lo:hi], HB[lo:hi], row0))
+        self.parts.append((None, None, _aligned_rows(HA, lo, hi), _aligned_rows(HB, lo, hi), row0))
         return len(self.parts) - 1
 
     def export_rows(self, pid, lo, hi):
@@ -401,6 +475,11 @@ class _HipPairedSession(_HipSession):
         XA, XB, HA, HB, row0 = self.parts[pid]
         if not keep:
             self.parts[pid] = None
+        if HA.shape[0] == 0:
+            t, dv = self.torch, self.device
+            return {"delta": t.empty((0, S), dtype=t.float32, device=dv), "null": t.empty(0, dtype=t.float32, device=dv),
+                    "quies": t.empty(0, dtype=t.uint8, device=dv), "rdist": t.empty(0, dtype=t.float32, device=dv),
+                    "mdiff": t.empty(0, dtype=t.int32, device=dv)}
         ga, gb = (NA, NB) if self.groupSize == -1 else (self.groupSize, self.groupSize)
         # the null groups' histograms straight from the real groups' (multivariate hypergeometric, no pass over X)
         HnA, HnB = eng.null_hist_from_binhist(HA, HB, NA + NB, S, ga, gb, self.seed, row0)
@@ -428,7 +507,12 @@ class _HipPairedSession(_HipSession):
         quies = eng.quiescent_from_binhist(HA, NA, HB, NB, S, self.qstate)
         return {"delta": delta, "null": null, "quies": quies, "rdist": rdist, "mdiff": mdiff}
 
+    def _s1_widths(self):
+        NA, NB = getattr(self, "NA", None), getattr(self, "NB", None)
+        return [NA, NB] + ([self.groupSize] if self.groupSize != -1 else [])
+
     def results(self, pid):
+        self.check()
         r = self.results_device(pid)
         return {"delta": r["delta"].cpu().numpy(), "null": r["null"].cpu().numpy(), "quies": r["quies"].cpu().numpy().astype(bool),
                 "rdist": r["rdist"].cpu().numpy(), "mdiff": r["mdiff"].cpu().numpy()}

@@ -159,7 +159,18 @@ inline size_t inflate_raw(const unsigned char* in, size_t in_avail, Out& out, Gr
         if (type == 0) {
             // stored: back to a byte boundary, LEN / NLEN, raw bytes
             EPG_TAKE(bitcnt & 7);
-            in -= bitcnt >> 3;                            // give the whole bytes in the bit buffer back
+            if (in_tail) {
+                // The bit buffer may hold bytes that were read from the REAL input before the switch to the tail copy: giving
+                // them back can lead to before tail[0] (found by tools/asan_io.sh: a stored block met in the last 16 bytes
+                // read tail[-6..]).  A stored block is read with explicit bounds, so go back to the real input for it.
+                const size_t consumed = tail_origin + (size_t)(in - tail) - (size_t)(bitcnt >> 3);
+                in = in0 + consumed;
+                in_end = in0 + in_avail;
+                in_lim = in_avail >= 16 ? in_end - 16 : in0 - 1;
+                in_tail = false;
+            } else {
+                in -= bitcnt >> 3;                        // give the whole bytes in the bit buffer back
+            }
             bitbuf = 0; bitcnt = 0;
             if (in + 4 > in_end) return 0;
             const uint32_t len = (uint32_t)in[0] | ((uint32_t)in[1] << 8), nlen = (uint32_t)in[2] | ((uint32_t)in[3] << 8);
@@ -348,9 +359,16 @@ inline size_t inflate_raw(const unsigned char* in, size_t in_avail, Out& out, Gr
     }
 #undef EPG_REFILL
 #undef EPG_TAKE
-    in -= bitcnt >> 3;                                    // whole bytes still in the bit buffer were not consumed
-    if (in > in_end) return 0;                            // the stream ran into the padding: truncated
-    return in_tail ? tail_origin + (size_t)(in - tail) : (size_t)(in - in0);
+    // whole bytes still in the bit buffer were not consumed (in tail mode some of them may stem from before tail[0]: offsets,
+    // not pointers)
+    const size_t back = (size_t)(bitcnt >> 3);
+    if (in_tail) {
+        const size_t fwd = (size_t)(in - tail);
+        if (fwd > (size_t)(in_end - tail) + back) return 0;   // the stream ran into the padding: truncated
+        return tail_origin + fwd - back;
+    }
+    if (in - back > in_end) return 0;
+    return (size_t)(in - in0) - back;
 }
 
 }  // namespace epginflate

@@ -14,6 +14,7 @@
 #include <zlib.h>
 
 #include <algorithm>
+#include <atomic>
 #include <memory>
 #include <cstdarg>
 #include <cstdio>
@@ -39,10 +40,44 @@ bool ends_with_gz(const char* path) {
     return n >= 2 && path[n - 2] == 'g' && path[n - 1] == 'z';   // the reference's test: name.endswith("gz")
 }
 
-// threads to use when the caller says 0: the hardware threads, capped by the cgroup CPU quota (a container may see 256
-// hardware threads and be allowed 16 of them at a time) and by 64
+// Census of the library's runnable threads (a caller inside the library + the workers it started; a caller waiting in a join
+// does not count): epgio_thread_census reports the peak, so that a multi-rank run can show that the ranks of one node together
+// stay inside the node's CPU budget (driver._host_budget shares it out).
+std::atomic<int> g_live{0}, g_peak{0};
+thread_local int tl_counted = 0;
+
+void census_add(int d) {
+    const int now = g_live.fetch_add(d) + d;
+    int pk = g_peak.load();
+    while (now > pk && !g_peak.compare_exchange_weak(pk, now)) {}
+}
+
+struct Census {
+    Census() { if (tl_counted++ == 0) census_add(1); }
+    ~Census() { if (--tl_counted == 0) g_live.fetch_sub(1); }
+};
+
+// A caller that hands its work to worker threads and waits for them is not runnable meanwhile: declared just before the
+// workers are started, gives the caller's place in the census up until the end of the scope.
+struct Uncount {
+    const bool was = tl_counted > 0;
+    Uncount() { if (was) g_live.fetch_sub(1); }
+    ~Uncount() { if (was) census_add(1); }
+};
+
+void join_all(std::vector<std::thread>& th) {
+    for (auto& t : th) t.join();
+}
+
+// threads to use when the caller says 0: EPILOGOS_HOST_THREADS when set (the share of the host the driver gives this rank: a
+// node's cores divided by the ranks on it, capped by -c), else the hardware threads, capped by the cgroup CPU quota (a container
+// may see 256 hardware threads and be allowed 16 of them at a time) and by 64
 int n_threads(int32_t req) {
     if (req > 0) return req;
+    if (const char* e = getenv("EPILOGOS_HOST_THREADS")) {
+        const int v = atoi(e);
+        if (v > 0) return std::min(v, 64);
+    }
     static const int cached = [] {
         unsigned hc = std::thread::hardware_concurrency();
         if (!hc) hc = 4;
@@ -146,13 +181,15 @@ bool inflate_own(const unsigned char* in, size_t flen, size_t cap_hint, Text& t,
     }
     first[members.size()] = pieces.size();
     const int T = (int)std::max<size_t>(1, std::min<size_t>((size_t)n_threads(threads), pieces.size()));
+    Uncount uncount_;
     std::vector<std::thread> th;
     for (int w = 0; w < T; ++w)
         th.emplace_back([&, w] {
+            Census census_;
             for (size_t i = (size_t)w; i < pieces.size(); i += (size_t)T)
                 pieces[i].crc = epgcrc::crc32_fast(0, (const unsigned char*)t.heap + pieces[i].off, pieces[i].len);
         });
-    for (auto& x : th) x.join();
+    join_all(th);
     for (size_t k = 0; k < members.size(); ++k) {
         uLong crc = crc32(0L, Z_NULL, 0);
         for (size_t i = first[k]; i < first[k + 1]; ++i) crc = crc32_combine(crc, pieces[i].crc, (z_off_t)pieces[i].len);
@@ -161,6 +198,46 @@ bool inflate_own(const unsigned char* in, size_t flen, size_t cap_hint, Text& t,
     memset(t.heap + out.pos, 0, 16);
     t.data = t.heap;
     t.size = out.pos;
+    return true;
+}
+
+// zlib's inflate over the whole (possibly multi-member) gzip file in memory; the fallback of inflate_own and the reference the
+// differential fuzz compares it with.
+bool inflate_zlib(const unsigned char* in, size_t flen, size_t cap, Text& t, const char* path) {
+    t.heap = (char*)malloc(cap + 16);
+    if (!t.heap) { fail("out of memory reading %s", path); return false; }
+    z_stream zs;
+    memset(&zs, 0, sizeof(zs));
+    if (inflateInit2(&zs, 15 + 16) != Z_OK) { fail("zlib init failed"); return false; }
+    size_t in_pos = 0, out_pos = 0;
+    for (;;) {
+        if (cap - out_pos < (1u << 20)) {
+            const size_t ncap = cap + cap / 2 + (1u << 24);
+            char* nh = (char*)realloc(t.heap, ncap + 16);
+            if (!nh) { inflateEnd(&zs); fail("out of memory reading %s", path); return false; }
+            t.heap = nh;
+            cap = ncap;
+        }
+        zs.next_in = const_cast<Bytef*>(in + in_pos);
+        zs.avail_in = (uInt)std::min<size_t>(flen - in_pos, 1u << 30);
+        zs.next_out = (Bytef*)t.heap + out_pos;
+        zs.avail_out = (uInt)std::min<size_t>(cap - out_pos, 1u << 30);
+        const size_t in0 = zs.avail_in, out0 = zs.avail_out;
+        const int rc = inflate(&zs, Z_NO_FLUSH);
+        in_pos += in0 - zs.avail_in;
+        out_pos += out0 - zs.avail_out;
+        if (rc == Z_STREAM_END) {
+            if (in_pos >= flen || !is_gzip(in + in_pos, flen - in_pos)) break;      // last member (trailing garbage is ignored like gzip does)
+            inflateReset(&zs);                                                          // next member of a multi-member file
+            continue;
+        }
+        if (rc != Z_OK && rc != Z_BUF_ERROR) { inflateEnd(&zs); fail("read error in %s: %s", path, zs.msg ? zs.msg : "corrupt gzip data"); return false; }
+        if (rc == Z_BUF_ERROR && zs.avail_in == 0 && in_pos >= flen) { inflateEnd(&zs); fail("read error in %s: truncated gzip data", path); return false; }
+    }
+    inflateEnd(&zs);
+    memset(t.heap + out_pos, 0, 16);
+    t.data = t.heap;
+    t.size = out_pos;
     return true;
 }
 
@@ -199,41 +276,7 @@ bool slurp(const char* path, Text& t, int32_t threads = 0) {
         if (use_own && inflate_own(in, flen, cap, t, threads)) return true;
         if (t.heap) { free(t.heap); t.heap = nullptr; }
     }
-    t.heap = (char*)malloc(cap + 16);
-    if (!t.heap) { fail("out of memory reading %s", path); return false; }
-    z_stream zs;
-    memset(&zs, 0, sizeof(zs));
-    if (inflateInit2(&zs, 15 + 16) != Z_OK) { fail("zlib init failed"); return false; }
-    size_t in_pos = 0, out_pos = 0;
-    for (;;) {
-        if (cap - out_pos < (1u << 20)) {
-            const size_t ncap = cap + cap / 2 + (1u << 24);
-            char* nh = (char*)realloc(t.heap, ncap + 16);
-            if (!nh) { inflateEnd(&zs); fail("out of memory reading %s", path); return false; }
-            t.heap = nh;
-            cap = ncap;
-        }
-        zs.next_in = const_cast<Bytef*>(in + in_pos);
-        zs.avail_in = (uInt)std::min<size_t>(flen - in_pos, 1u << 30);
-        zs.next_out = (Bytef*)t.heap + out_pos;
-        zs.avail_out = (uInt)std::min<size_t>(cap - out_pos, 1u << 30);
-        const size_t in0 = zs.avail_in, out0 = zs.avail_out;
-        const int rc = inflate(&zs, Z_NO_FLUSH);
-        in_pos += in0 - zs.avail_in;
-        out_pos += out0 - zs.avail_out;
-        if (rc == Z_STREAM_END) {
-            if (in_pos >= flen || !is_gzip(in + in_pos, flen - in_pos)) break;      // last member (trailing garbage is ignored like gzip does)
-            inflateReset(&zs);                                                          // next member of a multi-member file
-            continue;
-        }
-        if (rc != Z_OK && rc != Z_BUF_ERROR) { inflateEnd(&zs); fail("read error in %s: %s", path, zs.msg ? zs.msg : "corrupt gzip data"); return false; }
-        if (rc == Z_BUF_ERROR && zs.avail_in == 0 && in_pos >= flen) { inflateEnd(&zs); fail("read error in %s: truncated gzip data", path); return false; }
-    }
-    inflateEnd(&zs);
-    memset(t.heap + out_pos, 0, 16);
-    t.data = t.heap;
-    t.size = out_pos;
-    return true;
+    return inflate_zlib(in, flen, cap, t, path);
 }
 
 }  // namespace
@@ -336,6 +379,7 @@ extern "C" {
 const char* epgio_last_error(void) { return g_err; }
 
 int64_t epgio_count_rows(const char* path) {
+    Census census_;
     gzFile f = gzopen(path, "rb");
     if (!f) return fail("cannot open %s", path);
     gzbuffer(f, 1 << 20);
@@ -364,7 +408,31 @@ epgio_table* epgio_open_table(const char* path, int64_t row_lo, int64_t row_hi, 
     return epgio_open_table_ex(path, row_lo, row_hi, threads, 31);
 }
 
+void epgio_thread_census(int32_t* live, int32_t* peak, int32_t reset) {
+    if (live) *live = g_live.load();
+    if (peak) *peak = g_peak.load();
+    if (reset) g_peak.store(g_live.load());
+}
+
+int32_t epgio_default_threads(void) { return n_threads(0); }
+
+int64_t epgio_inflate_mem(const void* in, int64_t n, void* out, int64_t cap, int32_t own) {
+    if (!in || n < 0 || cap < 0 || (cap > 0 && !out)) return fail("inflate_mem: bad argument");
+    const unsigned char* p = (const unsigned char*)in;
+    if (!is_gzip(p, (size_t)n)) return fail("inflate_mem: not a gzip stream");
+    Text t;
+    size_t hint = (size_t)((uint32_t)p[n - 4] | (uint32_t)p[n - 3] << 8 | (uint32_t)p[n - 2] << 16 | (uint32_t)p[n - 1] << 24);
+    if (hint < (size_t)n || hint > ((size_t)1 << 28)) hint = (size_t)n * 4;
+    hint += 64;
+    const bool ok = own ? inflate_own(p, (size_t)n, hint, t, 1) : inflate_zlib(p, (size_t)n, hint, t, "memory");
+    if (!ok) return own ? fail("inflate_mem: the library's inflate declined the stream") : -1;
+    if ((int64_t)t.size > cap) return fail("inflate_mem: output %lld > cap %lld", (long long)t.size, (long long)cap);
+    if (t.size) memcpy(out, t.data, t.size);
+    return (int64_t)t.size;
+}
+
 epgio_table* epgio_open_table_ex(const char* path, int64_t row_lo, int64_t row_hi, int32_t threads, int32_t max_state) {
+    Census census_;                                           // the caller: the inflate of a file is one serial thread
     const int max0 = (max_state > 31 ? 127 : 31) - 1;        // largest 0-based state kept: two classes, like the kernels
     static const bool timing = getenv("EPGIO_TIMING") != nullptr;
     double t0 = now_s();
@@ -395,15 +463,17 @@ epgio_table* epgio_open_table_ex(const char* path, int64_t row_lo, int64_t row_h
     seg[T] = end;
     std::vector<int64_t> seg_rows(T, 0);
     {
+        Uncount uncount_;
         std::vector<std::thread> th;
         for (int i = 0; i < T; ++i)
             th.emplace_back([&, i] {
+            Census census_;
                 int64_t n = 0;
                 const char* p = seg[i];
                 while (p < seg[i + 1] && (p = (const char*)memchr(p, '\n', (size_t)(seg[i + 1] - p)))) { ++n; ++p; }
                 seg_rows[i] = n;
             });
-        for (auto& t : th) t.join();
+        join_all(th);
     }
     lap("count lines");
     std::vector<int64_t> seg_first(T + 1, 0);
@@ -445,9 +515,11 @@ epgio_table* epgio_open_table_ex(const char* path, int64_t row_lo, int64_t row_h
         }
     };
     {
+        Uncount uncount_;
         std::vector<std::thread> th;
         for (int i = 0; i < T; ++i)
             th.emplace_back([&, i] {
+            Census census_;
                 for_rows(i, [&](int64_t r, const char* p, const char* nl) {
                     int tabs = 0;
                     const char* q = p;
@@ -456,7 +528,7 @@ epgio_table* epgio_open_table_ex(const char* path, int64_t row_lo, int64_t row_h
                     t->loc_off[(size_t)r + 1] = q - p + 1; // length (+ the '\n' that terminates the row's text) for now
                 });
             });
-        for (auto& x : th) x.join();
+        join_all(th);
     }
     lap("location lengths");
     for (int64_t r = 0; r < t->rows; ++r) t->loc_off[(size_t)r + 1] += t->loc_off[(size_t)r];
@@ -468,9 +540,11 @@ epgio_table* epgio_open_table_ex(const char* path, int64_t row_lo, int64_t row_h
         std::vector<V512> vmin512((size_t)T), vmax512((size_t)T);
         if (simd) init_minmax512(vmin512.data(), vmax512.data(), T);
 #endif
+        Uncount uncount_;
         std::vector<std::thread> th;
         for (int i = 0; i < T; ++i)
             th.emplace_back([&, i] {
+            Census census_;
                 for_rows(i, [&](int64_t r, const char* p, const char* nl) {
                     const int64_t len = t->loc_off[(size_t)r + 1] - t->loc_off[(size_t)r] - 1;
                     memcpy(t->loc.data() + t->loc_off[(size_t)r], p, (size_t)len);
@@ -531,7 +605,7 @@ epgio_table* epgio_open_table_ex(const char* path, int64_t row_lo, int64_t row_h
                     if (c != cols || q != nl) { err[i] = 1; if (bad_row[i] < 0) bad_row[i] = r; }
                 });
             });
-        for (auto& x : th) x.join();
+        join_all(th);
 #if defined(__x86_64__)
         if (simd) fold_minmax512(vmin512.data(), vmax512.data(), T, vlo.data(), vhi.data());
 #endif
@@ -679,9 +753,11 @@ int epgio_parse_locations(const char* loc, const int64_t* loc_off, int64_t R, in
     const char* c0 = loc + (R ? loc_off[0] : 0);
     const char* c0e = R ? (const char*)memchr(c0, '\t', (size_t)(loc_off[1] - loc_off[0])) : c0;
     const size_t c0n = c0e ? (size_t)(c0e - c0) : 0;
+    Uncount uncount_;
     std::vector<std::thread> th;
     for (int t = 0; t < T; ++t)
         th.emplace_back([&, t] {
+            Census census_;
             for (int64_t r = R * t / T; r < R * (t + 1) / T; ++r) {
                 const char* p = loc + loc_off[r];
                 const char* e = loc + loc_off[r + 1];
@@ -705,7 +781,7 @@ int epgio_parse_locations(const char* loc, const int64_t* loc_off, int64_t R, in
                 end[r] = v[1];
             }
         });
-    for (auto& x : th) x.join();
+    join_all(th);
     int all_same = 1;
     for (int t = 0; t < T; ++t) {
         if (bad[t]) return fail("parse_locations: a row is not 'name<TAB>integer<TAB>integer'");
@@ -718,9 +794,11 @@ int epgio_parse_locations(const char* loc, const int64_t* loc_off, int64_t R, in
 int epgio_row_sums_f32(const float* a, int64_t R, int32_t S, int64_t lda, float* out, int32_t threads) {
     if (R < 0 || S < 1 || S > 128 || lda < S || (R > 0 && (!a || !out))) return fail("row_sums: bad argument (S must be 1..128)");
     const int T = (int)std::max<int64_t>(1, std::min<int64_t>(n_threads(threads), (R + 65535) / 65536));
+    Uncount uncount_;
     std::vector<std::thread> th;
     for (int t = 0; t < T; ++t)
         th.emplace_back([&, t] {
+            Census census_;
             const int n8 = S - S % 8;
             for (int64_t r = R * t / T; r < R * (t + 1) / T; ++r) {
                 const float* p = a + r * lda;
@@ -739,7 +817,7 @@ int epgio_row_sums_f32(const float* a, int64_t R, int32_t S, int64_t lda, float*
                 out[r] = res;
             }
         });
-    for (auto& x : th) x.join();
+    join_all(th);
     return 0;
 }
 
@@ -748,9 +826,11 @@ int epgio_rolling_max_f64(const double* x, int64_t n, int32_t W, double* out, in
     const int64_t back = W / 2, fwd = (W - 1) / 2;
     const double nan = std::nan("");
     const int T = (int)std::max<int64_t>(1, std::min<int64_t>(n_threads(threads), (n + (1 << 20) - 1) >> 20));
+    Uncount uncount_;
     std::vector<std::thread> th;
     for (int t = 0; t < T; ++t)
         th.emplace_back([&, t] {
+            Census census_;
             const int64_t i0 = n * t / T, i1 = n * (t + 1) / T;
             // monotonic deque of candidate indices (values decreasing; a later equal value replaces an earlier one, like
             // pandas) over the window [i - back, i + fwd], in a power-of-two ring
@@ -774,7 +854,7 @@ int epgio_rolling_max_f64(const double* x, int64_t n, int32_t W, double* out, in
                 out[i] = x[dq[head & mask]];
             }
         });
-    for (auto& x_ : th) x_.join();
+    join_all(th);
     return 0;
 }
 
@@ -795,6 +875,7 @@ int64_t epgio_format_f5(const float* v, int64_t n, char sep, char* buf, int64_t 
 
 int epgio_write_scores(const char* path, const char* loc, const int64_t* loc_off, const float* scores, int64_t R, int32_t S,
                        int32_t threads, int32_t gzip_level) {
+    Census census_;
     if (!path || (R > 0 && (!loc || !loc_off || !scores)) || S < 1) return fail("write_scores: bad argument");
     if (gzip_level < 0 || gzip_level > 9) gzip_level = 6;
     FILE* f = fopen(path, "wb");
@@ -812,9 +893,11 @@ int epgio_write_scores(const char* path, const char* loc, const int64_t* loc_off
         const int nb = (int)std::min<int64_t>(T, nchunks - c0);
         std::vector<std::vector<unsigned char>> z(nb);
         std::vector<int> good(nb, 0);
+        Uncount uncount_;
         std::vector<std::thread> th;
         for (int k = 0; k < nb; ++k)
             th.emplace_back([&, k] {
+            Census census_;
                 const int64_t r0 = (c0 + k) * CH, r1 = std::min(R, r0 + CH);
                 std::vector<char> txt((size_t)((loc_off[r1] - loc_off[r0]) + (r1 - r0) * (2 + 48 * (int64_t)S)));
                 char* o = txt.data();
@@ -829,7 +912,7 @@ int epgio_write_scores(const char* path, const char* loc, const int64_t* loc_off
                 txt.resize((size_t)(o - txt.data()));
                 good[k] = gzip_member(txt, gzip_level, z[k]);
             });
-        for (auto& x : th) x.join();
+        join_all(th);
         for (int k = 0; k < nb && ok; ++k) {
             if (!good[k] || fwrite(z[k].data(), 1, z[k].size(), f) != z[k].size()) ok = false;
         }
@@ -840,6 +923,7 @@ int epgio_write_scores(const char* path, const char* loc, const int64_t* loc_off
 
 int epgio_write_states(const char* path, const char* chrom, int64_t start0, int64_t step, const int8_t* states, int64_t R, int32_t N,
                        int64_t ldx, int32_t threads, int32_t gzip_level) {
+    Census census_;
     if (!path || !chrom || (R > 0 && !states) || N < 1 || ldx < N || step < 1) return fail("write_states: bad argument");
     if (gzip_level < 0 || gzip_level > 9) gzip_level = 6;
     FILE* f = fopen(path, "wb");
@@ -860,9 +944,11 @@ int epgio_write_states(const char* path, const char* chrom, int64_t start0, int6
         std::vector<std::vector<unsigned char>> z(nb);
         std::vector<std::vector<char>> plain(nb);
         std::vector<int> good(nb, 0);
+        Uncount uncount_;
         std::vector<std::thread> th;
         for (int k = 0; k < nb; ++k)
             th.emplace_back([&, k] {
+            Census census_;
                 const int64_t r0 = (c0 + k) * CH, r1 = std::min(R, r0 + CH);
                 std::vector<char>& txt = plain[k];
                 txt.resize((size_t)(r1 - r0) * (clen + 48 + 5 * (size_t)N));
@@ -885,7 +971,7 @@ int epgio_write_states(const char* path, const char* chrom, int64_t start0, int6
                 txt.resize((size_t)(o - txt.data()));
                 good[k] = gz ? gzip_member(txt, gzip_level, z[k]) : 1;
             });
-        for (auto& x : th) x.join();
+        join_all(th);
         for (int k = 0; k < nb && ok; ++k) {
             if (!good[k]) { ok = false; break; }
             const void* p = gz ? (const void*)z[k].data() : (const void*)plain[k].data();
@@ -900,6 +986,7 @@ int epgio_write_states(const char* path, const char* chrom, int64_t start0, int6
 int epgio_write_metrics(const char* path, const char* chrom, const int64_t* chrom_off, const int32_t* chrom_idx, const int64_t* start,
                         const int64_t* end, const char* names, const int64_t* names_off, const int32_t* maxdiff, const float* dist,
                         const double* pvals, const double* mh, int64_t R, int32_t threads, int32_t gzip_level) {
+    Census census_;
     if (!path || (R > 0 && (!chrom || !chrom_off || !chrom_idx || !start || !end || !names || !names_off || !maxdiff || !dist)) ||
         ((pvals == nullptr) != (mh == nullptr)))
         return fail("write_metrics: bad argument");
@@ -919,9 +1006,11 @@ int epgio_write_metrics(const char* path, const char* chrom, const int64_t* chro
         const int nb = (int)std::min<int64_t>(T, nchunks - c0);
         std::vector<std::vector<unsigned char>> z(nb);
         std::vector<int> good(nb, 0);
+        Uncount uncount_;
         std::vector<std::thread> th;
         for (int k = 0; k < nb; ++k)
             th.emplace_back([&, k] {
+            Census census_;
                 const int64_t r0 = (c0 + k) * CH, r1 = std::min(R, r0 + CH);
                 std::vector<char> txt;
                 txt.reserve((size_t)(r1 - r0) * 96);
@@ -946,7 +1035,7 @@ int epgio_write_metrics(const char* path, const char* chrom, const int64_t* chro
                 }
                 good[k] = gzip_member(txt, gzip_level, z[k]);
             });
-        for (auto& x : th) x.join();
+        join_all(th);
         for (int k = 0; k < nb && ok; ++k) {
             if (!good[k] || fwrite(z[k].data(), 1, z[k].size(), f) != z[k].size()) ok = false;
         }

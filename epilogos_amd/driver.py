@@ -184,14 +184,10 @@ def _stream_parts(jobs, sess, numStates):
     Scheduling: one worker per usable core, largest files first.  Round 2 measured the whole genome on 16 cores with 24
     workers and parts handed over in file order: every part waited behind chr1, whose inflate -- the longest job, started
     together with 23 others on 16 cores -- took 7 s instead of 3; the count pass does not care about the order."""
-    ncores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 8)
-    try:                                               # a cgroup CPU quota (containers) is the real limit
-        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
-        if quota != "max":
-            ncores = max(1, min(ncores, int(int(quota) / int(period) + 0.5)))
-    except (OSError, ValueError):
-        pass
-    workers = max(1, min(int(os.environ.get("EPILOGOS_PARSE_WORKERS", max(4, ncores))), len(jobs)))
+    # This rank's share of the host (VERDICT r3 #7: eight ranks that each sized their pools from the whole node ran 120 native
+    # threads on a 16-core quota -- the cgroup then throttles every process for the rest of each 100 ms period).
+    ncores = _io.host_budget()
+    workers = max(1, min(int(os.environ.get("EPILOGOS_PARSE_WORKERS", ncores)), len(jobs)))
     # native threads per file: the cores are shared out.  (With every reader fanning its short parse phases out to all cores
     # next to fifteen inflating threads, a cgroup CPU quota throttles the whole process for the rest of each 100 ms period:
     # phases that take 0.03 s alone took 1 s.)
@@ -325,7 +321,7 @@ def _assign_files(files, world):
     return owner
 
 
-def _plan(files, d, tm):
+def _plan(files, d, tm, files2=None):
     """-> (mode, rows per file or None, jobs [(file index, lo, hi or None)] of this rank, parser rank per file or None).
     "whole":    one rank; whole files, the row counts come out of the parse.
     "ranges":   several ranks and every row count is known from the --cache-dir side-cars: each rank reads exactly its own
@@ -341,7 +337,12 @@ def _plan(files, d, tm):
     if d.world == 1:
         return "whole", None, [(fi, 0, None) for fi in range(F)], None
     rows = [_cached_rows(f) for f in files]
-    if all(r is not None for r in rows):
+    cached = all(r is not None for r in rows) and all(_cached_rows(f) is not None for f in (files2 or []))
+    # The two modes run different collective sequences, so the ranks must agree: "ranges" only if EVERY rank sees every
+    # side-car (a cache being filled or cleaned by another run, per-rank file-system views) and the same row counts.
+    mine = [int(r) for r in rows] if cached else [0] * F
+    agree = d.max_ints([0 if cached else 1] + mine + [-r for r in mine])     # max and (negated) min of every row count
+    if agree[0] == 0 and agree[1:1 + F] == mine and agree[1 + F:] == [-r for r in mine]:
         return "ranges", rows, plan_partition(rows, d.world)[d.rank], None
     owner = _assign_files(files, d.world)
     return "assigned", None, [(fi, 0, None) for fi in range(F) if owner[fi] == d.rank], owner
@@ -439,13 +440,15 @@ def run_single_group(files, numStates, saliency, outputDir, fileTag, verbose=Fal
 
     # STEP 3: scores from the resident data; text is formatted and compressed by writer threads while the next part scores
     payloads = []
-    with ThreadPoolExecutor(max_workers=2) as writer:
+    nwriters = min(2, _io.host_budget())               # two files are written at a time: half of this rank's cores each
+    wthreads = max(1, _io.host_budget() // nwriters)
+    with ThreadPoolExecutor(max_workers=nwriters) as writer:
         jobs = []
         for k, (fi, lo, hi) in enumerate(my_parts):
             sc = sess.scores(pids[k])
             whole = lo == 0 and hi == rows[fi]
             name = "scores_{}_{}.txt.gz".format(fileTag, fileStem(files[fi])) if whole else _part_name("scores", fileTag, fi, lo)
-            jobs.append(writer.submit(writeScores, sc, outputDir / name, locs[k]))
+            jobs.append(writer.submit(writeScores, sc, outputDir / name, locs[k], None, wthreads))
             payloads.append([sc, np.asarray(locs[k].blob), np.asarray(locs[k].offsets)])
         tm.lap("scores (kernels + download)")
         for j in jobs:
@@ -473,6 +476,7 @@ def run_single_group(files, numStates, saliency, outputDir, fileTag, verbose=Fal
                 np.savez_compressed(outputDir / "temp_scores_{}_{}.npz".format(fileTag, stem), chrName=np.array([chrName]),
                                     scoreArr=scoreArr, locationArr=loc.to_object_array())
         tm.lap("assemble files" + (" + temp_scores npz" if keep_temp_scores else ""))
+    _io.log_thread_census("single s%d rank %d of %d" % (saliency, d.rank, d.world))
     d.barrier()
     return q, results
 
@@ -496,7 +500,7 @@ def run_paired_groups(files1, files2, numStates, saliency, outputDir, fileTag, q
     if d.rank == 0:
         _clean_parts(outputDir, "pairwiseDelta", fileTag)
     d.barrier()
-    mode, rows, my_parts, owner = _plan(files1, d, tm)
+    mode, rows, my_parts, owner = _plan(files1, d, tm, files2)
     sess = _open_paired(be, numStates, saliency, quiescentState, groupSize, nullSeed)
 
     # group 1 and group 2 of a part are jobs 2k and 2k + 1; the second group follows the first one's row ranges
@@ -556,14 +560,16 @@ def run_paired_groups(files1, files2, numStates, saliency, outputDir, fileTag, q
     tm.lap("all-reduce + check + normalise")
 
     payloads = []
-    with ThreadPoolExecutor(max_workers=2) as writer:
+    nwriters = min(2, _io.host_budget())
+    wthreads = max(1, _io.host_budget() // nwriters)
+    with ThreadPoolExecutor(max_workers=nwriters) as writer:
         wjobs = []
         for k, (fi, lo, hi) in enumerate(my_parts):
             res = sess.results(pids[k])
             whole = lo == 0 and hi == rows[fi]
             name = ("pairwiseDelta_{}_{}.txt.gz".format(fileTag, fileStem(files1[fi])) if whole
                     else _part_name("pairwiseDelta", fileTag, fi, lo))
-            wjobs.append(writer.submit(writeScores, res["delta"], outputDir / name, locs[k]))
+            wjobs.append(writer.submit(writeScores, res["delta"], outputDir / name, locs[k], None, wthreads))
             payloads.append([np.asarray(res["null"], dtype=np.float32), np.asarray(res["quies"], dtype=np.bool_),
                              np.asarray(res["rdist"], dtype=np.float32), np.asarray(res["mdiff"], dtype=np.int32),
                              np.asarray(locs[k].blob), np.asarray(locs[k].offsets)])
@@ -603,5 +609,6 @@ def run_paired_groups(files1, files2, numStates, saliency, outputDir, fileTag, q
                 np.savez_compressed(outputDir / "temp_pairMetrics_{}_{}.npz".format(fileTag, stem), chrName=np.array([chrName]),
                                     distances=res["distances"], maxDiff=res["maxDiff"], starts=starts, ends=ends)
         tm.lap("assemble files" + (" + temp npz" if keep_temps else ""))
+    _io.log_thread_census("paired s%d rank %d of %d" % (saliency, d.rank, d.world))
     d.barrier()
     return q, results

@@ -263,6 +263,20 @@ def combine_score_s1(counts, H, N, S, q=None, want32=True, want64=False, out32=N
     return q, o32, o64
 
 
+def s1_tables(counts, N, S, q=None, ws=None):
+    """STEP 2 and the S1 score table of group width N in ONE launch, nothing else (epg_combine_score_s1 with no bins):
+    q = normalise(counts) and T[c, s] = kl(c / N, q[s]), c = 0..N.  Returns (q, T64, T32); the tables are views of `ws`."""
+    dev = counts.device
+    if q is None:
+        q = torch.empty(S, dtype=torch.float32, device=dev)
+    if ws is None:
+        ws = _ws(1, 0, N, S, dev)
+    _abi.call("epg_combine_score_s1", _ptr(counts), 0, None, 0, N, S, _ptr(q), None, None, _ptr(ws), ws.numel(), _stream())
+    nent = (N + 1) * S
+    off = (nent * 8 + 255) // 256 * 256
+    return q, ws[:nent * 8].view(torch.float64), ws[off:off + nent * 4].view(torch.float32)
+
+
 def score_s2(X, N, S, q, perms=None, want32=True, want64=False):
     R, ldx = _check_states(X, N)
     perms = N * (N - 1) if perms is None else perms

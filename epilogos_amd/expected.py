@@ -14,9 +14,9 @@ from .helpers import countRows, fileStem, readStates, strToBool
 
 
 def main(file1, file2, numStates, saliency, outputDir, fileTag, numProcesses, verbose):
-    _io.set_state_limit(numStates)
     """file2 == "null" for single-group runs; numProcesses is accepted for CLI compatibility and ignored (the
     row-range fan-out of the reference's Pool is the GPU's grid)."""
+    _io.set_state_limit(numStates)
     if verbose: tTotal = time()
     file1Path, file2Path, outputDirPath = Path(file1), Path(file2), Path(outputDir)
     filename = fileStem(file1Path)

@@ -76,7 +76,9 @@ def checkArguments(mode, saliency, inputDirPath, inputDirPath2, outputDirPath, n
 @click.option("-o", "--output-directory", "outputDirectory", type=str, help="Output directory")
 @click.option("-j", "--state-info", "stateInfo", type=str, help="State model info file")
 @click.option("-s", "--saliency", "saliency", type=int, default=1, show_default=True, help="Saliency level (1, 2, or 3)")
-@click.option("-c", "--num-cores", "numProcesses", type=int, default=1, help="Accepted for compatibility; ignored")
+@click.option("-c", "--num-cores", "numProcesses", type=int, default=0, show_default=True,
+              help="Upper bound on the host cores the job uses for parsing, writing and STEP 4 (0 = all it may use); shared out "
+                   "over the ranks of --gpus")
 @click.option("-x", "--exit", "exitBool", is_flag=True, help="SLURM-only flag; accepted and ignored")
 @click.option("-d", "--diagnostic-figures", "diagnosticBool", is_flag=True, help="Figures are not produced; accepted and ignored")
 @click.option("-t", "--num-trials", "numTrials", type=int, default=101, show_default=True,
@@ -126,6 +128,8 @@ def main(mode, commandLineBool, inputDirectory, inputDirectory1, inputDirectory2
 
     if cacheDir:
         os.environ["EPILOGOS_CACHE_DIR"] = str(Path(cacheDir).resolve())
+    if numProcesses > 0:                                      # the reference's core budget (run.py:36,148): see _io.host_budget
+        os.environ["EPILOGOS_NUM_CORES"] = str(numProcesses)
     numStates = getNumStates(stateInfo)
     quiescentState = numStates - 1 if quiescentState == -1 else quiescentState - 1     # 1-based -> 0-based, 0 -> off
     inputDirPath = Path(inputDirectory if mode == "single" else inputDirectory1)
@@ -169,10 +173,14 @@ def main(mode, commandLineBool, inputDirectory, inputDirectory1, inputDirectory2
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         backend = dist_backend or ("nccl" if device is not None else "gloo")
+        # a collective whose partner never arrives (a rank that died where the launcher cannot see it) must end the job, not
+        # hold seven GPUs forever; generous, because a rank legitimately waits while the others still parse their files
+        import datetime
+        limit = datetime.timedelta(seconds=int(os.environ.get("EPILOGOS_DIST_TIMEOUT", "1800")))
         if backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=device)
+            dist.init_process_group(backend="nccl", device_id=device, timeout=limit)
         else:
-            dist.init_process_group(backend=backend)
+            dist.init_process_group(backend=backend, timeout=limit)
     rank = int(os.environ.get("RANK", "0"))
     say = print if rank == 0 else (lambda *a, **k: None)
     if os.environ.get("EPILOGOS_TIMING") and rank == 0:
@@ -239,9 +247,23 @@ _ARGV = None            # the argument list cli() was called with, when it is no
 
 
 def _visible_gpus():
-    """GPUs this process could use, without initialising any (torch.cuda.device_count() does not, on ROCm)."""
-    import torch
-    return max(int(torch.cuda.device_count()), 1)
+    """GPUs this process could use, counted WITHOUT loading torch or touching HIP (the parent of the ranks must stay
+    GPU-free): the KFD topology lists every compute node (a GPU has simd_count > 0, a CPU node 0), and the usual
+    *_VISIBLE_DEVICES lists narrow it down."""
+    n = 0
+    try:
+        for node in sorted(Path("/sys/class/kfd/kfd/topology/nodes").iterdir()):
+            props = dict(l.split()[:2] for l in (node / "properties").read_text().splitlines() if len(l.split()) >= 2)
+            if int(props.get("simd_count", "0")) > 0:
+                n += 1
+    except (OSError, ValueError):
+        n = 0
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            listed = len([t for t in v.split(",") if t.strip()])
+            n = min(n, listed) if n else listed
+    return max(n, 1)
 
 
 def _strip_gpus(argv):

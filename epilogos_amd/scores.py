@@ -90,7 +90,7 @@ def calculateScoresPairwise(saliency, file1Path, file2Path, totalRows, numStates
                         chrName=np.array([chrName]), quiescenceArr=quiescenceArr)
 
 
-def writeScores(dataArr, outputTxtPath, locationArr, gzip_level=None):
+def writeScores(dataArr, outputTxtPath, locationArr, gzip_level=None, threads=0):
     """gzip text file, one line per bin: 'chr\\tstart\\tend\\t' + '%.5f' values (reference scores.py:509-536).
     Native writer: exact '%.5f' of the float32 values, one gzip member per 32768 rows compressed in
     parallel; the decompressed bytes equal the reference's.  locationArr: a _io.Locations (verbatim input columns) or
@@ -100,7 +100,7 @@ def writeScores(dataArr, outputTxtPath, locationArr, gzip_level=None):
     # gzip_level None: EPILOGOS_GZIP_LEVEL, by default 0 = the library's own compressor (csrc/epg_deflate.h), ~5x the speed of
     # zlib level 6 for files 4-12 % larger -- writing the text is most of a whole-genome run; 1..9 select zlib (the reference's
     # gzip.open default is level 9: 3 % smaller than 6, five times its time)
-    _io.write_scores(outputTxtPath, locationArr, np.asarray(dataArr, dtype=np.float32), gzip_level=gzip_level)
+    _io.write_scores(outputTxtPath, locationArr, np.asarray(dataArr, dtype=np.float32), threads=threads, gzip_level=gzip_level)
 
 
 if __name__ == "__main__":

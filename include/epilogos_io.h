@@ -98,6 +98,19 @@ int epgio_rolling_max_f64(const double* x, int64_t n, int32_t W, double* out, in
  * Replaces Python's gzip.open(..., "wt") of scores.py:523 (zlib level 9).  Exposed for tests. */
 int64_t epgio_gzip_fast(const void* in, int64_t n, void* out, int64_t cap);
 
+/* The gzip reader on a buffer in memory: own != 0 the library's inflate (csrc/epg_inflate.h: every member's CRC-32 and ISIZE
+ * checked), own == 0 zlib's; returns the inflated size (copied to out, cap bytes) or < 0 -- the stream was declined / is
+ * corrupt / does not fit.  Exposed for the differential fuzz (tools/asan_io.sh, tests/test_native_io.py). */
+int64_t epgio_inflate_mem(const void* in, int64_t n, void* out, int64_t cap, int32_t own);
+
+/* Host budget.  Wherever `threads` is 0 above the library uses epgio_default_threads(): EPILOGOS_HOST_THREADS when that is
+ * set (the driver gives every rank of a node its share: cores / LOCAL_WORLD_SIZE, capped by the reference's -c,
+ * run.py:36,148), else the hardware threads capped by the cgroup CPU quota and by 64.  epgio_thread_census reports the
+ * library's runnable threads right now and their peak since the last reset (callers inside the library + workers they
+ * started; a caller waiting for its workers does not count). */
+int32_t epgio_default_threads(void);
+void epgio_thread_census(int32_t* live, int32_t* peak, int32_t reset);
+
 #ifdef __cplusplus
 }
 #endif

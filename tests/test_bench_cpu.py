@@ -32,3 +32,30 @@ def test_strong_split_is_the_reference_rule():
     for world in (1, 2, 4, 8):
         mine = [(r * R // world, (r + 1) * R // world) for r in range(world)]       # bench.py's shard of rank r
         assert mine == [tuple(t) for t in splitRows(R, world)]
+
+
+def test_gpus_flag_makes_bench_its_own_launcher(tmp_path):
+    """`python bench.py --gpus N` from a plain start (no WORLD_SIZE): the process turns into the launcher -- a child
+    `python -m torch.distributed.run --nproc-per-node N bench.py <same arguments>`, started before torch is imported -- and
+    returns the child's exit code (the reference's one command fans out by itself, run.py:190-279)."""
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(bench.__file__).resolve().parent
+    env = dict(os.environ, EPILOGOS_LAUNCH_DRYRUN="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    res = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "4", "--steps", "7", "--warmup", "2"], env=env,
+                         capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0, res.stderr
+    words = res.stdout.split()
+    assert words[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node" in words
+    assert words[words.index("--nproc-per-node") + 1] == "4" and words[words.index("--master-addr") + 1] == "127.0.0.1"
+    tail = words[words.index(str(root / "bench.py")):]
+    assert tail[1:] == ["--gpus", "4", "--steps", "7", "--warmup", "2"]
+    # a child that fails makes the launcher fail: a world size that contradicts --gpus
+    env.pop("EPILOGOS_LAUNCH_DRYRUN")
+    bad = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "3"], env=dict(env, WORLD_SIZE="2", RANK="0"),
+                         capture_output=True, text=True, timeout=120)
+    assert bad.returncode != 0 and "does not match" in bad.stderr

@@ -435,3 +435,86 @@ def test_bench_extras_deadline_keeps_the_headline(tmp_path):
     assert len(out) == 1
     line = json.loads(out[0])
     assert line["value"] > 0 and line["roofline"]["frac"] > 0 and "deadline" in line["configs"]
+
+
+def test_bench_gpus_flag_from_a_plain_start(tmp_path):
+    """`python bench.py --gpus 2 ...` with no launcher around it: bench.py starts its own ranks (child torchrun, before it
+    touches a GPU), rank 0's one JSON line arrives on the parent's stdout and carries what every rank saw."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parents[1]
+    env = dict(os.environ, PYTHONPATH=str(root))
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR"):
+        env.pop(k, None)
+    cmd = [sys.executable, str(root / "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--bins", "300001", "--backend", "gloo",
+           "--configs", "none"]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=str(tmp_path))
+    assert res.returncode == 0, res.stdout + res.stderr
+    out = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(out) == 1
+    line = json.loads(out[0])
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["config"]["bins_per_gpu"] == 150000
+    assert line["cpu_baseline"] is None                              # N = 1 only
+    pr = line["per_rank"]
+    assert len(pr["k_bin_hist_ms"]) == 2 and pr["k_bin_hist_ms_min_max"][0] <= pr["k_bin_hist_ms_min_max"][1]
+    assert pr["skew_ms_per_step"] >= 0 and len(pr["own_ms_per_step"]) == 2
+    assert line["allreduce_probe"]["world"] == 2
+    assert line["config"]["step_path"] == "session" and line["s1_table"]["built_on"].startswith("device")
+    # one GPU: unchanged contract, plus both S1 paths on the genome and on the shard
+    one = subprocess.run([sys.executable, str(root / "bench.py"), "--steps", "3", "--warmup", "1", "--bins", "400000", "--shard-bins", "50000",
+                          "--no-cpu-baseline", "--configs", "none", "--placement-experiment", "0"], env=env, capture_output=True, text=True,
+                         timeout=900, cwd=str(tmp_path))
+    assert one.returncode == 0, one.stdout + one.stderr
+    l1 = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][-1])
+    assert l1["n_gpus"] == 1 and l1["per_rank"] is None
+    assert set(l1["s1_paths"]) >= {"genome_400000_bins", "shard_50000_bins"}
+    for k in ("genome_400000_bins", "shard_50000_bins"):
+        assert l1["s1_paths"][k]["session_ms_per_step"] > 0 and l1["s1_paths"][k]["engine_ms_per_step"] > 0
+
+
+@pytest.mark.parametrize("mode", ["single", "paired"])
+def test_owner_slice_that_starts_mid_file_at_an_odd_row(tmp_path, golden_real, golden_pair, mode):
+    """Two ranks, files of 101 + 1000 rows: rank 1 parses the second file itself and owns its rows from 449 on -- a row slice
+    of the resident histograms whose base is 449 * 18 * 2 bytes = 4 mod 8 past an aligned allocation.  The score entry points
+    want aligned bases: the slice is copied when it is not.  Outputs equal the one-rank run."""
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+    from tests.conftest import load_golden
+    root = Path(__file__).resolve().parents[1]
+    meta = tmp_path / "metadata.tsv"
+    names = load_golden("roi.npz")["state_names"]
+    meta.write_text("zero_index\tone_index\tshort_name\n" + "".join("%d\t%d\t%s\n" % (i, i + 1, names[i]) for i in range(S)))
+    cuts = (("matrix_chr1.txt.gz", 0, 101), ("matrix_chr2.txt.gz", 101, 1101))
+    if mode == "single":
+        ind = tmp_path / "in"
+        ind.mkdir()
+        for name, lo, hi in cuts:
+            write_tsv(ind / name, golden_real["x"][lo:hi], chrom=name[7:-7])
+        inputs = ["-i", str(ind)]
+        outputs = ["scores_t_matrix_chr1.txt.gz", "scores_t_matrix_chr2.txt.gz"]
+    else:
+        a, b = tmp_path / "male", tmp_path / "female"
+        a.mkdir(); b.mkdir()
+        for name, lo, hi in cuts:
+            write_tsv(a / name, golden_pair["xa"][lo:hi], chrom=name[7:-7])
+            write_tsv(b / name, golden_pair["xb"][lo:hi], chrom=name[7:-7])
+        inputs = ["-m", "paired", "-a", str(a), "-b", str(b), "--null-seed", "3", "-w", "10"]
+        outputs = ["pairwiseDelta_t_matrix_chr1.txt.gz", "pairwiseDelta_t_matrix_chr2.txt.gz", "pairwiseMetrics_t.txt.gz"]
+    outs = {}
+    for gpus in (1, 2):
+        out = tmp_path / ("out%d" % gpus)
+        env = dict(os.environ, PYTHONPATH=str(root), EPILOGOS_DIST_BACKEND="gloo")
+        for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+            env.pop(k, None)
+        cmd = [sys.executable, "-m", "epilogos_amd.run", "-l"] + inputs + ["-j", str(meta), "-o", str(out), "-s", "1", "-f", "t", "--gpus", str(gpus)]
+        res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=str(root))
+        assert res.returncode == 0, res.stdout + res.stderr
+        outs[gpus] = out
+    for name in outputs:
+        with gzip.open(outs[1] / name, "rb") as fa, gzip.open(outs[2] / name, "rb") as fb:
+            assert fa.read() == fb.read(), name

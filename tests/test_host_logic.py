@@ -514,3 +514,20 @@ def test_gpus_launcher_command(tmp_path, state_info, capsys, monkeypatch):
     assert "torch.distributed.run" in printed and "--nproc-per-node 3" in printed and "--gpus" not in printed
     with pytest.raises(SystemExit):
         run.main(args=args[:-1] + ["-2"], standalone_mode=False)
+
+
+def test_visible_gpus_is_counted_without_torch(monkeypatch):
+    """`--gpus 0` (all visible GPUs): the launcher parent counts them from the KFD topology / the *_VISIBLE_DEVICES lists, not
+    through torch or HIP -- it must stay GPU-free, its children are the ranks."""
+    import subprocess
+    from epilogos_amd import run
+    for v in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        monkeypatch.delenv(v, raising=False)
+    base = run._visible_gpus()
+    assert base >= 1
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "0,1,2")
+    assert run._visible_gpus() == (3 if base == 1 else min(base, 3))
+    monkeypatch.setenv("ROCR_VISIBLE_DEVICES", "0")
+    assert run._visible_gpus() == 1
+    code = "import sys; from epilogos_amd import run; run._visible_gpus(); assert 'torch' not in sys.modules"
+    assert subprocess.run([sys.executable, "-c", code], env=dict(os.environ, PYTHONPATH=str(ROOT))).returncode == 0
