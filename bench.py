@@ -193,7 +193,7 @@ def bench_single(torch, be, d, sal, X, N, S, R, R_global, world, reps, fence):
         e[1].record()
         sess.ensure_acc(N)
         sess.all_reduce(d)                                        # the one collective: int64[S*S] or int32[N*N*S*S]
-        sess.finish_device(R_global, N)                           # count check + STEP 2
+        sess.finish_device(R_global, N)                           # STEP 2 (the count check is deferred to sess.check())
         e[2].record()
         o32 = sess.scores_device(pid)                             # STEP 3
         e[3].record()
@@ -202,13 +202,14 @@ def bench_single(torch, be, d, sal, X, N, S, R, R_global, world, reps, fence):
         if rep:
             walls.append(_max_over_ranks(torch, d, wall, dev))
             phases.append([e[i].elapsed_time(e[i + 1]) for i in range(3)])
+        sess.check()                                              # the deferred count check (S1 / S2; S3 checks at once)
         ok = bool(torch.isfinite(o32[:: max(R // 4096, 1)]).all()) if R else True
         del sess, o32
     wall_ms = float(np.median(walls)) * 1e3
     exp_ms, comb_ms, score_ms = (float(v) for v in np.median(np.array(phases), axis=0))
     out = {"bins_total": R_global, "bins_per_gpu": R, "biosamples": N, "states": S, "saliency": sal, "reps": reps,
            "job_ms": round(wall_ms, 3), "value": round(R_global / wall_ms / 1e3, 3), "unit": "Mbins/s", "scores_finite": ok,
-           "phases_ms": {"expected": round(exp_ms, 3), "allreduce+check+normalise": round(comb_ms, 3), "scores": round(score_ms, 3)},
+           "phases_ms": {"expected": round(exp_ms, 3), "allreduce+normalise": round(comb_ms, 3), "scores": round(score_ms, 3)},
            "path": "backend._HipSingleSession (the command line's session), device-resident"}
     if sal == 2:
         # bytes the job has to move per bin: X read, H written, H read by the pair counts, H read + float32 scores written
@@ -247,14 +248,41 @@ def bench_single(torch, be, d, sal, X, N, S, R, R_global, world, reps, fence):
     return out
 
 
+# hg19 chromosome lengths (chr1..chr22, X, Y; base pairs -- 200-bp bins are length // 200): the shape of the parts the command
+# line feeds a session with, one file per chromosome
+HG19_BP = [249250621, 243199373, 198022430, 191154276, 180915260, 171115067, 159138663, 146364022, 141213431, 135534747, 135006516,
+           133851895, 115169878, 107349540, 102531392, 90354753, 81195210, 78077248, 59128983, 63025520, 48129895, 51304566,
+           155270560, 59373566]
+
+
+def chromosome_parts(R_global, lo, hi):
+    """The genome of R_global bins cut into 24 files in hg19's proportions; -> [(file ordinal, first row in the file, global
+    first bin, global end bin)] of the pieces that fall into this rank's bin range [lo, hi) -- what driver.plan_partition gives
+    a rank of the command line."""
+    w = np.array(HG19_BP, dtype=np.float64)
+    edges = np.concatenate([[0], np.round(np.cumsum(w) / w.sum() * R_global)]).astype(np.int64)
+    edges[-1] = R_global
+    parts = []
+    for f in range(len(HG19_BP)):
+        a, b = max(lo, int(edges[f])), min(hi, int(edges[f + 1]))
+        if a < b:
+            parts.append((f, a - int(edges[f]), a, b))
+    return parts
+
+
 def bench_paired(torch, be, d, R, R_global, bin0, S, world, reps, fence, dev, dist_name, NA=379, NB=342):
     """Paired S1 (BASELINE config 5: male vs female, 379 + 342 biosamples) through backend._HipPairedSession: both groups'
     count passes, the all-reduce of the [A|B] counts, normalise, the hypergeometric null groups, four score passes, deltas, null
-    distances, STEP 4's per-bin reduction and the quiescence mask -- everything the command line computes before it writes."""
+    distances, STEP 4's per-bin reduction and the quiescence mask -- everything the command line computes before it writes.
+    The session is fed the way the command line feeds it: one part per chromosome file (24 in hg19's proportions, natural
+    order), each keyed by (file, row) -- so the null groups of a part are drawn on the session's second stream while the next
+    part is counted."""
+    from epilogos_amd.driver import shuffle_key
     eng = be.engine
     XA, XB = eng.alloc_states(R, NA, device=dev), eng.alloc_states(R, NB, device=dev)
     generate_shard(torch, XA, NA, S, bin0, dist=dist_name, seed=4321)
     generate_shard(torch, XB, NB, S, bin0, dist=dist_name, seed=8765)
+    parts = chromosome_parts(R_global, bin0, bin0 + R)
     walls, phases = [], []
     for rep in range(reps + 1):
         sess = be.open_paired(S, 1, S - 1, -1, 20240229)
@@ -262,21 +290,25 @@ def bench_paired(torch, be, d, R, R_global, bin0, S, world, reps, fence, dev, di
         e = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
         t0 = time.perf_counter()
         e[0].record()
-        pid = sess.add_staged(XA, NA, XB, NB, bin0)
+        pids = [sess.add_staged(XA[a - bin0:b - bin0], NA, XB[a - bin0:b - bin0], NB, shuffle_key(f, r0)) for f, r0, a, b in parts]
         e[1].record()
+        host_count_ms = (time.perf_counter() - t0) * 1e3
         sess.ensure_acc(NA + NB)
         sess.all_reduce(d)
         sess.finish_device(R_global, NA + NB)
         e[2].record()
-        res = sess.results_device(pid)
+        res = [sess.results_device(pid) for pid in pids]
         e[3].record()
         fence()
         wall = time.perf_counter() - t0
         if rep:
             walls.append(_max_over_ranks(torch, d, wall, dev))
             phases.append([e[i].elapsed_time(e[i + 1]) for i in range(3)])
-        ok = bool(torch.isfinite(res["delta"][:: max(R // 4096, 1)]).all()) and bool(torch.isfinite(res["null"][:: max(R // 4096, 1)]).all())
-        nq = int(res["quies"].sum().item())
+        sess.check()
+        ok = all(bool(torch.isfinite(r["delta"][:: max(r["delta"].shape[0] // 512, 1)]).all()) and
+                 bool(torch.isfinite(r["null"][:: max(r["null"].shape[0] // 512, 1)]).all()) for r in res)
+        nq = int(sum(int(r["quies"].sum().item()) for r in res))
+        patched = sess.verify_tables()
         del sess, res
     wall_ms = float(np.median(walls)) * 1e3
     exp_ms, comb_ms, res_ms = (float(v) for v in np.median(np.array(phases), axis=0))
@@ -285,14 +317,18 @@ def bench_paired(torch, be, d, R, R_global, bin0, S, world, reps, fence, dev, di
     bpb = (NA + NB) + 2 * 2 * S + 4 * 2 * S + (4 * 2 * S + 4 * S + 12) + (2 * 2 * S + 1)
     gb = R * bpb / (exp_ms + comb_ms + res_ms) / 1e6
     return {"bins_total": R_global, "bins_per_gpu": R, "biosamples": [NA, NB], "states": S, "saliency": 1, "reps": reps,
+            "parts": len(parts), "parts_what": "one per chromosome file in hg19's proportions, keyed (file, row) for the null shuffle",
             "job_ms": round(wall_ms, 3), "value": round(R_global / wall_ms / 1e3, 3), "unit": "Mbins/s",
-            "outputs_finite": ok, "quiescent_bins": nq,
-            "phases_ms": {"two count passes": round(exp_ms, 3), "allreduce+check+normalise": round(comb_ms, 3),
-                          "null groups + scores/deltas/null distances/metrics (one pass) + quiescence": round(res_ms, 3)},
+            "outputs_finite": ok, "quiescent_bins": nq, "s1_tables_equal_numpy_reference": patched == 0,
+            "host_enqueue_ms_of_the_count_phase": round(host_count_ms, 3),
+            "phases_ms": {"count passes of the 2 x %d parts (main stream; the null groups of part k run on the second stream under "
+                          "the count pass of part k + 1)" % len(parts): round(exp_ms, 3),
+                          "allreduce+normalise+tables": round(comb_ms, 3),
+                          "rest of the null groups + scores/deltas/null distances/metrics (one pass per part) + quiescence": round(res_ms, 3)},
             "roofline": {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBPS, "algorithmic_bytes_per_bin": bpb,
                          "achieved": round(gb, 1), "frac": round(gb / HBM_PEAK_GBPS, 4),
-                         "what": "whole job (device time of the three phases) against the bytes it has to move; the null groups "
-                                 "are compute-bound (Philox + selection sampling), see DESIGN.md 3"},
+                         "what": "whole job (device time of the three phases on the main stream) against the bytes it has to move; the "
+                                 "null groups are compute-bound (Philox + selection sampling), see DESIGN.md 3"},
             "path": "backend._HipPairedSession (the command line's session), device-resident"}
 
 

@@ -5,6 +5,8 @@ library or a GPU is missing -- there is no CPU fallback.  `set_for_testing` exis
 can exercise the host logic (file naming, partitioning, the gloo collective path) with an oracle-backed stand-in;
 nothing in the package ever installs one.
 """
+import os
+
 import numpy as np
 
 _override = None
@@ -410,6 +412,9 @@ class _HipPairedSession(_HipSession):
             raise ValueError("Please ensure that saliency metric is either 1 or 2 for Pairwise Epilogos")
         super().__init__(be, S, saliency)
         self.qstate, self.groupSize, self.seed = quiescentState, groupSize, seed
+        if getattr(be, "_null_stream", None) is None:    # one second stream per backend, not per session
+            be._null_stream = self.torch.cuda.Stream(device=self.device)
+        self.null_stream = be._null_stream
 
     def stage(self, arr, N, ticket):
         """One group's matrix of a part -> HBM as soon as it is parsed (its staging buffer goes back to the pool at once: a
@@ -417,19 +422,25 @@ class _HipPairedSession(_HipSession):
         return self._upload(arr, N, ticket)
 
     def set_row0(self, pid, row0):
-        XA, XB, HA, HB, _ = self.parts[pid]
-        self.parts[pid] = (XA, XB, HA, HB, row0)
+        XA, XB, HA, HB, _, null = self.parts[pid]
+        self.parts[pid] = (XA, XB, HA, HB, row0, null)
+        if null is None and HA.shape[0]:
+            self._start_null(pid)
 
     def add_part(self, arrA, NA, ticketA, arrB, NB, ticketB, row0):
         return self.add_staged(self._upload(arrA, NA, ticketA), NA, self._upload(arrB, NB, ticketB), NB, row0)
 
     def add_staged(self, XA, NA, XB, NB, row0):
+        """Count pass over one part's two groups.  row0 keys the null shuffle of the part's first row: the driver passes
+        (file ordinal << 40) + row in the file -- known the moment a file is parsed, whatever the partition -- so the null
+        groups are drawn at once, on a second stream, while the next part is counted (the sampler is VALU-bound, the count
+        pass HBM-bound: tools/overlap_probe.py)."""
         eng, S = self.eng, self.S
         # widths of the widest part seen: an empty file pair (no columns) must not be the one that is remembered
         self.NA, self.NB = max(getattr(self, "NA", 0) or 0, NA or 0), max(getattr(self, "NB", 0) or 0, NB or 0)
         if XA.shape[0] == 0 or not NA or not NB:         # nothing to count (and the ABI rejects a zero width)
             self.parts.append((XA, XB, self.torch.empty((0, S), dtype=self.torch.int16, device=self.device),
-                               self.torch.empty((0, S), dtype=self.torch.int16, device=self.device), row0))
+                               self.torch.empty((0, S), dtype=self.torch.int16, device=self.device), row0, None))
             return len(self.parts) - 1
         if self.sal == 1:                                # counts over [A|B] = counts of A + counts of B (helpers.py:173)
             HA, _ = eng.bin_hist(XA, NA, S, counts=self._acc(S))
@@ -438,25 +449,69 @@ class _HipPairedSession(_HipSession):
             HA, _ = eng.bin_hist(XA, NA, S, want_counts=False)
             HB, _ = eng.bin_hist(XB, NB, S, want_counts=False)
             eng.hist_s2_from_binhist_pair(HA, HB, S, counts=self._acc(S * S))
-        self.parts.append((XA, XB, HA, HB, row0))
-        return len(self.parts) - 1
+        self.parts.append((XA, XB, HA, HB, row0, None))
+        pid = len(self.parts) - 1
+        if row0 is not None:
+            self._start_null(pid)
+        return pid
+
+    def _start_null(self, pid):
+        """The null groups' histograms of part `pid` (multivariate hypergeometric, from the real groups' histograms; they do
+        not depend on exp_freq) on the session's second stream, behind the launches that produce HA / HB."""
+        t, eng = self.torch, self.eng
+        XA, XB, HA, HB, row0, _ = self.parts[pid]
+        NA, NB = self.NA, self.NB
+        ga, gb = (NA, NB) if self.groupSize == -1 else (self.groupSize, self.groupSize)
+        main = t.cuda.current_stream()
+        if self.null_stream is None or os.environ.get("EPILOGOS_NULL_OVERLAP", "1") == "0":
+            HnA, HnB = eng.null_hist_from_binhist(HA, HB, NA + NB, self.S, ga, gb, self.seed, row0)
+            self.parts[pid] = (XA, XB, HA, HB, row0, (HnA, HnB, None))
+            return
+        # outputs from the main stream's pool (a second stream has a pool of its own in torch's allocator: every new session
+        # would start with device mallocs), launch on the second stream between two events, no stream switch on the host
+        ready = t.cuda.Event()
+        ready.record(main)
+        self.null_stream.wait_event(ready)
+        HnA, HnB = eng.null_hist_from_binhist(HA, HB, NA + NB, self.S, ga, gb, self.seed, row0, stream=self.null_stream)
+        done = t.cuda.Event()
+        done.record(self.null_stream)
+        for x in (HA, HB, HnA, HnB):
+            x.record_stream(self.null_stream)            # used there: their memory must not be reused before it is through
+        self.parts[pid] = (XA, XB, HA, HB, row0, (HnA, HnB, done))
+
+    def _null_of(self, pid):
+        """(HnA, HnB) of part `pid`, ready for the current stream."""
+        if self.parts[pid][5] is None:
+            self._start_null(pid)
+        HnA, HnB, done = self.parts[pid][5]
+        if done is not None:
+            self.torch.cuda.current_stream().wait_event(done)
+        return HnA, HnB
 
     # ---- multi-rank hand-over: the score pass of paired mode reads the two groups' histograms only
     n_export = 2
 
     def slice_part(self, pid, lo, hi, row0=None):
-        _XA, _XB, HA, HB, _ = self.parts[pid]
-        self.parts.append((None, None, _aligned_rows(HA, lo, hi), _aligned_rows(HB, lo, hi), row0))
-        return len(self.parts) - 1
+        _XA, _XB, HA, HB, _, null = self.parts[pid]
+        self.parts.append((None, None, _aligned_rows(HA, lo, hi), _aligned_rows(HB, lo, hi), row0, None))
+        new = len(self.parts) - 1
+        if null is not None:
+            # the shuffle is keyed by (file, row in file): the rows' null groups are the ones drawn for the whole file
+            HnA, HnB = self._null_of(pid)
+            self.parts[new] = self.parts[new][:5] + ((_aligned_rows(HnA, lo, hi), _aligned_rows(HnB, lo, hi), None),)
+        return new
 
     def export_rows(self, pid, lo, hi):
-        _XA, _XB, HA, HB, _ = self.parts[pid]
+        _XA, _XB, HA, HB, _, _null = self.parts[pid]
         return [HA[lo:hi], HB[lo:hi]]
 
     def import_rows(self, tensors, widths, row0=None):
         self.NA, self.NB = widths
-        self.parts.append((None, None, tensors[0].to(self.device), tensors[1].to(self.device), row0))
-        return len(self.parts) - 1
+        self.parts.append((None, None, tensors[0].to(self.device), tensors[1].to(self.device), row0, None))
+        pid = len(self.parts) - 1
+        if row0 is not None and self.parts[pid][2].shape[0]:
+            self._start_null(pid)
+        return pid
 
     def drop_part(self, pid):
         self.parts[pid] = None
@@ -472,7 +527,10 @@ class _HipPairedSession(_HipSession):
         """Scores of A, B and the two null groups, deltas, null distances, STEP 4's per-bin reduction and the quiescence mask
         of part `pid` from its resident histograms, as device tensors."""
         eng, S, NA, NB, q = self.eng, self.S, self.NA, self.NB, self.q
-        XA, XB, HA, HB, row0 = self.parts[pid]
+        XA, XB, HA, HB, row0, _null = self.parts[pid]
+        if HA.shape[0] and row0 is None:
+            raise ValueError("paired part %d has no shuffle key (row0)" % pid)
+        HnA, HnB = self._null_of(pid) if HA.shape[0] else (None, None)
         if not keep:
             self.parts[pid] = None
         if HA.shape[0] == 0:
@@ -481,8 +539,7 @@ class _HipPairedSession(_HipSession):
                     "quies": t.empty(0, dtype=t.uint8, device=dv), "rdist": t.empty(0, dtype=t.float32, device=dv),
                     "mdiff": t.empty(0, dtype=t.int32, device=dv)}
         ga, gb = (NA, NB) if self.groupSize == -1 else (self.groupSize, self.groupSize)
-        # the null groups' histograms straight from the real groups' (multivariate hypergeometric, no pass over X)
-        HnA, HnB = eng.null_hist_from_binhist(HA, HB, NA + NB, S, ga, gb, self.seed, row0)
+        # (the null groups' histograms were drawn straight from the real groups' when the part was counted: _start_null)
         if self.sal == 1:
             # one pass over the four histograms: table gathers, deltas, null distances and STEP 4's reduction (round 3); groups
             # too wide for the tables to sit in LDS take the separate passes below

@@ -170,11 +170,11 @@ __global__ __launch_bounds__(256) void k_null_hist_h_seq(const u16* __restrict__
             }
             // ONE flat loop over the columns that are drawn -- every state but the modal one, then the columns without a state
             // -- so that the 64 rows of a wave run n - max h steps each (209 +- 12 on chr1-like rows) instead of the sum over
-            // the categories of the wave's largest count.  A draw takes ONE BYTE of Philox output: with u in [byte, byte + 1) / 256
-            // the column joins A if (byte + 1) rem <= 256 needA, B if byte rem >= 256 needA and (byte + 1) rem <= 256 (needA +
-            // needB), neither if byte rem >= 256 (needA + needB); in the remaining ~2 of 256 cases 32 more bits from a second
-            // stream decide -- the outcome is that of a 40-bit uniform number, 16 draws per Philox call instead of 4.
-            u32 A256 = (u32)ga << 8, AB256 = (u32)(ga + gb) << 8, rem = (u32)n_cols;
+            // the categories of the wave's largest count.  A draw takes SIXTEEN BITS of Philox output (round 4; a byte before):
+            // with u in [v, v + 1) / 65536 the column joins A if (v + 1) rem <= 65536 needA, B if v rem >= 65536 needA and
+            // (v + 1) rem <= 65536 (needA + needB), neither if v rem >= 65536 (needA + needB); in the remaining ~2 of 65536 cases
+            // 32 more bits from a second stream decide -- the outcome is that of a 48-bit uniform number, 8 draws per Philox call.
+            u32 A256 = (u32)ga << 16, AB256 = (u32)(ga + gb) << 16, rem = (u32)n_cols;
             const u32 ndraw = (u32)n_cols - best;
             const u64 grow = (u64)(row0 + r0 + lane);
             u32 r0w = 0, r1w = 0, r2w = 0, r3w = 0, cur = 0, nb = 0, calls = 0;          // main stream: 16 bytes per call
@@ -190,17 +190,17 @@ __global__ __launch_bounds__(256) void k_null_hist_h_seq(const u16* __restrict__
                     left = s < S ? (u32)pa[s] : (u32)n_cols - tot;
                     inA = 0; inB = 0;
                 }
-                if ((nb & 3u) == 0) {
+                if ((nb & 1u) == 0) {
                     if (nb == 0) {
                         u32 c[4] = {(u32)grow, (u32)(grow >> 32), calls++, 0x6e756c6cu};
                         philox4x32_10(c, (u32)seed, (u32)(seed >> 32));
                         r0w = c[0]; r1w = c[1]; r2w = c[2]; r3w = c[3];
-                        nb = 16;
+                        nb = 8;
                     }
                     cur = r0w; r0w = r1w; r1w = r2w; r2w = r3w;
                 }
-                const u32 byte = cur & 0xffu;
-                cur >>= 8;
+                const u32 byte = cur & 0xffffu;                                           // (sixteen bits)
+                cur >>= 16;
                 --nb;
                 const u32 t = byte * rem, hi = t + rem;
                 bool a = hi <= A256;
@@ -212,16 +212,16 @@ __global__ __launch_bounds__(256) void k_null_hist_h_seq(const u16* __restrict__
                         a0w = c[0]; a1w = c[1]; a2w = c[2]; a3w = c[3];
                         ahave = 4;
                     }
-                    const u64 u40 = ((u64)byte << 32) | a0w;
+                    const u64 u48 = ((u64)byte << 32) | a0w;
                     a0w = a1w; a1w = a2w; a2w = a3w;
                     --ahave;
-                    const u32 pick = (u32)((u40 * rem) >> 40);                            // uniform in [0, rem)
-                    a = pick < (A256 >> 8);
-                    b = !a && pick < (AB256 >> 8);
+                    const u32 pick = (u32)((u48 * rem) >> 48);                            // uniform in [0, rem)
+                    a = pick < (A256 >> 16);
+                    b = !a && pick < (AB256 >> 16);
                 }
                 inA += a; inB += b;
-                A256 -= a ? 256u : 0u;
-                AB256 -= (a || b) ? 256u : 0u;
+                A256 -= a ? 65536u : 0u;
+                AB256 -= (a || b) ? 65536u : 0u;
                 --rem;
                 --left;
             }
@@ -230,8 +230,8 @@ __global__ __launch_bounds__(256) void k_null_hist_h_seq(const u16* __restrict__
             if (s >= 0 && s < S) { pa[s] = (u16)inA; pb[s] = (u16)inB; }
             for (int z = s + 1; z < S; ++z)
                 if (z != modal) pa[z] = 0;
-            pa[modal] = (u16)(A256 >> 8);
-            pb[modal] = (u16)((AB256 - A256) >> 8);
+            pa[modal] = (u16)(A256 >> 16);
+            pb[modal] = (u16)((AB256 - A256) >> 16);
         }
         __builtin_amdgcn_wave_barrier();
         store_staged(sa, reinterpret_cast<char*>(OA + r0 * S), rows * rowb, lane);
@@ -264,18 +264,28 @@ __device__ __forceinline__ u32 nh_range_pop(const u32* __restrict__ bits, u32 o,
     return cnt;
 }
 
-template <bool FULL>
+// Round 4: the draw loop again.  Where round 3's 3.15 ms went: ~14 instructions per draw on the main path, Philox 4 (64 per
+// call -- the 32 x 32 multiplies are full rate on gfx950, tools/ubench/rng_rate.hip --, 16 byte-sized draws per call) and ~7 for
+// the tie path, which a wave walked whenever ONE of its 64 lanes' bytes straddled need_A / remaining: 22 % of the draws.  Now
+//  * a draw takes 16 bits (8 per Philox call: +4 instructions per draw), so a lane ties once in ~65536 draws instead of 256;
+//  * the eight draws of a call run SPECULATIVELY with six instructions each -- x = (need_A << 16) - 1 - v * rem by one
+//    v_mad_i32_i24 (rem = n - d is scalar), a = x >= rem - 1 (signed), the outcome bit into the string by v_lshl_or, need_A by
+//    another v_mad_i32_i24 -- and ONE test per call, umin over the eight (u32)x < rem, catches every possible tie (a tie is
+//    0 <= x < rem - 1; the test is conservative); if any lane of the wave fails it (0.8 % of the calls) the wave repeats the
+//    call's eight draws from the saved state on the careful path, which resolves ties with 32 more bits like k_null_hist_h_seq.
+// Same law, same Philox counters and tie rule as k_null_hist_h_seq (identical outputs, tests/test_hip_s3_null.py); the
+// arithmetic is signed 32-bit, hence rows of at most 32767 columns here (the bit strings limit the kernel to 3072 anyway).
+// Only the case the command line has without -g: ga + gb == n (a column that does not join A joins B, one bit string).
 __global__ __launch_bounds__(256) void k_null_hist_h(const u16* __restrict__ HA, const u16* __restrict__ HB, long R, int S, int n_cols,
                                                       int ga, int gb, u64 seed, long row0, u16* __restrict__ OA, u16* __restrict__ OB, int TR,
                                                       int NW) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int rowb = 2 * S;
-    const size_t per_wave = (size_t)2 * TR * rowb + (size_t)(FULL ? 1 : 2) * NW * 256;
+    const size_t per_wave = (size_t)2 * TR * rowb + (size_t)NW * 256;
     char* sa = smem + (size_t)wave * per_wave;                    // the wave's TR rows of hA, later of the A group's counts
     char* sb = sa + TR * rowb;
     u32* bitsA = reinterpret_cast<u32*>(sb + TR * rowb) + lane;   // [word][lane]
-    u32* bitsB = bitsA + (FULL ? 0 : NW * 64);
     const long ntiles = (R + TR - 1) / TR;
     for (long tile = (long)blockIdx.x * 4 + wave; tile < ntiles; tile += (long)gridDim.x * 4) {
         const long r0 = tile * TR;
@@ -293,82 +303,105 @@ __global__ __launch_bounds__(256) void k_null_hist_h(const u16* __restrict__ HA,
                 pa[s] = (u16)h;
                 if (h > best) { best = h; modal = s; }
             }
-            u32 A256 = (u32)ga << 8, AB256 = (u32)(ga + gb) << 8;
+            int Am1 = (int)(((u32)ga << 16) - 1u);                                        // (need_A << 16) - 1
             const u32 m = (u32)n_cols - best;
             const u64 grow = (u64)(row0 + r0 + lane);
-            u32 r0w = 0, r1w = 0, r2w = 0, r3w = 0, calls = 0;
+            u32 calls = 0;
             u32 a0w = 0, a1w = 0, a2w = 0, a3w = 0, ahave = 0, acalls = 0;
-            u32 wA = 0, wB = 0;
-            // one draw at position d (rem = n - d is the same in every lane: scalar) from one byte of Philox output: with u in
-            // [byte, byte + 1) / 256 the column joins A if (byte + 1) rem <= 256 need_A, B if byte rem >= 256 need_A and (byte + 1)
-            // rem <= 256 (need_A + need_B), neither if byte rem >= 256 (need_A + need_B); in the ~2 of 256 other cases 32 more
-            // bits from a second stream decide -- the outcome is that of a 40-bit uniform number
-            auto draw = [&](u32 byte, u32 d) {
-                const u32 rem = (u32)n_cols - d;
-                const u32 hi = __umul24(byte, rem) + rem, t = hi - rem;                   // 24-bit operands: n <= 65535
-                bool a = hi <= A256;
-                bool b = FULL ? !a && t >= A256 : t >= A256 && hi <= AB256;
-                if (!(a || b || (!FULL && t >= AB256))) {
+            u32 wA = 0;
+            // the careful draw at position d: certain unless the 16-bit interval straddles need_A / rem, then 32 more bits decide
+            auto draw = [&](u32 v, u32 d) {
+                const int rem = n_cols - (int)d;
+                const int x = Am1 - (int)__umul24(v, (u32)rem);                           // (need_A << 16) - 1 - v rem
+                bool a = x >= rem - 1;                                                    // (v + 1) rem <= need_A << 16
+                if (!a && x >= 0) {                                                       // v rem < need_A << 16 < (v + 1) rem
                     if (ahave == 0) {
                         u32 c[4] = {(u32)grow, (u32)(grow >> 32), acalls++, 0x74696573u};
                         philox4x32_10(c, (u32)seed, (u32)(seed >> 32));
                         a0w = c[0]; a1w = c[1]; a2w = c[2]; a3w = c[3];
                         ahave = 4;
                     }
-                    const u64 u40 = ((u64)byte << 32) | a0w;
+                    const u64 u48 = ((u64)v << 32) | a0w;
                     a0w = a1w; a1w = a2w; a2w = a3w;
                     --ahave;
-                    const u32 pick = (u32)((u40 * rem) >> 40);                            // uniform in [0, rem)
-                    a = pick < (A256 >> 8);
-                    b = !a && (FULL || pick < (AB256 >> 8));
+                    const u32 pick = (u32)((u48 * (u32)rem) >> 48);                       // uniform in [0, rem)
+                    a = pick < (((u32)Am1 + 1u) >> 16);
                 }
-                const u32 bit = 1u << (d & 31u);
-                wA |= a ? bit : 0u;
-                if (!FULL) wB |= b ? bit : 0u;
-                A256 -= a ? 256u : 0u;
-                if (!FULL) AB256 -= (a || b) ? 256u : 0u;
+                wA |= a ? 1u << (d & 31u) : 0u;
+                Am1 -= a ? 65536 : 0;
             };
-            auto refill = [&]() {                                                         // 16 draws per call
+            u32 d = 0;
+            for (; d + 8 <= m; d += 8) {
                 u32 c[4] = {(u32)grow, (u32)(grow >> 32), calls++, 0x6e756c6cu};
                 philox4x32_10(c, (u32)seed, (u32)(seed >> 32));
-                r0w = c[0]; r1w = c[1]; r2w = c[2]; r3w = c[3];
-            };
-            // whole words of four draws, then the last one to three
-            u32 d = 0;
-            for (; d + 4 <= m; d += 4) {
-                if ((d & 15u) == 0) refill();
-                const u32 cur = r0w;
-                r0w = r1w; r1w = r2w; r2w = r3w;
+                const int Am1_0 = Am1;
+                const u32 wA_0 = wA;
+                const int rem0 = __builtin_amdgcn_readfirstlane(n_cols - (int)d);         // every lane of the wave is at the same d
+                const int bit0 = __builtin_amdgcn_readfirstlane((int)(d & 31u));
+                u32 low = 0xffffffffu;
+                // two draws per word of Philox output, 13 instructions: v_and / v_lshrrev (the two halves), then per draw
+                // v_mad_i32_i24 (x), v_cmp_le_i32 (a), v_cndmask (a as 0 / 1), v_lshl_or (the outcome bit), v_mad_i32_i24 (need_A),
+                // and one v_min3_u32 for the tie test
+#define NH_PAIR(W, K)                                                                                                             \
+                {                                                                                                                 \
+                    u32 v0_, v1_, x0_, x1_, a_;                                                                                   \
+                    asm volatile(                                                                                                 \
+                        "v_and_b32_e32 %[v0], 0xffff, %[w]\n\t"                                                                   \
+                        "v_lshrrev_b32_e32 %[v1], 16, %[w]\n\t"                                                                   \
+                        "v_mad_i32_i24 %[x0], %[v0], %[nr0], %[am]\n\t"                                                           \
+                        "v_cmp_le_i32_e32 vcc, %[rm0], %[x0]\n\t"                                                                 \
+                        "v_cndmask_b32_e64 %[a], 0, 1, vcc\n\t"                                                                   \
+                        "v_lshl_or_b32 %[wa], %[a], %[b0], %[wa]\n\t"                                                             \
+                        "v_mad_i32_i24 %[am], %[a], %[m64k], %[am]\n\t"                                                           \
+                        "v_mad_i32_i24 %[x1], %[v1], %[nr1], %[am]\n\t"                                                           \
+                        "v_cmp_le_i32_e32 vcc, %[rm1], %[x1]\n\t"                                                                 \
+                        "v_cndmask_b32_e64 %[a], 0, 1, vcc\n\t"                                                                   \
+                        "v_lshl_or_b32 %[wa], %[a], %[b1], %[wa]\n\t"                                                             \
+                        "v_mad_i32_i24 %[am], %[a], %[m64k], %[am]\n\t"                                                           \
+                        "v_min3_u32 %[lo], %[x0], %[x1], %[lo]"                                                                   \
+                        : [v0] "=&v"(v0_), [v1] "=&v"(v1_), [x0] "=&v"(x0_), [x1] "=&v"(x1_), [a] "=&v"(a_), [wa] "+v"(wA),       \
+                          [am] "+v"(Am1), [lo] "+v"(low)                                                                          \
+                        : [w] "v"(W), [nr0] "s"((K) - rem0), [nr1] "s"((K) + 1 - rem0), [rm0] "s"(rem0 - (K) - 1),                \
+                          [rm1] "s"(rem0 - (K) - 2), [b0] "s"(bit0 + (K)), [b1] "s"(bit0 + (K) + 1), [m64k] "s"(-65536)           \
+                        : "vcc");                                                                                                 \
+                }
+                NH_PAIR(c[0], 0)
+                NH_PAIR(c[1], 2)
+                NH_PAIR(c[2], 4)
+                NH_PAIR(c[3], 6)
+#undef NH_PAIR
+                if (low < (u32)rem0) {                                                    // a tie is possible in this call: repeat it carefully
+                    Am1 = Am1_0;
+                    wA = wA_0;
 #pragma unroll
-                for (u32 k = 0; k < 4; ++k) draw((cur >> (8 * k)) & 0xffu, d + k);
-                if ((d & 31u) == 28u) {
+                    for (int k = 0; k < 8; ++k) draw((k & 1) ? c[k >> 1] >> 16 : c[k >> 1] & 0xffffu, d + k);
+                }
+                if ((d & 31u) == 24u) {
                     bitsA[(d >> 5) * 64] = wA;
                     wA = 0;
-                    if (!FULL) { bitsB[(d >> 5) * 64] = wB; wB = 0; }
                 }
             }
-            if (d < m) {
-                if ((d & 15u) == 0) refill();
-                u32 cur = r0w;
-                for (; d < m; ++d, cur >>= 8) draw(cur & 0xffu, d);
+            if (d < m) {                                                                  // the last one to seven draws
+                u32 c[4] = {(u32)grow, (u32)(grow >> 32), calls++, 0x6e756c6cu};
+                philox4x32_10(c, (u32)seed, (u32)(seed >> 32));
+#pragma unroll
+                for (int k = 0; k < 7; ++k)
+                    if (d + k < m) draw((k & 1) ? c[k >> 1] >> 16 : c[k >> 1] & 0xffffu, d + k);
             }
-            if (m & 31u) {
-                bitsA[(m >> 5) * 64] = wA;
-                if (!FULL) bitsB[(m >> 5) * 64] = wB;
-            }
+            if (m & 31u) bitsA[(m >> 5) * 64] = wA;
             // counts per state: range popcounts between the prefix sums of the histogram; the modal state takes what is missing
             u32 o = 0;
             for (int s = 0; s < S; ++s) {
                 const u32 h = s == modal ? 0u : (u32)pa[s];
                 const u32 ca = nh_range_pop(bitsA, o, h);
-                const u32 cb = FULL ? h - ca : nh_range_pop(bitsB, o, h);
                 pa[s] = (u16)ca;
-                pb[s] = (u16)cb;
+                pb[s] = (u16)(h - ca);
                 o += h;
             }
             // positions o .. m - 1 are the columns without a state: drawn (they take places in the groups), not reported
-            pa[modal] = (u16)(A256 >> 8);                                                 // = ga - (A members among the m drawn)
-            pb[modal] = FULL ? (u16)(best - (A256 >> 8)) : (u16)((AB256 - A256) >> 8);
+            const u32 needA = ((u32)Am1 + 1u) >> 16;                                      // = ga - (A members among the m drawn)
+            pa[modal] = (u16)needA;
+            pb[modal] = (u16)(best - needA);
         }
         __builtin_amdgcn_wave_barrier();
         store_staged(sa, reinterpret_cast<char*>(OA + r0 * S), rows * rowb, lane);
@@ -389,26 +422,21 @@ int null_hist_from_binhist_impl(const uint16_t* HA, const uint16_t* HB, int64_t 
     const int TR = tile_rows(2 * 2 * S);
     long blocks = ((R + TR - 1) / TR + 3) / 4;
     if (blocks > num_cus() * 8L) blocks = num_cus() * 8L;
-    // the bit-string kernel while a lane's string fits the wave's share of LDS; EPG_NULL_HIST=seq: the round-2 kernel (A/B)
+    // the bit-string kernel while a lane's string fits the wave's share of LDS and the two groups fill the row (the command line
+    // without -g); otherwise, and with EPG_NULL_HIST=seq (A/B), the column-by-column kernel -- same draws, same outputs
     const bool full = ga + gb == n_cols;
     const int NW = (n_cols + 31) / 32;
-    const size_t bits_bytes = (size_t)(full ? 1 : 2) * NW * 256;
+    const size_t bits_bytes = (size_t)NW * 256;
     const char* env = getenv("EPG_NULL_HIST");
-    // (-g runs, ga + gb < n: two bit strings and a three-way decision per draw measured 5 % SLOWER than the round-2 kernel, which stays)
-    if (bits_bytes <= 24 * 1024 && !(env && env[0] == 's') && (full || (env && env[0] == 'b'))) {
+    if (full && bits_bytes <= 24 * 1024 && !(env && env[0] == 's')) {
         const size_t shmem = 4 * ((size_t)2 * TR * 2 * S + bits_bytes);
         static bool attr_set = false;
         if (!attr_set) {
-            EPG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_null_hist_h<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            EPG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_null_hist_h<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            EPG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_null_hist_h), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             attr_set = true;
         }
-        if (full)
-            hipLaunchKernelGGL(k_null_hist_h<true>, dim3((unsigned)blocks), dim3(256), shmem, st, HA, HB, (long)R, S, n_cols, ga, gb, (u64)seed,
-                               (long)row0, OA, OB, TR, NW);
-        else
-            hipLaunchKernelGGL(k_null_hist_h<false>, dim3((unsigned)blocks), dim3(256), shmem, st, HA, HB, (long)R, S, n_cols, ga, gb, (u64)seed,
-                               (long)row0, OA, OB, TR, NW);
+        hipLaunchKernelGGL(k_null_hist_h, dim3((unsigned)blocks), dim3(256), shmem, st, HA, HB, (long)R, S, n_cols, ga, gb, (u64)seed,
+                           (long)row0, OA, OB, TR, NW);
         EPG_LAUNCH_CHECK("k_null_hist_h");
         return EPG_OK;
     }

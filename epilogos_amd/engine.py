@@ -432,13 +432,15 @@ def quiescent_from_binhist(HA, NA, HB, NB, S, qstate):
     return mask
 
 
-def null_hist_from_binhist(HA, HB, n_cols, S, ga, gb, seed, row0=0):
-    """Histograms of the two shuffled null groups from the REAL groups' histograms (multivariate hypergeometric, exact)."""
+def null_hist_from_binhist(HA, HB, n_cols, S, ga, gb, seed, row0=0, stream=None):
+    """Histograms of the two shuffled null groups from the REAL groups' histograms (multivariate hypergeometric, exact).
+    stream: a torch.cuda.Stream to launch on instead of the current one (the outputs are allocated from the CURRENT stream's
+    pool all the same; the caller orders the streams with events)."""
     if HA.shape != HB.shape:
         raise ValueError("paired histograms must have the same shape")
     OA, OB = torch.empty_like(HA), torch.empty_like(HB)
     _abi.call("epg_null_hist_from_binhist", _ptr(HA), _ptr(HB), HA.shape[0], S, n_cols, ga, gb, seed, row0, _ptr(OA), _ptr(OB),
-              _stream())
+              _stream() if stream is None else C.c_void_p(stream.cuda_stream))
     return OA, OB
 
 

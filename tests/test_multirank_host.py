@@ -156,3 +156,19 @@ def test_ranks_agree_on_the_plan_when_only_some_see_the_cache(tmp_path, golden_r
     assert driver._plan(files, Two(other_rows), None)[0] == "assigned"
     monkeypatch.setattr(driver, "_cached_rows", lambda f: 10 if f.name == "a.txt" else None)   # group 2 of a paired run uncached
     assert driver._plan(files[:1], Two(lambda v: v), None, files2=files[1:])[0] == "assigned"
+
+
+def test_parse_assignment_is_balanced_on_hg19():
+    """driver._assign_files shares the files out by bytes, longest first (LPT): on hg19's 24 chromosome sizes the fullest of 8
+    ranks holds <= 1.15 x the mean (1.40 with the round-3 rule "the rank whose bin range holds most of the
+    file"); every file has exactly one parser; one or two files per rank stay with the rank that owns their bins."""
+    from epilogos_amd import driver
+    import bench
+    bp = bench.HG19_BP
+    for world in (2, 3, 4, 8, 16):
+        owner = driver._assign_files([None] * len(bp), world, sizes=bp)
+        assert len(owner) == len(bp) and all(0 <= g < world for g in owner)
+        load = np.bincount(owner, weights=bp, minlength=world)
+        assert load.max() / load.mean() <= (1.15 if world <= 8 else 1.35), (world, load.max() / load.mean())
+    assert driver._assign_files([None] * 2, 2, sizes=[100, 1000]) == [0, 1]
+    assert driver._assign_files([None] * 3, 3, sizes=[500, 500, 500]) == [0, 1, 2]
