@@ -8,6 +8,8 @@ import numpy as np
 from . import build as _build
 
 _lib = None
+# int8_t* alloc(int64_t rows, int32_t cols, int64_t* ldx, void* user): include/epilogos_io.h epgio_alloc_fn
+_ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_int64, C.c_int32, C.POINTER(C.c_int64), C.c_void_p)
 
 
 class EpilogosIOError(RuntimeError):
@@ -31,6 +33,8 @@ def load():
     lib.epgio_open_table.argtypes = [C.c_char_p, i64, i64, i32]
     lib.epgio_open_table_ex.restype = p
     lib.epgio_open_table_ex.argtypes = [C.c_char_p, i64, i64, i32, i32]
+    lib.epgio_open_table_into.restype = p
+    lib.epgio_open_table_into.argtypes = [C.c_char_p, i64, i64, i32, i32, _ALLOC_FN, p]
     lib.epgio_table_rows.restype = i64
     lib.epgio_table_rows.argtypes = [p]
     lib.epgio_table_cols.restype = i32
@@ -61,6 +65,10 @@ def load():
     lib.epgio_rolling_max_f64.argtypes = [p, i64, C.c_int32, p, C.c_int32]
     lib.epgio_inflate_mem.restype = i64
     lib.epgio_inflate_mem.argtypes = [p, i64, p, i64, i32]
+    lib.epgio_release_buffers.restype = None
+    lib.epgio_release_buffers.argtypes = [i32]
+    lib.epgio_set_reader_plan.restype = None
+    lib.epgio_set_reader_plan.argtypes = [i32]
     lib.epgio_default_threads.restype = i32
     lib.epgio_default_threads.argtypes = []
     lib.epgio_thread_census.restype = None
@@ -115,6 +123,14 @@ def inflate_mem(blob, own=True, cap=None):
     out = C.create_string_buffer(cap)
     n = load().epgio_inflate_mem(blob, len(blob), out, cap, 1 if own else 0)
     return None if n < 0 else out.raw[:n]
+
+
+def release_buffers(background=True):
+    load().epgio_release_buffers(1 if background else 0)
+
+
+def set_reader_plan(n):
+    load().epgio_set_reader_plan(int(n))
 
 
 def thread_census(reset=False):
@@ -225,22 +241,45 @@ def read_table(path, rows=None, threads=0, ldx=None, alloc=None, with_range=Fals
     lib = load()
     lo, hi = (0, -1) if rows is None else rows
     _log_io("read", path, lo, hi)
-    h = lib.epgio_open_table_ex(str(path).encode(), lo, hi, threads, _state_limit)
+    dest, failure = [], []
+
+    def check(states, R, N):
+        if states.dtype != np.int8 or states.ndim != 2 or states.shape[0] != R or states.shape[1] < N \
+                or (R and states.strides != (states.shape[1], 1)):
+            raise ValueError("alloc must return a C-contiguous int8 [R, width >= N] array")
+        return states
+
+    if alloc is not None:
+        # the native reader calls back once it knows the shape (after the inflate and the line count) and parses every row
+        # straight into the caller's array -- a page-locked staging buffer in the driver: no intermediate matrix, no copy
+        def native_alloc(R, N, ldx_out, _user):
+            try:
+                states = check(alloc(int(R), int(N)), int(R), int(N))
+                dest.append(states)
+                ldx_out[0] = states.shape[1]
+                return states.ctypes.data or 1          # (an empty array may have no address: any non-NULL value will do)
+            except BaseException as e:                  # must not propagate through the C frames
+                failure.append(e)
+                return None
+        cb = _ALLOC_FN(native_alloc)
+        h = lib.epgio_open_table_into(str(path).encode(), lo, hi, threads, _state_limit, cb, None)
+    else:
+        h = lib.epgio_open_table_ex(str(path).encode(), lo, hi, threads, _state_limit)
+    if failure:
+        if h:
+            lib.epgio_close_table(h)
+        raise failure[0]
     if not h:
         raise EpilogosIOError(_err())
     try:
         R, N = lib.epgio_table_rows(h), lib.epgio_table_cols(h)
-        if alloc is not None:
-            states = alloc(R, N)
-            if states.dtype != np.int8 or states.ndim != 2 or states.shape[0] != R or states.shape[1] < N \
-                    or (R and states.strides != (states.shape[1], 1)):
-                raise ValueError("alloc must return a C-contiguous int8 [R, width >= N] array")
-            width = states.shape[1]
+        if alloc is not None:                           # (an empty file returns before the reader asks for a destination)
+            states = dest[0] if dest else check(alloc(R, N), R, N)
         else:
             width = N if ldx is None else ldx
             states = np.empty((R, width), dtype=np.int8)
-        if lib.epgio_table_copy_states(h, states.ctypes.data, width) != 0:
-            raise EpilogosIOError(_err())
+            if lib.epgio_table_copy_states(h, states.ctypes.data, width) != 0:
+                raise EpilogosIOError(_err())
         slo, shi = C.c_int32(0), C.c_int32(0)
         lib.epgio_table_state_range(h, C.byref(slo), C.byref(shi))
         offp = C.c_void_p()

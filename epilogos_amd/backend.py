@@ -171,9 +171,12 @@ class _HipSession:
         self.torch, self.eng, self.device = be.torch, be.engine, be.device
         # staging buffers in flight; paired mode holds a part's A and B at once, so never fewer than two
         # (first come, first served: the driver takes the parts as their parsers finish)
-        # (no more of them than parser threads this rank may run: every buffer is ~1 GB of page-locked memory per rank)
+        # A reader holds its buffer from the moment it knows its file's shape until the upload is over -- the parse runs straight
+        # into it -- so fewer buffers than readers serialise the parse stage (profiles/r04k: four buffers for sixteen readers,
+        # every reader waited 0.3-1.7 s).  Half as many as this rank may run parser threads, at most 8 (~1 GB of page-locked
+        # memory each for a whole-genome run).
         from . import _io
-        self.pool = be.engine.PinnedPool(max(2, int(__import__("os").environ.get("EPILOGOS_PINNED_BUFFERS", min(4, _io.host_budget())))),
+        self.pool = be.engine.PinnedPool(max(2, int(__import__("os").environ.get("EPILOGOS_PINNED_BUFFERS", min(8, max(4, _io.host_budget() // 2))))),
                                          in_order=False)
         self.copy_stream = self.torch.cuda.Stream(device=self.device)
         self.held = {}                                   # ticket -> pinned buffer handed to the parser

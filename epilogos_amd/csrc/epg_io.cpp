@@ -16,6 +16,7 @@
 #include <algorithm>
 #include <atomic>
 #include <memory>
+#include <mutex>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -100,14 +101,74 @@ int n_threads(int32_t req) {
 // from the mapped compressed bytes with the zlib inflate API into ONE malloc'd buffer whose size comes from the gzip trailer
 // (ISIZE; a multi-member or > 4 GiB file simply grows it).  The first version went through gzread into a std::vector that
 // doubled and zero-filled as it grew: 0.55 GB/s for plain text, 0.15-0.2 GB/s of text for gzip.
+// The inflated text of a big file is gigabytes; handing such a buffer back to the kernel (munmap) and faulting the next one in
+// holds the process's memory-map lock for tenths of a second, and every other reader thread -- they all fault pages into their
+// own buffers -- stands still meanwhile (profiles/r04l: eight readers returning in the same millisecond, one second after their
+// parses had ended).  Buffers of 64 MiB and more are therefore kept and reused by the next file that fits (the driver reads
+// the largest files first); they are never returned during a run -- the command line leaves through _exit.
+struct BigBufs {
+    std::mutex m;
+    std::vector<std::pair<char*, size_t>> free_list;
+};
+BigBufs& big_bufs() { static BigBufs* b = new BigBufs(); return *b; }
+constexpr size_t BIG_MIN = (size_t)64 << 20;
+
+void advise_huge(void* p, size_t n);
+
+char* big_alloc(size_t n, size_t* cap) {
+    if (n >= BIG_MIN) {
+        BigBufs& b = big_bufs();
+        std::lock_guard<std::mutex> g(b.m);
+        int best = -1;
+        for (int i = 0; i < (int)b.free_list.size(); ++i)
+            if (b.free_list[i].second >= n && (best < 0 || b.free_list[i].second < b.free_list[best].second)) best = i;
+        if (best >= 0) {
+            char* p = b.free_list[best].first;
+            *cap = b.free_list[best].second;
+            b.free_list.erase(b.free_list.begin() + best);
+            return p;
+        }
+    }
+    char* p = (char*)malloc(n);
+    if (p && n >= BIG_MIN) advise_huge(p, n);
+    *cap = n;
+    return p;
+}
+
+void big_free(char* p, size_t cap) {
+    if (!p) return;
+    if (cap >= BIG_MIN) {
+        // keep the address range, give the PAGES back now: MADV_DONTNEED takes the memory-map lock shared (page faults of the
+        // other readers go on) and runs on this reader's own thread, in parallel with the others' -- where munmap, and the
+        // teardown of tens of gigabytes at process exit, are exclusive and serial
+#ifdef MADV_DONTNEED
+        const uintptr_t a = ((uintptr_t)p + 4095) & ~(uintptr_t)4095, e = ((uintptr_t)p + cap) & ~(uintptr_t)4095;
+        if (e > a) madvise((void*)a, (size_t)(e - a), MADV_DONTNEED);
+#endif
+        BigBufs& b = big_bufs();
+        std::lock_guard<std::mutex> g(b.m);
+        if (b.free_list.size() < 64) { b.free_list.emplace_back(p, cap); return; }
+    }
+    free(p);
+}
+
+char* big_grow(char* p, size_t old_cap, size_t used, size_t n, size_t* cap) {   // a larger buffer with the first `used` bytes kept
+    char* q = big_alloc(n, cap);
+    if (!q) return nullptr;
+    if (used) memcpy(q, p, used);
+    big_free(p, old_cap);
+    return q;
+}
+
 struct Text {
     const char* data = nullptr;
     size_t size = 0;
     void* map = nullptr;           // mmap of the file (plain: the text itself)
     size_t map_len = 0;
     char* heap = nullptr;          // inflated text
+    size_t heap_cap = 0;
     ~Text() {
-        if (heap) free(heap);
+        big_free(heap, heap_cap);
         if (map) munmap(map, map_len);
     }
 };
@@ -131,19 +192,20 @@ bool inflate_own(const unsigned char* in, size_t flen, size_t cap_hint, Text& t,
     struct Member { size_t out0, out1; uint32_t crc, isize; };
     std::vector<Member> members;
     epginflate::Out out{nullptr, 0, cap_hint};
-    t.heap = (char*)malloc(cap_hint + 320 + 16);
+    t.heap = big_alloc(cap_hint + 320 + 16, &t.heap_cap);
     if (!t.heap) return false;
-    advise_huge(t.heap, cap_hint);
+    out.cap = t.heap_cap - 320 - 16;                       // (a reused buffer may be larger than asked for)
     out.base = (unsigned char*)t.heap;
     auto grow = [&](size_t min_cap) {
         size_t ncap = out.cap + out.cap / 2 + (1u << 24);
         if (ncap < min_cap) ncap = min_cap + (1u << 24);
-        char* nh = (char*)realloc(t.heap, ncap + 320 + 16);
+        size_t got = 0;
+        char* nh = big_grow(t.heap, t.heap_cap, out.pos, ncap + 320 + 16, &got);
         if (!nh) return false;
-        advise_huge(nh, ncap);
         t.heap = nh;
+        t.heap_cap = got;
         out.base = (unsigned char*)nh;
-        out.cap = ncap;
+        out.cap = got - 320 - 16;
         return true;
     };
     size_t pos = 0;
@@ -204,8 +266,9 @@ bool inflate_own(const unsigned char* in, size_t flen, size_t cap_hint, Text& t,
 // zlib's inflate over the whole (possibly multi-member) gzip file in memory; the fallback of inflate_own and the reference the
 // differential fuzz compares it with.
 bool inflate_zlib(const unsigned char* in, size_t flen, size_t cap, Text& t, const char* path) {
-    t.heap = (char*)malloc(cap + 16);
+    t.heap = big_alloc(cap + 16, &t.heap_cap);
     if (!t.heap) { fail("out of memory reading %s", path); return false; }
+    cap = t.heap_cap - 16;
     z_stream zs;
     memset(&zs, 0, sizeof(zs));
     if (inflateInit2(&zs, 15 + 16) != Z_OK) { fail("zlib init failed"); return false; }
@@ -213,10 +276,12 @@ bool inflate_zlib(const unsigned char* in, size_t flen, size_t cap, Text& t, con
     for (;;) {
         if (cap - out_pos < (1u << 20)) {
             const size_t ncap = cap + cap / 2 + (1u << 24);
-            char* nh = (char*)realloc(t.heap, ncap + 16);
+            size_t got = 0;
+            char* nh = big_grow(t.heap, t.heap_cap, out_pos, ncap + 16, &got);
             if (!nh) { inflateEnd(&zs); fail("out of memory reading %s", path); return false; }
             t.heap = nh;
-            cap = ncap;
+            t.heap_cap = got;
+            cap = got - 16;
         }
         zs.next_in = const_cast<Bytef*>(in + in_pos);
         zs.avail_in = (uInt)std::min<size_t>(flen - in_pos, 1u << 30);
@@ -259,7 +324,7 @@ bool slurp(const char* path, Text& t, int32_t threads = 0) {
         // plain text: parse in place when the mapping leaves slack after the last byte (it does unless the size is a multiple
         // of the page size), else through a copy
         if (flen % 4096 != 0 && 4096 - flen % 4096 >= 16) { t.data = (const char*)m; t.size = flen; return true; }
-        t.heap = (char*)malloc(flen + 16);
+        t.heap = big_alloc(flen + 16, &t.heap_cap);
         if (!t.heap) { fail("out of memory reading %s", path); return false; }
         memcpy(t.heap, m, flen);
         memset(t.heap + flen, 0, 16);
@@ -274,7 +339,9 @@ bool slurp(const char* path, Text& t, int32_t threads = 0) {
     {
         static const bool use_own = [] { const char* e = getenv("EPGIO_INFLATE"); return !(e && e[0] == 'z'); }();
         if (use_own && inflate_own(in, flen, cap, t, threads)) return true;
-        if (t.heap) { free(t.heap); t.heap = nullptr; }
+        big_free(t.heap, t.heap_cap);
+        t.heap = nullptr;
+        t.heap_cap = 0;
     }
     return inflate_zlib(in, flen, cap, t, path);
 }
@@ -368,7 +435,9 @@ void fold_minmax512(const void* mn, const void* mx, int T, int* vlo, int* vhi) {
 struct epgio_table {
     int64_t rows = 0;
     int32_t cols = 0;
-    std::unique_ptr<int8_t[]> states;   // [rows * cols], not zero-filled
+    std::unique_ptr<int8_t[]> states;   // [rows * cols], not zero-filled; empty when the caller supplied the destination
+    const int8_t* ext = nullptr;        // the caller's destination (epgio_open_table_into), row pitch ext_ld
+    int64_t ext_ld = 0;
     std::vector<char> loc;          // concatenated "chr\tstart\tend"
     std::vector<int64_t> loc_off;   // [rows + 1]
     int32_t state_lo = 0, state_hi = 0;   // smallest / largest state value as written in the file (1-based); 0, 0 when empty
@@ -416,6 +485,7 @@ void epgio_thread_census(int32_t* live, int32_t* peak, int32_t reset) {
 
 int32_t epgio_default_threads(void) { return n_threads(0); }
 
+
 int64_t epgio_inflate_mem(const void* in, int64_t n, void* out, int64_t cap, int32_t own) {
     if (!in || n < 0 || cap < 0 || (cap > 0 && !out)) return fail("inflate_mem: bad argument");
     const unsigned char* p = (const unsigned char*)in;
@@ -431,16 +501,66 @@ int64_t epgio_inflate_mem(const void* in, int64_t n, void* out, int64_t cap, int
     return (int64_t)t.size;
 }
 
+static epgio_table* open_table_impl(const char* path, int64_t row_lo, int64_t row_hi, int32_t threads, int32_t max_state,
+                                    epgio_alloc_fn alloc, void* user);
+
 epgio_table* epgio_open_table_ex(const char* path, int64_t row_lo, int64_t row_hi, int32_t threads, int32_t max_state) {
+    return open_table_impl(path, row_lo, row_hi, threads, max_state, nullptr, nullptr);
+}
+
+epgio_table* epgio_open_table_into(const char* path, int64_t row_lo, int64_t row_hi, int32_t threads, int32_t max_state,
+                                   epgio_alloc_fn alloc, void* user) {
+    if (!alloc) { fail("open_table_into: no allocator"); return nullptr; }
+    return open_table_impl(path, row_lo, row_hi, threads, max_state, alloc, user);
+}
+
+// readers inside open_table_impl right now: with threads == 0 ("share") every parallel phase of a file takes the rank's budget
+// divided by the files being read at that moment -- one thread each while sixteen files inflate side by side, more for the
+// last, largest files once the small ones are done
+static std::atomic<int> g_readers{0}, g_reader_plan{0};
+static int reader_share() {                       // threads of one file's parallel phase under threads == 0
+    const int active = std::max(1, std::max(g_readers.load(), g_reader_plan.load()));
+    return std::max(1, n_threads(0) / active);
+}
+extern "C" void epgio_set_reader_plan(int32_t n) { g_reader_plan.store(n > 0 ? n : 0); }
+
+// The kept text buffers go back to the kernel -- on a thread of its own when `background` (the driver calls this when its last
+// file has been parsed: unmapping tens of gigabytes takes seconds, which then pass under the score pass and the writers instead
+// of at process exit).
+extern "C" void epgio_release_buffers(int32_t background) {
+    std::vector<std::pair<char*, size_t>> bufs;
+    {
+        BigBufs& b = big_bufs();
+        std::lock_guard<std::mutex> g(b.m);
+        bufs.swap(b.free_list);
+    }
+    if (bufs.empty()) return;
+    auto work = [bufs] { for (auto& e : bufs) free(e.first); };
+    if (background) std::thread(work).detach();
+    else work();
+}
+struct ReaderScope {
+    ReaderScope() { g_readers.fetch_add(1); }
+    ~ReaderScope() { g_readers.fetch_sub(1); }
+};
+
+static epgio_table* open_table_impl(const char* path, int64_t row_lo, int64_t row_hi, int32_t threads, int32_t max_state,
+                                    epgio_alloc_fn alloc, void* user) {
     Census census_;                                           // the caller: the inflate of a file is one serial thread
+    ReaderScope reader_;
     const int max0 = (max_state > 31 ? 127 : 31) - 1;        // largest 0-based state kept: two classes, like the kernels
     static const bool timing = getenv("EPGIO_TIMING") != nullptr;
     double t0 = now_s();
-    auto lap = [&](const char* what) {
-        if (timing) { const double t1 = now_s(); fprintf(stderr, "    [epgio] %-28s %7.3f s\n", what, t1 - t0); t0 = t1; }
+    const char* fname = strrchr(path, '/') ? strrchr(path, '/') + 1 : path;
+    auto lap = [&](const char* what) {            // EPGIO_TIMING: the phase, its file, its time and when it ended (CLOCK_MONOTONIC)
+        if (timing) {
+            const double t1 = now_s();
+            fprintf(stderr, "    [epgio] %-26s %-26s %7.3f s  ends %.3f\n", fname, what, t1 - t0, t1);
+            t0 = t1;
+        }
     };
     Text buf;
-    if (!slurp(path, buf, threads)) return nullptr;
+    if (!slurp(path, buf, threads > 0 ? threads : reader_share())) return nullptr;
     lap("read / inflate");
     const char* base = buf.data;
     const char* end = base + buf.size;
@@ -450,7 +570,7 @@ epgio_table* epgio_open_table_ex(const char* path, int64_t row_lo, int64_t row_h
     if (!last_nl) { auto* t = new epgio_table(); t->loc_off.assign(1, 0); return t; }
     end = last_nl + 1;
 
-    const int T = n_threads(threads);
+    const int T = threads > 0 ? threads : reader_share();
     // segment borders on line starts
     std::vector<const char*> seg(T + 1);
     seg[0] = base;
@@ -495,8 +615,22 @@ epgio_table* epgio_open_table_ex(const char* path, int64_t row_lo, int64_t row_h
     auto* t = new epgio_table();
     t->rows = row_hi - row_lo;
     t->cols = cols;
-    t->states.reset(new int8_t[(size_t)t->rows * cols + 1]);
-    advise_huge(t->states.get(), (size_t)t->rows * cols);
+    int8_t* sbase = nullptr;
+    int64_t sld = cols;
+    if (alloc) {
+        // the caller's destination (a pinned, row-padded staging buffer): rows are parsed straight into it -- no 1 GB intermediate
+        // matrix, no copy of it (round 3: both, single-threaded, after the parse)
+        int64_t ld = 0;
+        sbase = alloc(t->rows, cols, &ld, user);
+        if (!sbase || ld < cols) { fail("%s: no destination for %lld x %d states", path, (long long)t->rows, cols); delete t; return nullptr; }
+        sld = ld;
+        t->ext = sbase;
+        t->ext_ld = ld;
+    } else {
+        t->states.reset(new int8_t[(size_t)t->rows * cols + 1]);
+        advise_huge(t->states.get(), (size_t)t->rows * cols);
+        sbase = t->states.get();
+    }
     t->loc_off.assign((size_t)t->rows + 1, 0);
 
     // pass 1: location text lengths; pass 2 (after prefix sum): states + location text.  Both per segment.
@@ -550,7 +684,8 @@ epgio_table* epgio_open_table_ex(const char* path, int64_t row_lo, int64_t row_h
                     memcpy(t->loc.data() + t->loc_off[(size_t)r], p, (size_t)len);
                     t->loc[(size_t)(t->loc_off[(size_t)r] + len)] = '\n';
                     const char* q = p + len;
-                    int8_t* out = t->states.get() + (size_t)r * cols;
+                    int8_t* out = sbase + (size_t)r * (size_t)sld;
+                    if (sld > cols) memset(out + cols, 0xff, (size_t)(sld - cols));    // pad bytes: not a state
                     int c = 0;
 #if defined(__x86_64__)
                     if (simd) {
@@ -639,6 +774,7 @@ int epgio_table_state_range(const epgio_table* t, int32_t* lo, int32_t* hi) {
 
 int epgio_table_copy_states(const epgio_table* t, int8_t* out, int64_t ldx) {
     if (!t || !out || ldx < t->cols) return fail("copy_states: bad argument");
+    if (t->ext) return t->ext == out && t->ext_ld == ldx ? 0 : fail("copy_states: the states were parsed into the caller's own destination");
     for (int64_t r = 0; r < t->rows; ++r) {
         memcpy(out + r * ldx, t->states.get() + (size_t)r * t->cols, (size_t)t->cols);
         if (ldx > t->cols) memset(out + r * ldx + t->cols, 0xff, (size_t)(ldx - t->cols));

@@ -196,10 +196,14 @@ def _stream_parts(jobs, sess, numStates):
     # threads on a 16-core quota -- the cgroup then throttles every process for the rest of each 100 ms period).
     ncores = _io.host_budget()
     workers = max(1, min(int(os.environ.get("EPILOGOS_PARSE_WORKERS", ncores)), len(jobs)))
-    # native threads per file: the cores are shared out.  (With every reader fanning its short parse phases out to all cores
-    # next to fifteen inflating threads, a cgroup CPU quota throttles the whole process for the rest of each 100 ms period:
-    # phases that take 0.03 s alone took 1 s.)
-    file_threads = max(1, ncores // workers)
+    # native threads per file: 0 = "share" -- every parallel phase of a file takes this rank's budget divided by the files being
+    # read at that moment (one thread each while sixteen files inflate side by side, more for the last, largest files).  (With
+    # every reader fanning its short parse phases out to all cores next to fifteen inflating threads, a cgroup CPU quota
+    # throttles the whole process for the rest of each 100 ms period: phases that take 0.03 s alone took 1 s.)
+    file_threads = 0
+    if hasattr(sess, "pool") and all(hi is None for _p, _lo, hi in jobs):
+        # whole text files: their sizes tell the staging pool how large its buffers will have to become (see PinnedPool.hint)
+        sess.pool.hint({t: max(os.path.getsize(jobs[t][0]), 1) for t in range(len(jobs))})
 
     trace = os.environ.get("EPILOGOS_TIMING") == "2"        # per-part timeline on stderr
     t_origin = time.perf_counter()
@@ -218,9 +222,9 @@ def _stream_parts(jobs, sess, numStates):
         except BaseException:
             sess.skip(ticket)
             raise
-        if trace:
-            print("    [part %2d] %-28s reader %6.2f .. %6.2f s" % (ticket, Path(path).name[:28], t_begin, time.perf_counter() - t_origin),
-                  file=sys.stderr, flush=True)
+        if trace:                                          # (absolute CLOCK_MONOTONIC seconds too: they line up with [epgio])
+            print("    [part %2d] %-28s reader %6.2f .. %6.2f s  (%.3f .. %.3f)" % (ticket, Path(path).name[:28], t_begin,
+                  time.perf_counter() - t_origin, t_begin + t_origin, time.perf_counter()), file=sys.stderr, flush=True)
         return ticket, arr, N[0], loc, rng
 
     def weight(ticket):                                # bytes of input behind a job (a row range: unknown share, the whole file)
@@ -232,9 +236,13 @@ def _stream_parts(jobs, sess, numStates):
     from concurrent.futures import as_completed
     pool = ThreadPoolExecutor(max_workers=workers)
     futs = []
+    left = len(jobs)
     try:
+        _io.set_reader_plan(min(workers, left))        # files being read side by side: what the readers share the cores by
         futs = [pool.submit(read, t) for t in sorted(range(len(jobs)), key=lambda t: (-weight(t), t))]
         for f in as_completed(futs):
+            left -= 1
+            _io.set_reader_plan(min(workers, left))
             t, arr, N, loc, rng = f.result()
             _check_range(jobs[t][0], rng, numStates)
             t_yield = time.perf_counter() - t_origin
@@ -248,6 +256,7 @@ def _stream_parts(jobs, sess, numStates):
             f.cancel()
         raise
     finally:
+        _io.set_reader_plan(0)
         pool.shutdown(wait=True)
 
 

@@ -360,6 +360,36 @@ def null_hist(XA, NA, XB, NB, S, ga, gb, seed, row0=0):
     return HA, HB
 
 
+_hip_rt = None
+
+
+def _pinned_bytes(nbytes):
+    """A page-locked int8 host tensor of EXACTLY nbytes, from hipHostMalloc through ctypes.  torch.empty(pin_memory=True) rounds
+    every request up to a power of two (its caching host allocator): the 1.11 GB staging buffers of a whole-genome run became
+    2 GiB each -- twice the memory to lock (0.15-0.6 s per buffer, during which every thread of the process that faults a page
+    stands still) and to give back at exit.  torch recognises the memory as pinned (it asks the driver), so copies from it are
+    asynchronous.  The buffers live as long as the process."""
+    global _hip_rt
+    if _hip_rt is None:
+        for name in ("libamdhip64.so", "libamdhip64.so.7", "libamdhip64.so.6"):
+            try:
+                _hip_rt = C.CDLL(name)
+                break
+            except OSError:
+                continue
+        if _hip_rt is None:
+            _hip_rt = False
+    if _hip_rt:
+        ptr = C.c_void_p()
+        if _hip_rt.hipHostMalloc(C.byref(ptr), C.c_size_t(int(nbytes)), C.c_uint(0)) == 0 and ptr.value:
+            arr = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_int8)), shape=(int(nbytes),))
+            t = torch.from_numpy(arr)
+            if t.is_pinned():
+                return t
+            _hip_rt.hipHostFree(ptr)
+    return torch.empty(int(nbytes), dtype=torch.int8, pin_memory=True)
+
+
 class PinnedPool:
     """A few page-locked host staging buffers.  in_order=True hands them out IN TICKET ORDER (ticket k waits until tickets
     < k were served and a buffer is free): for a consumer that takes the parts in ticket order, parser threads running
@@ -374,6 +404,16 @@ class PinnedPool:
         self.next = 0
         self.in_order = in_order
         self.aborted = False
+        self.weights = {}
+        self.target = 0
+        self.waiting = set()
+
+    def hint(self, weights):
+        """{ticket: bytes of the input file behind it}.  Page-locking memory is slow (~3 GB/s): a pool whose buffers grow to each
+        larger request re-allocated ~1 GB a dozen times while the files of a genome completed smallest first (profiles/r04h:
+        1.5 s between the end of chr1's parse and its hand-over).  With the hint, the first request scales its own size by
+        (largest file / its file) and every buffer is allocated ONCE, at that size (+ 5 %)."""
+        self.weights = dict(weights)
 
     def abort(self):
         """The consumer gave up (an error): wake every waiting parser thread instead of leaving it blocked."""
@@ -382,15 +422,34 @@ class PinnedPool:
             self.cv.notify_all()
 
     def acquire(self, ticket, nbytes):
+        import os, sys, time
+        trace = os.environ.get("EPILOGOS_TIMING") == "2"
+        t_in = time.perf_counter()
         with self.cv:
-            self.cv.wait_for(lambda: self.aborted or ((not self.in_order or self.next == ticket) and len(self.free) > 0))
+            # among the readers waiting for a buffer the one with the LARGEST file goes first: the largest files finish last
+            # and nothing can start behind them -- they are the critical path of the parse stage
+            self.waiting.add(ticket)
+            first = lambda: not self.weights or self.weights.get(ticket, 0) >= max(self.weights.get(t, 0) for t in self.waiting)
+            self.cv.wait_for(lambda: self.aborted or ((not self.in_order or self.next == ticket) and len(self.free) > 0 and first()))
+            self.waiting.discard(ticket)
             if self.aborted:
                 raise RuntimeError("staging pool aborted")
             buf = self.free.pop()
             self.next += 1
             self.cv.notify_all()
+        w = self.weights.get(ticket)
+        if w and nbytes:
+            self.target = max(self.target, int(nbytes / w * max(self.weights.values()) * 1.05))
+        t_got = time.perf_counter()
+        grew = 0
         if buf is None or buf.numel() < nbytes:
-            buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.int8, pin_memory=True)
+            buf = None                                   # (give the smaller buffer back before asking for the larger one)
+            buf = _pinned_bytes(max(int(nbytes), self.target, 1 << 20))
+            grew = buf.numel()
+        if trace:
+            print("    [pool] ticket %2d: waited %.2f s for a staging buffer%s  (at %.3f)" % (
+                ticket, t_got - t_in, ", page-locked %.2f GB in %.2f s" % (grew / 1e9, time.perf_counter() - t_got) if grew else "",
+                time.perf_counter()), file=sys.stderr, flush=True)
         return buf
 
     def skip(self, ticket):

@@ -238,6 +238,12 @@ def main(mode, commandLineBool, inputDirectory, inputDirectory1, inputDirectory2
     if os.environ.get("EPILOGOS_TIMING") and rank == 0:
         import time
         print("    [timing] %-34s %7.2f s" % ("end of main (since process start)", time.time() - _T_START), flush=True)
+        try:                                                     # what the process holds (and will have to give back at exit)
+            st = dict(l.split(":", 1) for l in open("/proc/self/status").read().splitlines() if ":" in l)
+            print("    [timing] memory at the end: " + ", ".join("%s %.1f GB" % (k, int(st[k].split()[0]) / 1048576.0)
+                                                              for k in ("VmHWM", "VmRSS", "RssAnon", "RssFile", "RssShmem") if k in st), flush=True)
+        except (OSError, ValueError):
+            pass
     if world > 1 or under_launcher:
         import torch.distributed as dist
         dist.destroy_process_group()

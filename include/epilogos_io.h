@@ -38,6 +38,16 @@ epgio_table* epgio_open_table(const char* path, int64_t row_lo, int64_t row_hi, 
 /* The same for a state model of `max_state` states: up to 31 (what epgio_open_table assumes) values outside 1..31 are stored
  * as "not a state", above that values outside 1..127 -- the GPU kernels of the wide models decode the whole byte. */
 epgio_table* epgio_open_table_ex(const char* path, int64_t row_lo, int64_t row_hi, int32_t threads, int32_t max_state);
+
+/* The same, parsing the states STRAIGHT INTO the caller's destination: once the number of rows and state columns is known
+ * (after the inflate and the line count), alloc(rows, cols, &ldx, user) is called once, on the calling thread, and returns an
+ * int8 buffer of rows * ldx bytes with ldx >= cols (or NULL to give up); every row is parsed into it, bytes cols .. ldx - 1 of
+ * a row are set to -1.  What the driver uses with page-locked, row-padded staging buffers: no intermediate matrix, no copy.
+ * epgio_table_copy_states is a no-op check on such a table.  threads == 0 here and above means "share": each parallel phase
+ * takes epgio_default_threads() divided by the number of files this process is reading at that moment. */
+typedef int8_t* (*epgio_alloc_fn)(int64_t rows, int32_t cols, int64_t* ldx, void* user);
+epgio_table* epgio_open_table_into(const char* path, int64_t row_lo, int64_t row_hi, int32_t threads, int32_t max_state,
+                                   epgio_alloc_fn alloc, void* user);
 int64_t epgio_table_rows(const epgio_table* t);
 int32_t epgio_table_cols(const epgio_table* t);          /* number of state columns N */
 /* Smallest and largest state value of the parsed rows AS WRITTEN IN THE FILE (1-based); 0, 0 for an empty table.  The
@@ -109,6 +119,13 @@ int64_t epgio_inflate_mem(const void* in, int64_t n, void* out, int64_t cap, int
  * library's runnable threads right now and their peak since the last reset (callers inside the library + workers they
  * started; a caller waiting for its workers does not count). */
 int32_t epgio_default_threads(void);
+/* How many files the caller is reading, or is about to read, side by side (worker threads that still have a file to do): the
+ * "share" of threads == 0 divides by the larger of this and the readers inside the library at that moment -- a worker between
+ * two files must not make the others believe its cores are free.  0 = no plan. */
+void epgio_set_reader_plan(int32_t n);
+/* The readers keep the text buffers of big files (>= 64 MiB inflated) for the next file instead of returning them to the kernel
+ * in the middle of a run; this returns them -- on a detached thread when background != 0.  Call it when nothing is left to read. */
+void epgio_release_buffers(int32_t background);
 void epgio_thread_census(int32_t* live, int32_t* peak, int32_t reset);
 
 #ifdef __cplusplus

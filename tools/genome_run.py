@@ -36,6 +36,10 @@ ap.add_argument("--keep", action="store_true")
 ap.add_argument("--skip-warm", action="store_true")
 ap.add_argument("--also", default="", help="comma list of further saliencies to run from the warm cache, e.g. 2,3")
 ap.add_argument("--paired", action="store_true", help="also write the 379 + 342 column split as two groups and run -m paired (S1)")
+ap.add_argument("--ranks", type=int, default=0, help="also: a cold run WITHOUT the cache on this many ranks (`--gpus N`, gloo transport, the "
+                                                   "ranks share the GPU) next to a cold one-rank run without the cache; thread census per rank")
+ap.add_argument("--only-ranks", action="store_true", help="stop after the --ranks comparison")
+ap.add_argument("--timeline", action="store_true", help="per-part reader timeline and per-file reader phases of the cold runs (stderr of the CLI)")
 ap.add_argument("--pvals", action="store_true", help="with --paired: one more warm run with -n (null-distribution fit, p-values, BH)")
 a = ap.parse_args()
 N, S = a.biosamples, 18
@@ -79,16 +83,29 @@ WRAP = ("import resource, subprocess, sys, json, time; t = time.time(); r = subp
         "'peak_rss_gb': resource.getrusage(resource.RUSAGE_CHILDREN).ru_maxrss / 1048576.0})); sys.exit(r.returncode)")
 
 
-def run(label, out, saliency=None, paired=False, extra=()):
+def run(label, out, saliency=None, paired=False, extra=(), use_cache=True, gpus=1, timeline=False):
     src = ["-m", "paired", "-a", str(gA), "-b", str(gB), "--null-seed", "7", *extra] if paired else ["-i", str(ind)]
     cmd = [sys.executable, "-c", WRAP, sys.executable, "-m", "epilogos_amd.run", "-l", *src, "-j", str(meta), "-o", str(out),
-           "-s", str(saliency or a.saliency), "--cache-dir", str(cache)]
-    r = subprocess.run(cmd, cwd=str(ROOT), capture_output=True, text=True, env=dict(os.environ, EPILOGOS_TIMING=os.environ.get("EPILOGOS_TIMING", "1")))
+           "-s", str(saliency or a.saliency)] + (["--cache-dir", str(cache)] if use_cache else []) + (["--gpus", str(gpus)] if gpus > 1 else [])
+    env = dict(os.environ, EPILOGOS_TIMING=os.environ.get("EPILOGOS_TIMING", "2" if timeline else "1"))
+    if timeline:
+        env["EPGIO_TIMING"] = "1"
+    tlog = base / ("threads_%d.log" % len(list(base.glob("threads_*.log"))))
+    env["EPILOGOS_THREAD_LOG"] = str(tlog)
+    if gpus > 1:
+        env["EPILOGOS_DIST_BACKEND"] = "gloo"                   # several ranks on the one GPU of this box
+        for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+            env.pop(k, None)
+    r = subprocess.run(cmd, cwd=str(ROOT), capture_output=True, text=True, env=env)
+    if tlog.exists():
+        census = [l.split("\t") for l in tlog.read_text().splitlines()]
+        print("== %s: native threads -- per rank peak runnable / budget: %s; sum of peaks %d of %s node cores" % (
+            label, ", ".join("%s/%s" % (c[1], c[2]) for c in census), sum(int(c[1]) for c in census), census[0][3] if census else "?"))
     info = [json.loads(l[2:]) for l in r.stdout.splitlines() if l.startswith("@@")]
     print("== %s" % label)
     print("".join(l + "\n" for l in r.stdout.splitlines() if "[timing]" in l or ("[Done]" in l and " s" in l)), end="")
-    if os.environ.get("EPGIO_TIMING") or os.environ.get("EPILOGOS_TIMING") == "2":   # reader phases / part timeline (stderr)
-        print("".join(l + "\n" for l in r.stderr.splitlines() if "[epgio]" in l or "[part" in l), end="")
+    if timeline or os.environ.get("EPGIO_TIMING") or os.environ.get("EPILOGOS_TIMING") == "2":   # reader phases / part timeline (stderr)
+        print("".join(l + "\n" for l in r.stderr.splitlines() if "[epgio]" in l or "[part" in l or "[pool]" in l), end="")
     if r.returncode != 0 or not info:
         print(r.stdout[-3000:], r.stderr[-5000:])
         raise SystemExit("%s failed" % label)
@@ -99,7 +116,19 @@ def run(label, out, saliency=None, paired=False, extra=()):
 
 
 out1, out2 = base / "out_cold", base / "out_warm"
-cold = run("cold (inflate + parse text, fills the cache)", out1)
+if a.ranks:
+    c1 = run("cold, no cache, 1 rank", base / "out_cold_nc1", use_cache=False, timeline=a.timeline)
+    cN = run("cold, no cache, %d ranks on the one GPU (gloo)" % a.ranks, base / "out_cold_ncN", use_cache=False, gpus=a.ranks, timeline=a.timeline)
+    for name in ("chr1", "chr21", "chrY"):
+        fn = "scores_in_s%d_matrix_%s.txt.gz" % (a.saliency, name)
+        assert gzip.open(base / "out_cold_nc1" / fn, "rb").read() == gzip.open(base / "out_cold_ncN" / fn, "rb").read(), "1 rank vs %d ranks: %s" % (a.ranks, name)
+    print("1 rank vs %d ranks: chr1 / chr21 / chrY outputs identical; wall %.1f s vs %.1f s" % (a.ranks, c1["wall_s"], cN["wall_s"]), flush=True)
+    shutil.rmtree(base / "out_cold_nc1", ignore_errors=True)
+    shutil.rmtree(base / "out_cold_ncN", ignore_errors=True)
+    if a.only_ranks:
+        shutil.rmtree(base, ignore_errors=True)
+        raise SystemExit(0)
+cold = run("cold (inflate + parse text, fills the cache)", out1, timeline=a.timeline)
 warm = None if a.skip_warm else run("warm (memory-mapped int8 cache)", out2)
 
 for sal in [int(v) for v in a.also.split(",") if v]:
