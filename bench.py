@@ -297,7 +297,7 @@ def bench_paired(torch, be, d, R, R_global, bin0, S, world, reps, fence, dev, di
         sess.all_reduce(d)
         sess.finish_device(R_global, NA + NB)
         e[2].record()
-        res = [sess.results_device(pid) for pid in pids]
+        res = sess.results_device_all(pids)                    # one launch over all the parts (what sess.results() does first)
         e[3].record()
         fence()
         wall = time.perf_counter() - t0
@@ -324,7 +324,7 @@ def bench_paired(torch, be, d, R, R_global, bin0, S, world, reps, fence, dev, di
             "phases_ms": {"count passes of the 2 x %d parts (main stream; the null groups of part k run on the second stream under "
                           "the count pass of part k + 1)" % len(parts): round(exp_ms, 3),
                           "allreduce+normalise+tables": round(comb_ms, 3),
-                          "rest of the null groups + scores/deltas/null distances/metrics (one pass per part) + quiescence": round(res_ms, 3)},
+                          "rest of the null groups + scores/deltas/null distances/metrics/quiescence of all parts (one launch)": round(res_ms, 3)},
             "roofline": {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBPS, "algorithmic_bytes_per_bin": bpb,
                          "achieved": round(gb, 1), "frac": round(gb / HBM_PEAK_GBPS, 4),
                          "what": "whole job (device time of the three phases on the main stream) against the bytes it has to move; the "

@@ -41,6 +41,7 @@ PROTOTYPES = {
     "epg_score_s1_from_binhist": (C.c_int, [_p, _i64, _i32, _i32, _p, _p, _p, _p, _i64, _p]),
     "epg_score_s1_from_binhist_table": (C.c_int, [_p, _i64, _i32, _i32, _p, _p, _p, _p, _p]),
     "epg_pair_scores_s1_from_binhist": (C.c_int, [_p, _p, _p, _p, _i64, _i32, _i32, _i32, _i32, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
+    "epg_pair_scores_s1_parts": (C.c_int, [_i32, _p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _p]),
     "epg_score_s2": (C.c_int, [_p, _i64, _i32, _i64, _i32, _i64, _p, _p, _p, _p, _i64, _p]),
     "epg_score_s2_from_binhist": (C.c_int, [_p, _i64, _i32, _i32, _i64, _p, _p, _p, _p, _i64, _p]),
     "epg_score_s3": (C.c_int, [_p, _i64, _i32, _i64, _i32, _p, _p, _p, _p, _i64, _p]),

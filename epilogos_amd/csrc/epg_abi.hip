@@ -36,6 +36,9 @@ int normalise_i64_impl(const int64_t*, int64_t, float*, void*, int64_t, hipStrea
 int normalise_i32_impl(const int32_t*, int64_t, float*, void*, int64_t, hipStream_t);
 int hist_s2_from_binhist_impl(const uint16_t*, const uint16_t*, int64_t, int32_t, int64_t*, hipStream_t);
 int score_s1_from_hist_table_impl(const uint16_t*, int64_t, int32_t, int32_t, const double*, const float*, double*, float*, hipStream_t);
+int pair_scores_s1_parts_impl(int32_t, const uint16_t* const*, const uint16_t* const*, const uint16_t* const*, const uint16_t* const*, const int64_t*,
+                              int32_t, int32_t, int32_t, int32_t, int32_t, const float*, const float*, const float*, const float*, float* const*,
+                              float* const*, float* const*, int32_t* const*, uint8_t* const*, int32_t, hipStream_t);
 int pair_scores_s1_impl(const uint16_t*, const uint16_t*, const uint16_t*, const uint16_t*, int64_t, int32_t, int32_t, int32_t, int32_t, int32_t,
                         const float*, const float*, const float*, const float*, float*, float*, float*, int32_t*, hipStream_t);
 int combine_score_s1_impl(int64_t*, int32_t, const uint16_t*, int64_t, int32_t, int32_t, float*, double*, float*, void*, int64_t, hipStream_t);
@@ -146,6 +149,14 @@ int epg_score_s1_from_binhist(const uint16_t* H, int64_t R, int32_t N, int32_t S
 int epg_score_s1_from_binhist_table(const uint16_t* H, int64_t R, int32_t N, int32_t S, const double* T64, const float* T32,
                                     double* out64, float* out32, void* stream) {
     return score_s1_from_hist_table_impl(H, R, N, S, T64, T32, out64, out32, (hipStream_t)stream);
+}
+
+int epg_pair_scores_s1_parts(int32_t nparts, const uint16_t* const* HA, const uint16_t* const* HB, const uint16_t* const* HnA,
+                             const uint16_t* const* HnB, const int64_t* R, int32_t S, int32_t NA, int32_t NB, int32_t ga, int32_t gb,
+                             const float* TA, const float* TB, const float* TnA, const float* TnB, float* const* delta, float* const* null_dist,
+                             float* const* dist, int32_t* const* maxdiff, uint8_t* const* mask, int32_t qstate, void* stream) {
+    return pair_scores_s1_parts_impl(nparts, HA, HB, HnA, HnB, R, S, NA, NB, ga, gb, TA, TB, TnA, TnB, delta, null_dist, dist, maxdiff, mask, qstate,
+                                     (hipStream_t)stream);
 }
 
 int epg_pair_scores_s1_from_binhist(const uint16_t* HA, const uint16_t* HB, const uint16_t* HnA, const uint16_t* HnB, int64_t R, int32_t S,

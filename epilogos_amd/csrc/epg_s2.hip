@@ -2,6 +2,7 @@
 #include "epg_common.h"
 
 #include <stdlib.h>
+#include <string.h>
 
 namespace epg {
 
@@ -583,6 +584,10 @@ __device__ __forceinline__ void load_staged(char* lds, const char* src, int nbyt
         *reinterpret_cast<uint4*>(lds + 16 * c) = *reinterpret_cast<const uint4*>(src + 16 * c);
     for (int o = (nchunks << 4) + 4 * lane; o + 4 <= nbytes; o += 256)
         *reinterpret_cast<u32*>(lds + o) = *reinterpret_cast<const u32*>(src + o);
+    // an odd number of uint16 (odd state count x odd number of rows): the last two bytes.  (Round 4: they were left out -- the count
+    // of the last state in the LAST bin of a part read stale LDS, one wrong delta per file of a 15-state model whose bin count mod 64
+    // is odd; found by tests/test_hip_parity.py::test_paired_s1_several_parts_in_one_launch.)
+    if ((nbytes & 2) && lane == 0) *reinterpret_cast<u16*>(lds + nbytes - 2) = *reinterpret_cast<const u16*>(src + nbytes - 2);
 }
 
 // d * d as numpy computes it -- rounded to float32 BEFORE it is added.  `__fmul_rn` + `__fadd_rn` are ordinary multiplies and adds to
@@ -719,12 +724,31 @@ constexpr int PF_WAVES_MAX = 12;                     // waves per workgroup: as 
 // With the state count at compile time a lane first takes its 2 S counts of A and B into registers; the wave's 64 delta rows then
 // go where those histogram rows were (64 x 4 S bytes either way), so a wave stages 8 S instead of 12 S bytes per bin and twelve
 // waves instead of six fit next to 52 KB of tables -- the kernel is latency-bound, occupancy is what it lacks.
+// Several PARTS in one launch (round 4): the command line holds a chromosome file's bins as a part of their own -- 24 for hg19 --
+// and a launch per part paid the copy of the tables into LDS, the ramp and the tail 24 times (1.5 ms of kernel time for 15 M bins
+// against 1.0 in one launch).  The parts' pointers and row counts travel in the kernel argument (PF_MAXP at a time); a wave's
+// tile index walks through the parts' tiles in order.  The quiescence mask of scores.py:294-303 (every column of A and of B holds
+// the quiescent state <=> its count equals the group's width) comes out of the same pass when a part asks for it.
+constexpr int PF_MAXP = 24;
+struct PfParts {
+    const u16* ha[PF_MAXP];
+    const u16* hb[PF_MAXP];
+    const u16* hna[PF_MAXP];
+    const u16* hnb[PF_MAXP];
+    float* delta[PF_MAXP];
+    float* ndist[PF_MAXP];
+    float* rdist[PF_MAXP];
+    int* maxdiff[PF_MAXP];
+    unsigned char* mask[PF_MAXP];          // NULL: no mask for this part
+    long rows[PF_MAXP];
+    long tile0[PF_MAXP + 1];               // first tile (64 rows) of every part, and their total
+    int n;
+};
+
 template <int SC>
-__global__ __launch_bounds__(64 * PF_WAVES_MAX) void k_pair_fused_s1(const u16* __restrict__ HA, const u16* __restrict__ HB, const u16* __restrict__ HnA,
-                                                                  const u16* __restrict__ HnB, long R, int S_, const float* __restrict__ TA,
+__global__ __launch_bounds__(64 * PF_WAVES_MAX) void k_pair_fused_s1(const PfParts pt, int S_, const float* __restrict__ TA,
                                                                   int entA, const float* __restrict__ TB, int entB, const float* __restrict__ TnA,
-                                                                  int entnA, const float* __restrict__ TnB, int entnB, float* __restrict__ delta,
-                                                                  float* __restrict__ ndist, float* __restrict__ rdist, int* __restrict__ maxdiff) {
+                                                                  int entnA, const float* __restrict__ TnB, int entnB, int NA, int NB, int qstate) {
 #pragma clang fp contract(off)   // numpy squares, rounds, then adds: no fused multiply-add anywhere in here
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int S = SC ? SC : S_;
@@ -745,9 +769,21 @@ __global__ __launch_bounds__(64 * PF_WAVES_MAX) void k_pair_fused_s1(const u16* 
     const int nwaves = blockDim.x >> 6;
     char* stage = smem + tab_bytes + (size_t)wave * 64 * (4 * hb + (SC ? 0 : rowb));
     char* sA = stage, *sB = sA + 64 * hb, *snA = sB + 64 * hb, *snB = snA + 64 * hb, *sD = SC ? sA : snB + 64 * hb;
-    const long ntiles = (R + 63) >> 6;
+    const long ntiles = pt.tile0[pt.n];
+    int part = 0;
     for (long tile = (long)blockIdx.x * nwaves + wave; tile < ntiles; tile += (long)gridDim.x * nwaves) {
-        const long row0 = tile * 64;
+        while (tile >= pt.tile0[part + 1]) ++part;                   // (a wave's tiles ascend: the part only moves forward)
+        const u16* __restrict__ HA = pt.ha[part];
+        const u16* __restrict__ HB = pt.hb[part];
+        const u16* __restrict__ HnA = pt.hna[part];
+        const u16* __restrict__ HnB = pt.hnb[part];
+        float* __restrict__ delta = pt.delta[part];
+        float* __restrict__ ndist = pt.ndist[part];
+        float* __restrict__ rdist = pt.rdist[part];
+        int* __restrict__ maxdiff = pt.maxdiff[part];
+        unsigned char* __restrict__ mask = pt.mask[part];
+        const long R = pt.rows[part];
+        const long row0 = (tile - pt.tile0[part]) * 64;
         const int rows = (int)(R - row0 < 64 ? R - row0 : 64);
         load_staged(sA, reinterpret_cast<const char*>(HA + row0 * S), rows * hb, lane);
         load_staged(sB, reinterpret_cast<const char*>(HB + row0 * S), rows * hb, lane);
@@ -765,6 +801,7 @@ __global__ __launch_bounds__(64 * PF_WAVES_MAX) void k_pair_fused_s1(const u16* 
             // SC: the counts of A and B into registers before any lane's delta row overwrites them (every lane's reads are
             // issued before the first write: a wave's LDS operations execute in order)
             u32 ca[SC ? SC : 1], cb[SC ? SC : 1];
+            if (mask) mask[row0 + lane] = qstate >= 0 && ha[qstate] == (u16)NA && hbq[qstate] == (u16)NB;   // (before any delta row lands)
             if (SC) {
 #pragma unroll
                 for (int s = 0; s < SC; ++s) {
@@ -834,16 +871,24 @@ __global__ __launch_bounds__(64 * PF_WAVES_MAX) void k_pair_fused_s1(const u16* 
     }
 }
 
-int pair_scores_s1_impl(const uint16_t* HA, const uint16_t* HB, const uint16_t* HnA, const uint16_t* HnB, int64_t R, int32_t S, int32_t NA,
-                        int32_t NB, int32_t ga, int32_t gb, const float* TA, const float* TB, const float* TnA, const float* TnB, float* delta,
-                        float* ndist, float* rdist, int32_t* maxdiff, hipStream_t st) {
-    if (R < 0 || S < 1 || S > 127 || NA < 1 || NB < 1 || ga < 1 || gb < 1) return fail(EPG_ERR_INVALID_ARG, "pair_scores_s1: bad shape");
-    if (R == 0) return EPG_OK;
-    if (!HA || !HB || !HnA || !HnB || !TA || !TB || !TnA || !TnB || !delta || !ndist || !rdist || !maxdiff)
+int pair_scores_s1_parts_impl(int32_t nparts, const uint16_t* const* HA, const uint16_t* const* HB, const uint16_t* const* HnA,
+                              const uint16_t* const* HnB, const int64_t* R, int32_t S, int32_t NA, int32_t NB, int32_t ga, int32_t gb,
+                              const float* TA, const float* TB, const float* TnA, const float* TnB, float* const* delta, float* const* ndist,
+                              float* const* rdist, int32_t* const* maxdiff, uint8_t* const* mask, int32_t qstate, hipStream_t st) {
+    if (nparts < 0 || S < 1 || S > 127 || NA < 1 || NB < 1 || ga < 1 || gb < 1 || qstate >= S) return fail(EPG_ERR_INVALID_ARG, "pair_scores_s1: bad shape");
+    if (nparts == 0) return EPG_OK;
+    if (!HA || !HB || !HnA || !HnB || !R || !TA || !TB || !TnA || !TnB || !delta || !ndist || !rdist || !maxdiff)
         return fail(EPG_ERR_INVALID_ARG, "pair_scores_s1: NULL argument");
-    if ((reinterpret_cast<uintptr_t>(HA) | reinterpret_cast<uintptr_t>(HB) | reinterpret_cast<uintptr_t>(HnA) | reinterpret_cast<uintptr_t>(HnB) |
-         reinterpret_cast<uintptr_t>(delta)) & 15)
-        return fail(EPG_ERR_INVALID_ARG, "pair_scores_s1: histograms and delta must be 16-byte aligned");
+    if (NA > 65535 || NB > 65535) return fail(EPG_ERR_INVALID_ARG, "pair_scores_s1: more than 65535 columns");
+    for (int p = 0; p < nparts; ++p) {
+        if (R[p] < 0) return fail(EPG_ERR_INVALID_ARG, "pair_scores_s1: part %d has %lld rows", p, (long long)R[p]);
+        if (R[p] == 0) continue;
+        if (!HA[p] || !HB[p] || !HnA[p] || !HnB[p] || !delta[p] || !ndist[p] || !rdist[p] || !maxdiff[p])
+            return fail(EPG_ERR_INVALID_ARG, "pair_scores_s1: NULL argument in part %d", p);
+        if ((reinterpret_cast<uintptr_t>(HA[p]) | reinterpret_cast<uintptr_t>(HB[p]) | reinterpret_cast<uintptr_t>(HnA[p]) |
+             reinterpret_cast<uintptr_t>(HnB[p]) | reinterpret_cast<uintptr_t>(delta[p])) & 15)
+            return fail(EPG_ERR_INVALID_ARG, "pair_scores_s1: histograms and delta must be 16-byte aligned (part %d)", p);
+    }
     const int entA = (NA + 1) * S, entB = (NB + 1) * S, entnA = (ga + 1) * S, entnB = (gb + 1) * S;
     size_t tab = (size_t)(entA + entB + (TnA == TA ? 0 : entnA) + (TnB == TB ? 0 : entnB)) * 4;
     tab = (tab + 15) & ~(size_t)15;
@@ -860,8 +905,6 @@ int pair_scores_s1_impl(const uint16_t* HA, const uint16_t* HB, const uint16_t* 
         if (e && atoi(e) >= 1 && atoi(e) < waves) waves = atoi(e);
     }
     const size_t shmem = tab + (size_t)waves * per_wave;
-    long blocks = ((R + 63) / 64 + waves - 1) / waves;
-    if (blocks > num_cus()) blocks = num_cus();
 #define PF_LAUNCH(SC)                                                                                                            \
     do {                                                                                                                         \
         static bool attr_set = false;                                                                                            \
@@ -869,16 +912,45 @@ int pair_scores_s1_impl(const uint16_t* HA, const uint16_t* HB, const uint16_t* 
             EPG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pair_fused_s1<SC>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
             attr_set = true;                                                                                                     \
         }                                                                                                                        \
-        hipLaunchKernelGGL(k_pair_fused_s1<SC>, dim3((unsigned)blocks), dim3(64 * waves), shmem, st, HA, HB, HnA, HnB, (long)R, S, TA, entA, TB, \
-                           entB, TnA, entnA, TnB, entnB, delta, ndist, rdist, maxdiff);                                          \
+        hipLaunchKernelGGL(k_pair_fused_s1<SC>, dim3((unsigned)blocks), dim3(64 * waves), shmem, st, pt, S, TA, entA, TB, entB, TnA, entnA, \
+                           TnB, entnB, NA, NB, qstate);                                                                          \
     } while (0)
-    if (S == 18) PF_LAUNCH(18);
-    else if (S == 15) PF_LAUNCH(15);
-    else if (S == 25) PF_LAUNCH(25);
-    else PF_LAUNCH(0);
+    for (int p0 = 0; p0 < nparts;) {                                                  // PF_MAXP parts with rows per launch
+        PfParts pt;
+        memset(&pt, 0, sizeof(pt));
+        long tiles = 0;
+        int p = p0;
+        for (; p < nparts && pt.n < PF_MAXP; ++p) {
+            if (R[p] == 0) continue;
+            const int k = pt.n++;
+            pt.ha[k] = HA[p]; pt.hb[k] = HB[p]; pt.hna[k] = HnA[p]; pt.hnb[k] = HnB[p];
+            pt.delta[k] = delta[p]; pt.ndist[k] = ndist[p]; pt.rdist[k] = rdist[p]; pt.maxdiff[k] = maxdiff[p];
+            pt.mask[k] = mask ? mask[p] : nullptr;
+            pt.rows[k] = R[p];
+            pt.tile0[k] = tiles;
+            tiles += (R[p] + 63) / 64;
+        }
+        pt.tile0[pt.n] = tiles;
+        p0 = p;
+        if (pt.n == 0) break;
+        long blocks = (tiles + waves - 1) / waves;
+        if (blocks > num_cus()) blocks = num_cus();
+        if (S == 18) PF_LAUNCH(18);
+        else if (S == 15) PF_LAUNCH(15);
+        else if (S == 25) PF_LAUNCH(25);
+        else PF_LAUNCH(0);
+        EPG_LAUNCH_CHECK("k_pair_fused_s1");
+    }
 #undef PF_LAUNCH
-    EPG_LAUNCH_CHECK("k_pair_fused_s1");
     return EPG_OK;
+}
+
+int pair_scores_s1_impl(const uint16_t* HA, const uint16_t* HB, const uint16_t* HnA, const uint16_t* HnB, int64_t R, int32_t S, int32_t NA,
+                        int32_t NB, int32_t ga, int32_t gb, const float* TA, const float* TB, const float* TnA, const float* TnB, float* delta,
+                        float* ndist, float* rdist, int32_t* maxdiff, hipStream_t st) {
+    if (R < 0) return fail(EPG_ERR_INVALID_ARG, "pair_scores_s1: bad shape");
+    if (R > 0 && (!HA || !HB || !HnA || !HnB || !delta || !ndist || !rdist || !maxdiff)) return fail(EPG_ERR_INVALID_ARG, "pair_scores_s1: NULL argument");
+    return pair_scores_s1_parts_impl(1, &HA, &HB, &HnA, &HnB, &R, S, NA, NB, ga, gb, TA, TB, TnA, TnB, &delta, &ndist, &rdist, &maxdiff, nullptr, -1, st);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

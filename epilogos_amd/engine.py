@@ -323,6 +323,29 @@ def pair_scores_s1_from_binhist(HA, HB, HnA, HnB, S, NA, NB, ga, gb, TA, TB, TnA
     return delta, null, dist, maxdiff
 
 
+def pair_scores_s1_parts(parts, S, NA, NB, ga, gb, TA, TB, TnA, TnB, qstate=None):
+    """epg_pair_scores_s1_parts: `parts` is a list of (HA, HB, HnA, HnB) of the parts' histograms; one launch (per 24 parts) gives
+    every part's delta [R, S], null distance [R], STEP 4's distance [R] and largest-difference state [R] and -- with qstate not
+    None -- its quiescence mask uint8 [R] (qstate < 0: all zero).  Returns a list of dicts like _HipPairedSession.results_device."""
+    n = len(parts)
+    if n == 0:
+        return []
+    dev = parts[0][0].device
+    outs = []
+    for HA, _HB, _HnA, _HnB in parts:
+        R = HA.shape[0]
+        outs.append({"delta": torch.empty((R, S), dtype=torch.float32, device=dev), "null": torch.empty(R, dtype=torch.float32, device=dev),
+                     "rdist": torch.empty(R, dtype=torch.float32, device=dev), "mdiff": torch.empty(R, dtype=torch.int32, device=dev),
+                     "quies": torch.empty(R, dtype=torch.uint8, device=dev) if qstate is not None else None})
+    arr = lambda ts: (C.c_void_p * n)(*[t.data_ptr() if t is not None and t.numel() else None for t in ts])
+    rows = (C.c_int64 * n)(*[p[0].shape[0] for p in parts])
+    _abi.call("epg_pair_scores_s1_parts", n, arr([p[0] for p in parts]), arr([p[1] for p in parts]), arr([p[2] for p in parts]),
+              arr([p[3] for p in parts]), rows, S, NA, NB, ga, gb, _ptr(TA), _ptr(TB), _ptr(TnA), _ptr(TnB), arr([o["delta"] for o in outs]),
+              arr([o["null"] for o in outs]), arr([o["rdist"] for o in outs]), arr([o["mdiff"] for o in outs]),
+              arr([o["quies"] for o in outs]) if qstate is not None else None, -1 if qstate is None else int(qstate), _stream())
+    return outs
+
+
 def pair_finish(a, b, want_dist=True):
     R, S = a.shape
     delta = torch.empty_like(a)

@@ -127,6 +127,16 @@ int epg_pair_scores_s1_from_binhist(const uint16_t* HA, const uint16_t* HB, cons
                                     int32_t NA, int32_t NB, int32_t ga, int32_t gb, const float* TA, const float* TB, const float* TnA,
                                     const float* TnB, float* delta, float* null_dist, float* dist, int32_t* maxdiff, void* stream);
 
+/* The same pass over SEVERAL parts in one launch (the command line holds every chromosome file's bins as a part of their own):
+ * HA .. maxdiff are HOST arrays of nparts device pointers, R[p] the rows of part p (parts without rows are skipped); the tables
+ * and widths are shared.  mask (may be NULL, and so may its entries): uint8 [R[p]] per part, the quiescence mask of
+ * scores.py:294-303 -- 1 where every column of A and of B holds state `qstate` (0-based; < 0: nothing is quiescent) -- out of
+ * the same pass, which replaces epg_quiescent_from_binhist.  Same results as one call per part, bit for bit; same error codes. */
+int epg_pair_scores_s1_parts(int32_t nparts, const uint16_t* const* HA, const uint16_t* const* HB, const uint16_t* const* HnA,
+                             const uint16_t* const* HnB, const int64_t* R, int32_t S, int32_t NA, int32_t NB, int32_t ga, int32_t gb,
+                             const float* TA, const float* TB, const float* TnA, const float* TnB, float* const* delta, float* const* null_dist,
+                             float* const* dist, int32_t* const* maxdiff, uint8_t* const* mask, int32_t qstate, void* stream);
+
 /* S2: p[i,j] = (h_i*h_j - [i==j]*h_i) / perms, score[b, j] = sum_i kl(p[i,j], q[i,j]) in ascending i
  *     -- scores.py:347-452 s2Score/rowObsS2.  perms = N*(N-1) of the ORIGINAL group (scores.py:371,397-398). */
 int epg_score_s2(const int8_t* X, int64_t R, int32_t N, int64_t ldx, int32_t S, int64_t perms, const float* q,

@@ -399,3 +399,71 @@ def test_paired_s1_in_one_pass_says_when_the_tables_do_not_fit(eng):
     with pytest.raises(eng.EpilogosHipError) as e:
         eng.pair_scores_s1_from_binhist(HA, HB, HnA, HnB, S, NA, NB, NA, NB, tA, tB, tA, tB)
     assert e.value.code == -2
+
+
+@pytest.mark.parametrize("nparts,S_", [(3, 18), (30, 18), (5, 15), (4, 21)])
+def test_paired_s1_several_parts_in_one_launch(eng, nparts, S_):
+    """epg_pair_scores_s1_parts: the fused pass over SEVERAL parts (one per chromosome file in the command line) in one launch,
+    quiescence masks included, against one epg_pair_scores_s1_from_binhist + epg_quiescent_from_binhist call per part -- bit for
+    bit; parts of 1 row, of ragged sizes, an EMPTY part in the middle, more parts than fit one launch (24), a state count with
+    and without a compile-time instantiation; quiescent state off (-1) gives all-zero masks."""
+    from epilogos_amd.scores import s1ScoreTable
+    NA, NB = 37, 29
+    rng = np.random.default_rng(nparts)
+    sizes = [int(v) for v in rng.integers(1, 700, size=nparts)]
+    sizes[1] = 0
+    sizes[-1] = 1
+    R = sum(sizes)
+    xa, xb = synth_states(R, NA, S=S_, seed=1), synth_states(R, NB, S=S_, seed=2)
+    xa[5:9, :] = S_ - 1
+    xb[5:8, :] = S_ - 1                                       # bins 5..7 are quiescent in both groups
+    HA, cA = eng.bin_hist(eng.states_to_device(xa), NA, S_)
+    HB, _ = eng.bin_hist(eng.states_to_device(xb), NB, S_, counts=cA)
+    q = eng.normalise(cA).cpu().numpy()
+    HnA, HnB = eng.null_hist_from_binhist(HA, HB, NA + NB, S_, NA, NB, seed=3)
+    tA, tB = (torch.from_numpy(s1ScoreTable(q, n)[1]).cuda() for n in (NA, NB))
+    # every part in an allocation of its own (16-byte aligned bases), like the session's parts
+    cuts = np.concatenate([[0], np.cumsum(sizes)])
+    quads = [tuple(t[cuts[k]:cuts[k + 1]].clone() for t in (HA, HB, HnA, HnB)) for k in range(nparts)]
+    for qstate in (S_ - 1, -1):
+        res = eng.pair_scores_s1_parts(quads, S_, NA, NB, NA, NB, tA, tB, tA, tB, qstate=qstate)
+        assert len(res) == nparts
+        for k, (a, b, na, nb) in enumerate(quads):
+            r = res[k]
+            if sizes[k] == 0:
+                assert r["delta"].shape == (0, S_) and r["quies"].numel() == 0
+                continue
+            d, n, rd, md = eng.pair_scores_s1_from_binhist(a, b, na, nb, S_, NA, NB, NA, NB, tA, tB, tA, tB)
+            m = eng.quiescent_from_binhist(a, NA, b, NB, S_, qstate)
+            assert torch.equal(r["delta"], d) and torch.equal(r["null"], n) and torch.equal(r["rdist"], rd) and torch.equal(r["mdiff"], md), k
+            assert torch.equal(r["quies"], m), k
+        allq = torch.cat([r["quies"] for r in res])
+        assert int(allq.sum()) == (3 if qstate >= 0 else 0)
+    # without masks
+    res = eng.pair_scores_s1_parts(quads[:1], S_, NA, NB, NA, NB, tA, tB, tA, tB)
+    assert res[0]["quies"] is None
+
+
+@pytest.mark.parametrize("S_,R", [(15, 63), (15, 317), (21, 61), (25, 129), (15, 1)])
+def test_paired_s1_one_pass_with_an_odd_number_of_counts_in_the_last_tile(eng, S_, R):
+    """An odd state count x an odd number of rows in a wave's last tile: the staged histogram rows end on a two-byte tail, which
+    the loader left out until round 4 (the last state's count of the last bin came from stale LDS).  The one-pass kernel against
+    the separate passes, bit for bit."""
+    from epilogos_amd.scores import s1ScoreTable
+    NA, NB = 37, 29
+    xa, xb = synth_states(R, NA, S=S_, seed=1), synth_states(R, NB, S=S_, seed=2)
+    HA, cA = eng.bin_hist(eng.states_to_device(xa), NA, S_)
+    HB, _ = eng.bin_hist(eng.states_to_device(xb), NB, S_, counts=cA)
+    q = eng.normalise(cA).cpu().numpy()
+    HnA, HnB = eng.null_hist_from_binhist(HA, HB, NA + NB, S_, NA, NB, seed=3)
+    tA, tB = (torch.from_numpy(s1ScoreTable(q, n)[1]).cuda() for n in (NA, NB))
+    for rep in range(3):                                      # (stale LDS differs from launch to launch)
+        d, n, rd, md = eng.pair_scores_s1_from_binhist(HA, HB, HnA, HnB, S_, NA, NB, NA, NB, tA, tB, tA, tB)
+        sA, _ = eng.score_s1_from_binhist_table(HA, NA, S_, T32=tA)
+        sB, _ = eng.score_s1_from_binhist_table(HB, NB, S_, T32=tB)
+        nA, _ = eng.score_s1_from_binhist_table(HnA, NA, S_, T32=tA)
+        nB, _ = eng.score_s1_from_binhist_table(HnB, NB, S_, T32=tB)
+        d2, _ = eng.pair_finish(sA, sB, want_dist=False)
+        _, n2 = eng.pair_finish(nA, nB)
+        r2, m2 = eng.pair_metrics(d2, roundtrip=True)
+        assert torch.equal(d, d2) and torch.equal(n, n2) and torch.equal(rd, r2) and torch.equal(md, m2)
