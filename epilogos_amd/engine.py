@@ -403,13 +403,18 @@ def _pinned_bytes(nbytes):
         if _hip_rt is None:
             _hip_rt = False
     if _hip_rt:
+        import weakref
         ptr = C.c_void_p()
         if _hip_rt.hipHostMalloc(C.byref(ptr), C.c_size_t(int(nbytes)), C.c_uint(0)) == 0 and ptr.value:
-            arr = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_int8)), shape=(int(nbytes),))
-            t = torch.from_numpy(arr)
+            # numpy array -> ctypes array (its base) -> the page-locked memory; the memory goes back to the driver when the last
+            # of them -- i.e. the last tensor or view made from it -- is gone (a process that runs several jobs must not keep
+            # 9 GB of page-locked memory per job)
+            base = (C.c_int8 * int(nbytes)).from_address(ptr.value)
+            weakref.finalize(base, _hip_rt.hipHostFree, C.c_void_p(ptr.value))
+            t = torch.from_numpy(np.frombuffer(base, dtype=np.int8))
             if t.is_pinned():
                 return t
-            _hip_rt.hipHostFree(ptr)
+            del t                                        # (the finalizer frees it)
     return torch.empty(int(nbytes), dtype=torch.int8, pin_memory=True)
 
 

@@ -518,3 +518,40 @@ def test_owner_slice_that_starts_mid_file_at_an_odd_row(tmp_path, golden_real, g
     for name in outputs:
         with gzip.open(outs[1] / name, "rb") as fa, gzip.open(outs[2] / name, "rb") as fb:
             assert fa.read() == fb.read(), name
+
+
+def test_paired_driver_15_states_odd_last_tile(tmp_path):
+    """Paired S1 through the driver for a 15-state model whose file ends on an odd number of bins in its last 64-bin tile (two
+    files: 317 and 63 bins): every delta -- the LAST state of the LAST bin included, which the one-pass kernel's loader got from
+    stale LDS until round 4 -- equals the oracle's, and the quiescence mask and STEP 4's side-car are the oracle's."""
+    from epilogos_amd import driver
+    from oracle import oracle_np as onp
+    from tests.conftest import synth_states
+    S_, NA, NB = 15, 9, 7
+    a, b, out = tmp_path / "A", tmp_path / "B", tmp_path / "out"
+    a.mkdir(); b.mkdir(); out.mkdir()
+    xs = {}
+    for name, R, seed in (("m_chr1.txt.gz", 317, 1), ("m_chr2.txt.gz", 63, 2)):
+        xa, xb = synth_states(R, NA, S=S_, seed=seed), synth_states(R, NB, S=S_, seed=seed + 10)
+        xa[3:6, :] = S_ - 1
+        xb[3:5, :] = S_ - 1
+        write_tsv(a / name, xa, chrom=name[2:-7]); write_tsv(b / name, xb, chrom=name[2:-7])
+        xs[name] = (xa, xb)
+    fa, fb = sorted(a.glob("*")), sorted(b.glob("*"))
+    for rep in range(2):                                             # (stale LDS differs from run to run)
+        driver.run_paired_groups(fa, fb, S_, 1, out, "t", S_ - 1, -1, 11)
+        cat = np.concatenate([np.concatenate(xs[n], axis=1) for n in sorted(xs)])
+        q = onp.normalise(onp.expected_s1(cat, S_))
+        assert np.array_equal(np.load(out / "exp_freq_t.npy"), q)
+        for name in sorted(xs):
+            xa, xb = xs[name]
+            want, _ = onp.pair_finish(onp.score_s1(xa, q, S_).astype(np.float32), onp.score_s1(xb, q, S_).astype(np.float32))
+            with gzip.open(out / ("pairwiseDelta_t_%s.txt.gz" % name[:-7]), "rb") as fh:
+                got = _text_to_array(fh.read())
+            np.testing.assert_allclose(got, want, atol=1.01e-5)
+            assert abs(got[-1, -1] - want[-1, -1]) <= 1.01e-5
+            qm = np.load(out / ("temp_quiescence_t_%s.npz" % name[:-7]))["quiescenceArr"]
+            assert np.array_equal(qm, onp.quiescent_mask(xa, xb, S_ - 1)) and qm.sum() == 2
+            side = np.load(out / ("temp_pairMetrics_t_%s.npz" % name[:-7]))
+            rd, rm = onp.pair_metrics(got, roundtrip=False)
+            assert np.array_equal(side["distances"], rd) and np.array_equal(side["maxDiff"], rm)
