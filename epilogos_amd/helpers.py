@@ -6,14 +6,20 @@ import os
 from pathlib import Path
 
 import numpy as np
-import pandas as pd
 
 from . import _io
 
 
 def getNumStates(stateFile):
-    """Number of states = data rows of the state-metadata TSV (reference helpers.py:9-17)."""
-    return pd.read_table(Path(stateFile), header=0, sep="\t").shape[0]
+    """Number of states = data rows of the state-metadata TSV (reference helpers.py:9-17: pandas' read_table with a header
+    row, which skips blank lines -- counted here without importing pandas, a third of a second the command line spends before
+    it has read a byte otherwise)."""
+    with open(Path(stateFile), "r", newline=None) as fh:
+        rows = [l for l in fh.read().splitlines() if l.strip() != ""]
+    if not rows:
+        import pandas as pd
+        return pd.read_table(Path(stateFile), header=0, sep="\t").shape[0]      # (raises pandas' EmptyDataError like the reference)
+    return len(rows) - 1
 
 
 def strToBool(string):
@@ -142,6 +148,7 @@ def flushCacheWrites():
 
 def _read_int8(path, rowsToCalc):
     if rowsToCalc[1] - rowsToCalc[0] <= 0:
+        import pandas as pd
         ncols = pd.read_table(Path(path), nrows=1, header=None, sep="\t").shape[1]
         return np.zeros((0, ncols - 3), dtype=np.int8)
     return readTable(path, rowsToCalc)[0]

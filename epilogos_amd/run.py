@@ -65,6 +65,32 @@ def checkArguments(mode, saliency, inputDirPath, inputDirPath2, outputDirPath, n
         sys.exit()
 
 
+def _init_device_and_group(world, under_launcher):
+    """Import torch, pick this rank's GPU and join the process group (also a group of one: the collective path is the same code).
+    -> torch.device or None."""
+    import torch
+    device = None
+    # EPILOGOS_DIST_BACKEND=gloo lets several ranks share one GPU (testing the multi-rank path on a 1-GPU box)
+    dist_backend = os.environ.get("EPILOGOS_DIST_BACKEND", "")
+    if torch.cuda.is_available():
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+        torch.cuda.set_device(local % torch.cuda.device_count() if dist_backend else local)
+        device = torch.device("cuda", torch.cuda.current_device())
+    if world > 1 or under_launcher:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        backend = dist_backend or ("nccl" if device is not None else "gloo")
+        # a collective whose partner never arrives (a rank that died where the launcher cannot see it) must end the job, not
+        # hold seven GPUs forever; generous, because a rank legitimately waits while the others still parse their files
+        import datetime
+        limit = datetime.timedelta(seconds=int(os.environ.get("EPILOGOS_DIST_TIMEOUT", "1800")))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=device, timeout=limit)
+        else:
+            dist.init_process_group(backend=backend, timeout=limit)
+    return device
+
+
 @click.command(context_settings=dict(help_option_names=["-h", "--help"]))
 @click.option("-m", "--mode", "mode", type=click.Choice(["single", "paired"]), default="single", show_default=True,
               help="single for single group epilogos and paired for 2 group epilogos")
@@ -161,39 +187,44 @@ def main(mode, commandLineBool, inputDirectory, inputDirectory1, inputDirectory2
     # one process per GPU when launched under torch.distributed.run
     world = int(os.environ.get("WORLD_SIZE", "1"))
     under_launcher = "WORLD_SIZE" in os.environ and "RANK" in os.environ
-    import torch
-    device = None
-    # EPILOGOS_DIST_BACKEND=gloo lets several ranks share one GPU (testing the multi-rank path on a 1-GPU box)
-    dist_backend = os.environ.get("EPILOGOS_DIST_BACKEND", "")
-    if torch.cuda.is_available():
-        local = int(os.environ.get("LOCAL_RANK", "0"))
-        torch.cuda.set_device(local % torch.cuda.device_count() if dist_backend else local)
-        device = torch.device("cuda", torch.cuda.current_device())
-    if world > 1 or under_launcher:                      # also a group of one: the collective path is the same code
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        backend = dist_backend or ("nccl" if device is not None else "gloo")
-        # a collective whose partner never arrives (a rank that died where the launcher cannot see it) must end the job, not
-        # hold seven GPUs forever; generous, because a rank legitimately waits while the others still parse their files
-        import datetime
-        limit = datetime.timedelta(seconds=int(os.environ.get("EPILOGOS_DIST_TIMEOUT", "1800")))
-        if backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=device, timeout=limit)
-        else:
-            dist.init_process_group(backend=backend, timeout=limit)
+    files = sorted(inputDirPath.glob("*"), key=_natural_key)
+    files2 = []
+    if mode == "paired":
+        for file in files:
+            if not list(inputDirPath2.glob(file.name)):
+                raise FileNotFoundError("File not found: {}".format(str(inputDirPath2 / file.name))
+                                        + " Please ensure corresponding files within input directories 1 and 2 have the same name")
+            files2.append(next(inputDirPath2.glob(file.name)))
+    from . import driver, _io
+    if world == 1 and not under_launcher and os.environ.get("EPILOGOS_EARLY_READERS", "1") != "0":
+        # A single process: the files' readers start NOW -- inflating needs neither torch nor the GPU, and importing the one and
+        # initialising the other takes about a second, which a whole-genome run spent before its first byte was read.  A reader
+        # asks for its (page-locked) destination only after its inflate; the session is attached when it exists.
+        _io.set_state_limit(numStates)
+        jobs = []
+        for k, f in enumerate(files):
+            jobs += [(f, 0, None)] + ([(files2[k], 0, None)] if mode == "paired" else [])
+        driver.start_readers_early(jobs)
+    try:
+        device = _init_device_and_group(world, under_launcher)
+    except BaseException:
+        driver.abort_early_readers()
+        raise
     rank = int(os.environ.get("RANK", "0"))
     say = print if rank == 0 else (lambda *a, **k: None)
     if os.environ.get("EPILOGOS_TIMING") and rank == 0:
         import time
         print("    [timing] %-34s %7.2f s" % ("imports + device init (since process start)", time.time() - _T_START), flush=True)
 
-    files = sorted(inputDirPath.glob("*"), key=_natural_key)
     say("State Model =", numStates, " Saliency level =", saliency, " GPUs =", world)
     if mode == "single":
         from .driver import run_single_group
         say("\nSTEP 1-3: background counts -> all-reduce -> scores (bin-range partition over %d GPU(s))" % world)
-        _, results = run_single_group(files, numStates, saliency, outputDirPath, fileTag, verbose=False, device=device,
-                                      keep_temp_scores=False)
+        try:
+            _, results = run_single_group(files, numStates, saliency, outputDirPath, fileTag, verbose=False, device=device,
+                                          keep_temp_scores=False)
+        finally:
+            driver.abort_early_readers()                         # (nothing to do once the stage driver has taken them over)
         if rank == 0:
             say("\nSTEP 4: Finding regions of interest", flush=True)
             import time
@@ -204,12 +235,6 @@ def main(mode, commandLineBool, inputDirectory, inputDirectory1, inputDirectory2
                 print("    [timing] %-34s %7.2f s" % ("STEP 4", time.perf_counter() - t0), flush=True)
     else:
         from .driver import run_paired_groups
-        files2 = []
-        for file in files:
-            if not list(inputDirPath2.glob(file.name)):
-                raise FileNotFoundError("File not found: {}".format(str(inputDirPath2 / file.name))
-                                        + " Please ensure corresponding files within input directories 1 and 2 have the same name")
-            files2.append(next(inputDirPath2.glob(file.name)))
         if nullSeed is None:
             import numpy as np
             seed = np.array([int(np.random.SeedSequence().generate_state(1)[0])], dtype=np.int64)
@@ -222,8 +247,11 @@ def main(mode, commandLineBool, inputDirectory, inputDirectory1, inputDirectory2
                 seed = t.cpu().numpy()
             nullSeed = int(seed[0])
         say("\nSTEP 1-3: background counts over [A|B] -> all-reduce -> scores, null groups, deltas (%d GPU(s))" % world)
-        _, results = run_paired_groups(files, files2, numStates, saliency, outputDirPath, fileTag, quiescentState, groupSize,
-                                       nullSeed, verbose=False, device=device, keep_temps=False)
+        try:
+            _, results = run_paired_groups(files, files2, numStates, saliency, outputDirPath, fileTag, quiescentState, groupSize,
+                                           nullSeed, verbose=False, device=device, keep_temps=False)
+        finally:
+            driver.abort_early_readers()
         if rank == 0:
             say("\nSTEP 4: Generating p-values & regions of interest (figures are not produced)", flush=True)
             import time

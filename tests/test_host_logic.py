@@ -531,3 +531,25 @@ def test_visible_gpus_is_counted_without_torch(monkeypatch):
     assert run._visible_gpus() == 1
     code = "import sys; from epilogos_amd import run; run._visible_gpus(); assert 'torch' not in sys.modules"
     assert subprocess.run([sys.executable, "-c", code], env=dict(os.environ, PYTHONPATH=str(ROOT))).returncode == 0
+
+
+def test_early_readers_do_not_outlive_a_failed_start(tmp_path, golden_real, state_info):
+    """The single-process command line starts its file readers before it imports torch (round 4).  When the stage driver never
+    takes them over -- here: no GPU, the product backend raises -- they are aborted: the process ends at once with an error
+    instead of waiting for readers that wait for a session.  (With the oracle stand-in installed the same readers feed the run:
+    test_cli_single_mode and test_cli_paired_mode_to_step4 go through them.)"""
+    import time
+    ind = tmp_path / "in"
+    ind.mkdir()
+    for k in range(3):
+        write_tsv(ind / ("m_chr%d.txt.gz" % (k + 1)), golden_real["x"][k * 300:(k + 1) * 300], chrom="chr%d" % (k + 1))
+    env = dict(os.environ, PYTHONPATH=str(ROOT), HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    t0 = time.time()
+    res = subprocess.run([sys.executable, "-m", "epilogos_amd.run", "-l", "-i", str(ind), "-j", str(state_info), "-o", str(tmp_path / "out")],
+                         env=env, capture_output=True, text=True, timeout=300)
+    assert res.returncode != 0
+    assert "no HIP device" in res.stderr or "EpilogosHipError" in res.stderr or "HIP" in res.stderr, res.stderr[-500:]
+    assert time.time() - t0 < 120
+    assert not list((tmp_path / "out").glob("scores_*"))
