@@ -417,7 +417,9 @@ class _HipPairedSession(_HipSession):
         self.qstate, self.groupSize, self.seed = quiescentState, groupSize, seed
         self._ready = None                               # results of all parts, computed at the first results() call
         if getattr(be, "_null_stream", None) is None:    # one second stream per backend, not per session
-            be._null_stream = self.torch.cuda.Stream(device=self.device)
+            prio = os.environ.get("EPILOGOS_NULL_PRIORITY")
+            be._null_stream = (self.torch.cuda.Stream(device=self.device) if prio is None else
+                               self.torch.cuda.Stream(device=self.device, priority=int(prio)))
         self.null_stream = be._null_stream
 
     def stage(self, arr, N, ticket):

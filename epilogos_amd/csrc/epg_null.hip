@@ -421,7 +421,8 @@ int null_hist_from_binhist_impl(const uint16_t* HA, const uint16_t* HB, int64_t 
         return fail(EPG_ERR_INVALID_ARG, "null_hist_from_binhist: histogram arrays must be 16-byte aligned");
     const int TR = tile_rows(2 * 2 * S);
     long blocks = ((R + TR - 1) / TR + 3) / 4;
-    if (blocks > num_cus() * 8L) blocks = num_cus() * 8L;
+    static const long per_cu = [] { const char* e = getenv("EPG_NULL_BLOCKS_PER_CU"); return e && atoi(e) > 0 ? (long)atoi(e) : 8L; }();   // A/B
+    if (blocks > num_cus() * per_cu) blocks = num_cus() * per_cu;
     // the bit-string kernel while a lane's string fits the wave's share of LDS and the two groups fill the row (the command line
     // without -g); otherwise, and with EPG_NULL_HIST=seq (A/B), the column-by-column kernel -- same draws, same outputs
     const bool full = ga + gb == n_cols;
