@@ -172,3 +172,40 @@ def test_parse_assignment_is_balanced_on_hg19():
         assert load.max() / load.mean() <= (1.15 if world <= 8 else 1.35), (world, load.max() / load.mean())
     assert driver._assign_files([None] * 2, 2, sizes=[100, 1000]) == [0, 1]
     assert driver._assign_files([None] * 3, 3, sizes=[500, 500, 500]) == [0, 1, 2]
+
+
+def test_eight_ranks_twenty_four_files(tmp_path, golden_real):
+    """The shape of the real job -- 24 chromosome files in hg19's proportions over EIGHT ranks (gloo, CPU stand-in backend):
+    every file parsed once, by the rank the size-balanced assignment names, every range border inside a file handed over,
+    outputs byte-identical to the one-rank run, exp_freq identical."""
+    import bench
+    from epilogos_amd import driver
+    x = golden_real["x"]
+    w = np.array(bench.HG19_BP, dtype=np.float64)
+    edges = np.concatenate([[0], np.round(np.cumsum(w) / w.sum() * x.shape[0])]).astype(int)
+    ind = tmp_path / "in"
+    ind.mkdir()
+    names = ["m_chr%02d.txt" % (k + 1) for k in range(24)]
+    for k, name in enumerate(names):
+        write_tsv(ind / name, x[edges[k]:edges[k + 1]], chrom="chr%d" % (k + 1))
+    outs = {}
+    for world in (1, 8):
+        log = tmp_path / ("io%d.log" % world)
+        res, _ = _run(ind, tmp_path / ("out%d" % world), world, {"EPILOGOS_IO_LOG": str(log)}, timeout=900)
+        assert res.returncode == 0, res.stdout + res.stderr
+        outs[world] = tmp_path / ("out%d" % world)
+        lines = [l.split("\t") for l in log.read_text().splitlines()]
+        assert sorted(l[2] for l in lines) == sorted(str(ind / n) for n in names)           # each file once in total
+        if world == 8:
+            by_pid = {}
+            for l in lines:
+                by_pid.setdefault(l[0], []).append(l[2])
+            assert len(by_pid) == 8                                                        # every rank parsed something
+            owner = driver._assign_files([ind / n for n in names], 8)
+            groups = sorted(sorted(str(ind / names[k]) for k in range(24) if owner[k] == g) for g in range(8))
+            assert sorted(sorted(v) for v in by_pid.values()) == groups                    # ... exactly what _assign_files gave it
+    for name in names:
+        stem = name[:-4]
+        assert _decompressed(outs[1] / ("scores_t_s1_%s.txt.gz" % stem)) == _decompressed(outs[8] / ("scores_t_s1_%s.txt.gz" % stem)), stem
+    assert np.array_equal(np.load(outs[1] / "exp_freq_t_s1.npy"), np.load(outs[8] / "exp_freq_t_s1.npy"))
+    assert not list(outs[8].glob(".part_*"))
