@@ -1044,7 +1044,15 @@ int score_s2_from_hist_impl(const uint16_t* H, int64_t R, int32_t N, int32_t S, 
 // "%.5f" then strtod then float32: v * 1e5 is exact in double (24-bit x 17-bit significands), rint is half-even on that
 // exact value like the correctly rounded decimal conversion, and k / 1e5 is the correctly rounded quotient, i.e. the
 // double nearest to the decimal k * 10^-5 that the parser produces.
-__device__ __forceinline__ float text_roundtrip_f5(float v) { return (float)(rint((double)v * 1e5) / 1e5); }
+// Round 4: below 2^17 in magnitude the quotient is taken as k * 1e-5 -- one multiply where the float64 division is ~35 instructions,
+// eighteen times per bin in the one-pass paired kernel.  It is the same float32: with q = k / 10^5 in [2^E, 2^(E+1)), E <= 17, a
+// float32 rounding boundary is m = j 2^(E-24) with j odd, and |q - m| = |k 2^s - j 10^5| / (10^5 2^s), s = 24 - E >= 7; the
+// numerator is an integer and cannot be 0 (2^s would have to divide 10^5 j = 2^5 5^5 j), so q lies >= 2^28 / 10^5 = 2684 float64
+// ulps from every boundary, while k * double(1e-5) is within 1.5 ulps of q -- and so is strtod's correctly rounded value.
+__device__ __forceinline__ float text_roundtrip_f5(float v) {
+    const double k = rint((double)v * 1e5);
+    return fabsf(v) < 131072.0f ? (float)(k * 1e-5) : (float)(k / 1e5);
+}
 
 __global__ __launch_bounds__(256) void k_pair_metrics(const float* __restrict__ delta, long R, int S, int roundtrip,
                                                        float* __restrict__ dist, int* __restrict__ maxdiff, int TR) {
