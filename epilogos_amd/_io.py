@@ -116,12 +116,13 @@ def host_budget():
 
 
 def inflate_mem(blob, own=True, cap=None):
-    """Inflate a gzip stream held in memory with the library's own inflate (own=True) or zlib's; -> bytes, or None when the
-    stream is declined / corrupt.  For tests and the fuzz harness."""
+    """Inflate a gzip stream held in memory with the library's own inflate (own=True), its parallel BGZF reader (own=2: declines
+    whatever is not blocked gzip all the way) or zlib's (own=False); -> bytes, or None when the stream is declined / corrupt.  For
+    tests and the fuzz harness."""
     blob = bytes(blob)
     cap = cap if cap is not None else max(1 << 16, 64 * len(blob))
     out = C.create_string_buffer(cap)
-    n = load().epgio_inflate_mem(blob, len(blob), out, cap, 1 if own else 0)
+    n = load().epgio_inflate_mem(blob, len(blob), out, cap, 2 if own == 2 and own is not True else (1 if own else 0))
     return None if n < 0 else out.raw[:n]
 
 

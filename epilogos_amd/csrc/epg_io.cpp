@@ -96,6 +96,15 @@ int n_threads(int32_t req) {
     return cached;
 }
 
+// readers inside open_table_impl right now, and how many files the caller reads side by side (epgio_set_reader_plan): with
+// threads == 0 ("share") every parallel phase of a file takes the rank's budget divided by the larger of the two -- one thread
+// each while sixteen files inflate side by side, more for the last, largest files once the small ones are done
+std::atomic<int> g_readers{0}, g_reader_plan{0};
+int reader_share() {
+    const int active = std::max(1, std::max(g_readers.load(), g_reader_plan.load()));
+    return std::max(1, n_threads(0) / active);
+}
+
 // The whole (decompressed) file in memory, with 16 readable bytes of slack after the text (the value parser looks a few
 // characters ahead).  Plain files are parsed straight from the mapping of the file -- no copy --, gzip files are inflated
 // from the mapped compressed bytes with the zlib inflate API into ONE malloc'd buffer whose size comes from the gzip trailer
@@ -242,7 +251,7 @@ bool inflate_own(const unsigned char* in, size_t flen, size_t cap_hint, Text& t,
         for (size_t o = members[k].out0; o < members[k].out1; o += PIECE) pieces.push_back(Piece{o, std::min(PIECE, members[k].out1 - o), 0});
     }
     first[members.size()] = pieces.size();
-    const int T = (int)std::max<size_t>(1, std::min<size_t>((size_t)n_threads(threads), pieces.size()));
+    const int T = (int)std::max<size_t>(1, std::min<size_t>((size_t)(threads > 0 ? threads : reader_share()), pieces.size()));
     Uncount uncount_;
     std::vector<std::thread> th;
     for (int w = 0; w < T; ++w)
@@ -260,6 +269,97 @@ bool inflate_own(const unsigned char* in, size_t flen, size_t cap_hint, Text& t,
     memset(t.heap + out.pos, 0, 16);
     t.data = t.heap;
     t.size = out.pos;
+    return true;
+}
+
+// BGZF -- the blocked gzip of htslib (bgzip, tabix): every member is at most 64 KiB and carries its own compressed size in an extra
+// subfield ('B', 'C'), so the members' boundaries -- and, from their trailers, their places in the output -- are known without
+// decoding anything, and the members of ONE file inflate in parallel.  (A plain gzip file is one serial stream: the largest file
+// of a genome is then the critical path of a cold run, 3 s of inflate on one core)
+struct BgzfBlock { size_t in_off; uint32_t in_len, isize, crc; size_t out_off; };
+
+bool bgzf_header(const unsigned char* h, size_t avail, size_t* hdr_len, size_t* total) {
+    if (avail < 18 + 8 || h[0] != 0x1f || h[1] != 0x8b || h[2] != 8 || h[3] != 4) return false;   // FEXTRA and nothing else
+    const size_t xlen = (size_t)h[10] | ((size_t)h[11] << 8);
+    if (12 + xlen + 8 > avail) return false;
+    size_t bsize = 0;
+    for (size_t x = 12; x + 4 <= 12 + xlen;) {
+        const size_t slen = (size_t)h[x + 2] | ((size_t)h[x + 3] << 8);
+        if (x + 4 + slen > 12 + xlen) return false;
+        if (h[x] == 'B' && h[x + 1] == 'C' && slen == 2) bsize = ((size_t)h[x + 4] | ((size_t)h[x + 5] << 8)) + 1;
+        x += 4 + slen;
+    }
+    if (bsize < 12 + xlen + 8 || bsize > avail) return false;
+    *hdr_len = 12 + xlen;
+    *total = bsize;
+    return true;
+}
+
+bool bgzf_index(const unsigned char* in, size_t flen, std::vector<BgzfBlock>& blocks, size_t* out_total) {
+    size_t pos = 0, out = 0;
+    while (pos < flen) {
+        size_t hl = 0, total = 0;
+        if (!bgzf_header(in + pos, flen - pos, &hl, &total)) return false;      // not BGZF all the way: the general reader takes it
+        const unsigned char* tr = in + pos + total - 8;
+        BgzfBlock b;
+        b.in_off = pos + hl;
+        b.in_len = (uint32_t)(total - hl - 8);
+        b.crc = (uint32_t)tr[0] | (uint32_t)tr[1] << 8 | (uint32_t)tr[2] << 16 | (uint32_t)tr[3] << 24;
+        b.isize = (uint32_t)tr[4] | (uint32_t)tr[5] << 8 | (uint32_t)tr[6] << 16 | (uint32_t)tr[7] << 24;
+        if (b.isize > 65536) return false;
+        b.out_off = out;
+        out += b.isize;
+        blocks.push_back(b);
+        pos += total;
+    }
+    *out_total = out;
+    return !blocks.empty();
+}
+
+// false = not BGZF, or a member is not what its header and trailer say: the general reader (and then zlib) judges the file.
+bool inflate_bgzf(const unsigned char* in, size_t flen, Text& t, int32_t threads) {
+    size_t hl = 0, tot = 0;
+    if (!bgzf_header(in, flen, &hl, &tot)) return false;
+    std::vector<BgzfBlock> blocks;
+    size_t total = 0;
+    if (!bgzf_index(in, flen, blocks, &total)) return false;
+    t.heap = big_alloc(total + 16, &t.heap_cap);
+    if (!t.heap) return false;
+    std::atomic<size_t> next{0};
+    std::atomic<int> bad{0};
+    const size_t ROUND = 1024;                                    // blocks per round (<= 64 MiB of text): the thread count is
+    while (next.load() < blocks.size() && !bad.load()) {          // taken anew every round -- cores that other files' readers
+        const size_t r0 = next.load(), r1 = std::min(blocks.size(), r0 + ROUND);   // give back join in
+        const int T = (int)std::max<size_t>(1, std::min<size_t>((size_t)(threads > 0 ? threads : reader_share()), (r1 - r0 + 15) / 16));
+        std::atomic<size_t> cur{r0};
+        auto work = [&] {
+            std::vector<unsigned char> scratch(65536 + 512);      // a symbol's writes may run past the block's end: not into a neighbour
+            for (;;) {
+                const size_t k0 = cur.fetch_add(16);
+                if (k0 >= r1 || bad.load()) return;
+                for (size_t k = k0; k < std::min(r1, k0 + 16); ++k) {
+                    const BgzfBlock& b = blocks[k];
+                    epginflate::Out o{scratch.data(), 0, 65536};
+                    auto no_grow = [](size_t) { return false; };
+                    const size_t used = epginflate::inflate_raw(in + b.in_off, b.in_len, o, no_grow);
+                    if (used != b.in_len || o.pos != b.isize || epgcrc::crc32_fast(0, scratch.data(), b.isize) != b.crc) { bad.store(1); return; }
+                    memcpy(t.heap + b.out_off, scratch.data(), b.isize);
+                }
+            }
+        };
+        if (T == 1) work();
+        else {
+            Uncount uncount_;
+            std::vector<std::thread> th;
+            for (int w = 0; w < T; ++w) th.emplace_back([&] { Census census_; work(); });
+            join_all(th);
+        }
+        next.store(r1);
+    }
+    if (bad.load()) return false;
+    memset(t.heap + total, 0, 16);
+    t.data = t.heap;
+    t.size = total;
     return true;
 }
 
@@ -338,6 +438,10 @@ bool slurp(const char* path, Text& t, int32_t threads = 0) {
     // any doubt the file is read again with zlib below.  EPGIO_INFLATE=zlib skips it.
     {
         static const bool use_own = [] { const char* e = getenv("EPGIO_INFLATE"); return !(e && e[0] == 'z'); }();
+        if (use_own && inflate_bgzf(in, flen, t, threads)) return true;      // blocked gzip: the members in parallel
+        big_free(t.heap, t.heap_cap);
+        t.heap = nullptr;
+        t.heap_cap = 0;
         if (use_own && inflate_own(in, flen, cap, t, threads)) return true;
         big_free(t.heap, t.heap_cap);
         t.heap = nullptr;
@@ -494,7 +598,7 @@ int64_t epgio_inflate_mem(const void* in, int64_t n, void* out, int64_t cap, int
     size_t hint = (size_t)((uint32_t)p[n - 4] | (uint32_t)p[n - 3] << 8 | (uint32_t)p[n - 2] << 16 | (uint32_t)p[n - 1] << 24);
     if (hint < (size_t)n || hint > ((size_t)1 << 28)) hint = (size_t)n * 4;
     hint += 64;
-    const bool ok = own ? inflate_own(p, (size_t)n, hint, t, 1) : inflate_zlib(p, (size_t)n, hint, t, "memory");
+    const bool ok = own == 2 ? inflate_bgzf(p, (size_t)n, t, 2) : own ? inflate_own(p, (size_t)n, hint, t, 1) : inflate_zlib(p, (size_t)n, hint, t, "memory");
     if (!ok) return own ? fail("inflate_mem: the library's inflate declined the stream") : -1;
     if ((int64_t)t.size > cap) return fail("inflate_mem: output %lld > cap %lld", (long long)t.size, (long long)cap);
     if (t.size) memcpy(out, t.data, t.size);
@@ -514,19 +618,10 @@ epgio_table* epgio_open_table_into(const char* path, int64_t row_lo, int64_t row
     return open_table_impl(path, row_lo, row_hi, threads, max_state, alloc, user);
 }
 
-// readers inside open_table_impl right now: with threads == 0 ("share") every parallel phase of a file takes the rank's budget
-// divided by the files being read at that moment -- one thread each while sixteen files inflate side by side, more for the
-// last, largest files once the small ones are done
-static std::atomic<int> g_readers{0}, g_reader_plan{0};
-static int reader_share() {                       // threads of one file's parallel phase under threads == 0
-    const int active = std::max(1, std::max(g_readers.load(), g_reader_plan.load()));
-    return std::max(1, n_threads(0) / active);
-}
 extern "C" void epgio_set_reader_plan(int32_t n) { g_reader_plan.store(n > 0 ? n : 0); }
 
-// The kept text buffers go back to the kernel -- on a thread of its own when `background` (the driver calls this when its last
-// file has been parsed: unmapping tens of gigabytes takes seconds, which then pass under the score pass and the writers instead
-// of at process exit).
+// The kept text buffers (their pages are released after every file already) go back to the kernel -- on a thread of its own
+// when `background`.  For a process that is done reading and goes on living.
 extern "C" void epgio_release_buffers(int32_t background) {
     std::vector<std::pair<char*, size_t>> bufs;
     {
@@ -560,7 +655,7 @@ static epgio_table* open_table_impl(const char* path, int64_t row_lo, int64_t ro
         }
     };
     Text buf;
-    if (!slurp(path, buf, threads > 0 ? threads : reader_share())) return nullptr;
+    if (!slurp(path, buf, threads)) return nullptr;
     lap("read / inflate");
     const char* base = buf.data;
     const char* end = base + buf.size;
@@ -857,8 +952,45 @@ inline char* fmt_f5(float f, char* o) {
     return o + 5;
 }
 
+// EPILOGOS_BGZF=1: the writers emit BGZF (blocks of <= 65 280 bytes of text, each a gzip member with its compressed size in a 'BC'
+// extra subfield, an empty block as end marker) -- the same decompressed bytes, readable by gzip and zlib like any multi-member
+// file, and by bgzip / tabix with random access; this library's reader inflates such a file's blocks in parallel.
+bool bgzf_on() { const char* e = getenv("EPILOGOS_BGZF"); return e && e[0] && e[0] != '0'; }
+const unsigned char BGZF_EOF[28] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+
+bool bgzf_blocks(const char* in, size_t n, int level, std::vector<unsigned char>& out) {
+    z_stream zs;
+    memset(&zs, 0, sizeof(zs));
+    if (deflateInit2(&zs, level >= 1 ? level : 1, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) return false;
+    out.clear();
+    out.reserve(n / 3 + 64);
+    unsigned char blk[65536 + 64];
+    bool ok = true;
+    for (size_t off = 0; off < n && ok; off += 65280) {
+        const size_t len = std::min<size_t>(65280, n - off);
+        deflateReset(&zs);
+        zs.next_in = (Bytef*)(in + off);
+        zs.avail_in = (uInt)len;
+        zs.next_out = blk + 18;
+        zs.avail_out = 65536 - 18 - 8;
+        if (deflate(&zs, Z_FINISH) != Z_STREAM_END) { ok = false; break; }
+        const size_t total = 18 + (size_t)zs.total_out + 8;
+        static const unsigned char hdr[16] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0};
+        memcpy(blk, hdr, 16);
+        blk[16] = (unsigned char)((total - 1) & 0xff);
+        blk[17] = (unsigned char)((total - 1) >> 8);
+        const uint32_t crc = epgcrc::crc32_fast(0, (const unsigned char*)in + off, len), isize = (uint32_t)len;
+        memcpy(blk + total - 8, &crc, 4);
+        memcpy(blk + total - 4, &isize, 4);
+        out.insert(out.end(), blk, blk + total);
+    }
+    deflateEnd(&zs);
+    return ok;
+}
+
 // level 1..9: zlib; level 0: the writer's own fast compressor (epg_deflate.h)
 bool gzip_member(const std::vector<char>& in, int level, std::vector<unsigned char>& out) {
+    if (bgzf_on()) return bgzf_blocks(in.data(), in.size(), level, out);
     if (level == 0) {
         epgdeflate::gzip_member_fast(reinterpret_cast<const unsigned char*>(in.data()), in.size(), out);
         return true;
@@ -1053,6 +1185,7 @@ int epgio_write_scores(const char* path, const char* loc, const int64_t* loc_off
             if (!good[k] || fwrite(z[k].data(), 1, z[k].size(), f) != z[k].size()) ok = false;
         }
     }
+    if (ok && bgzf_on() && ends_with_gz(path) && fwrite(BGZF_EOF, 1, sizeof(BGZF_EOF), f) != sizeof(BGZF_EOF)) ok = false;
     if (fclose(f) != 0) ok = false;
     return ok ? 0 : fail("write error on %s", path);
 }
@@ -1115,6 +1248,7 @@ int epgio_write_states(const char* path, const char* chrom, int64_t start0, int6
             if (fwrite(p, 1, n, f) != n) ok = false;
         }
     }
+    if (ok && bgzf_on() && ends_with_gz(path) && fwrite(BGZF_EOF, 1, sizeof(BGZF_EOF), f) != sizeof(BGZF_EOF)) ok = false;
     if (fclose(f) != 0) ok = false;
     return ok ? 0 : fail("write error on %s", path);
 }
@@ -1176,6 +1310,7 @@ int epgio_write_metrics(const char* path, const char* chrom, const int64_t* chro
             if (!good[k] || fwrite(z[k].data(), 1, z[k].size(), f) != z[k].size()) ok = false;
         }
     }
+    if (ok && bgzf_on() && ends_with_gz(path) && fwrite(BGZF_EOF, 1, sizeof(BGZF_EOF), f) != sizeof(BGZF_EOF)) ok = false;
     if (fclose(f) != 0) ok = false;
     return ok ? 0 : fail("write error on %s", path);
 }

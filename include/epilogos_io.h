@@ -108,7 +108,15 @@ int epgio_rolling_max_f64(const double* x, int64_t n, int32_t W, double* out, in
  * Replaces Python's gzip.open(..., "wt") of scores.py:523 (zlib level 9).  Exposed for tests. */
 int64_t epgio_gzip_fast(const void* in, int64_t n, void* out, int64_t cap);
 
-/* The gzip reader on a buffer in memory: own != 0 the library's inflate (csrc/epg_inflate.h: every member's CRC-32 and ISIZE
+/* Blocked gzip.  A BGZF file (htslib's bgzip / tabix: members of at most 64 KiB, each with its compressed size in a 'B','C' extra
+ * subfield) is recognised by every reader above and its blocks are inflated IN PARALLEL -- a plain gzip file is one serial stream
+ * per file; with threads == 0 the thread count is taken anew every 1024 blocks, so cores that other files' readers give back join
+ * in.  Every block's CRC-32 and ISIZE are checked; a file that is not BGZF all the way, or a block that is not what its header
+ * and trailer say, goes to the general reader and then to zlib, whose verdict stands.  With the environment variable
+ * EPILOGOS_BGZF=1 every writer below emits BGZF (same decompressed bytes; gzip, zlib and this library read it like any
+ * multi-member file, tabix-style tools with random access). */
+
+/* The gzip reader on a buffer in memory: own == 2 the parallel BGZF reader (declines anything else), other own != 0 the library's inflate (csrc/epg_inflate.h: every member's CRC-32 and ISIZE
  * checked), own == 0 zlib's; returns the inflated size (copied to out, cap bytes) or < 0 -- the stream was declined / is
  * corrupt / does not fit.  Exposed for the differential fuzz (tools/asan_io.sh, tests/test_native_io.py). */
 int64_t epgio_inflate_mem(const void* in, int64_t n, void* out, int64_t cap, int32_t own);

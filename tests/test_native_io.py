@@ -453,3 +453,64 @@ def test_sanitizer_recipe_quick(tmp_path):
     if res.returncode == 77:
         pytest.skip("no libasan for g++ here")
     assert res.returncode == 0 and "asan_io: clean" in res.stdout, (res.stdout + res.stderr)[-4000:]
+
+
+def test_bgzf_blocks_are_read_in_parallel_and_written_on_request(tmp_path, monkeypatch):
+    """BGZF (htslib's blocked gzip: members of <= 64 KiB carrying their compressed size in a 'BC' extra subfield).  Reader: such a
+    file's blocks are inflated in parallel (epg_io.cpp inflate_bgzf) -- same states and coordinates as the plain-gzip file, for
+    any thread count, with or without the end marker; a block that is not what its header says sends the file to the general
+    reader and zlib, with their verdict.  Writer: EPILOGOS_BGZF=1 makes every writer emit BGZF -- the same decompressed bytes,
+    'BC' subfield, <= 64 KiB blocks, the 28-byte end marker."""
+    import zlib
+    sys_path = __import__("sys").path
+    sys_path.insert(0, str(__import__("tests.conftest").conftest.ROOT / "tools"))
+    from fuzz_inflate import BGZF_EOF, bgzf
+    x, text = _table_text(R=900, N=61)
+    plain = tmp_path / "p_chr1.txt.gz"
+    plain.write_bytes(gzip.compress(text, 6))
+    want_s, want_l = _io.read_table(plain)
+    for k, blob in enumerate((bgzf(text, 6, 60000), bgzf(text, 1, 3000, eof=False), bgzf(text, 0, 65280), bgzf(text[:0]))):
+        f = tmp_path / ("b%d_chr1.txt.gz" % k)
+        f.write_bytes(blob)
+        if k < 3:
+            assert _io.inflate_mem(blob, own=2, cap=1 << 24) == text
+            for threads in (0, 1, 3):
+                s, l = _io.read_table(f, threads=threads)
+                assert np.array_equal(s, want_s) and np.array_equal(l.blob, want_l.blob) and np.array_equal(l.offsets, want_l.offsets)
+        else:
+            s, l = _io.read_table(f)
+            assert s.shape[0] == 0 and len(l) == 0
+    # a block whose trailer lies about its size / whose payload is damaged: not accepted by the block reader, judged like zlib does
+    good = bgzf(text, 6, 5000)
+    for pos in (len(good) // 2, 30, len(good) - 40):
+        bad = bytearray(good)
+        bad[pos] ^= 0x20
+        bad = bytes(bad)
+        mine, theirs = _io.inflate_mem(bad, own=2, cap=1 << 24), _io.inflate_mem(bad, own=False, cap=1 << 24)
+        assert mine is None or mine == theirs
+        (tmp_path / "bad_chr1.txt.gz").write_bytes(bad)
+        if theirs is None:
+            with pytest.raises(_io.EpilogosIOError):
+                _io.read_table(tmp_path / "bad_chr1.txt.gz")
+    assert _io.inflate_mem(plain.read_bytes(), own=2) is None          # plain gzip is not blocked gzip
+    # the writers
+    monkeypatch.setenv("EPILOGOS_BGZF", "1")
+    st = (x - 1).astype(np.int8)
+    _io.write_states(tmp_path / "w_chr1.txt.gz", "chr1", st, gzip_level=1)
+    sc = np.random.default_rng(1).standard_normal((900, 18)).astype(np.float32)
+    _io.write_scores(tmp_path / "w_scores.txt.gz", want_l, sc)
+    monkeypatch.delenv("EPILOGOS_BGZF")
+    _io.write_states(tmp_path / "v_chr1.txt.gz", "chr1", st, gzip_level=1)
+    _io.write_scores(tmp_path / "v_scores.txt.gz", want_l, sc)
+    for name in ("chr1", "scores"):
+        b = (tmp_path / ("w_%s.txt.gz" % name)).read_bytes()
+        assert b[:4] == b"\x1f\x8b\x08\x04" and b[12:16] == b"BC\x02\x00" and b.endswith(BGZF_EOF)
+        assert gzip.decompress(b) == gzip.decompress((tmp_path / ("v_%s.txt.gz" % name)).read_bytes())
+        pos = 0
+        while pos < len(b):                                            # every block says how long it is, and is <= 64 KiB
+            size = int.from_bytes(b[pos + 16:pos + 18], "little") + 1
+            assert b[pos:pos + 4] == b"\x1f\x8b\x08\x04" and size <= 65536
+            pos += size
+        assert pos == len(b)
+    s, _l = _io.read_table(tmp_path / "w_chr1.txt.gz")
+    assert np.array_equal(s, st)

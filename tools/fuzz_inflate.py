@@ -34,6 +34,22 @@ def member(data, level=6, strategy=zlib.Z_DEFAULT_STRATEGY, wbits=-15, memlevel=
             + (len(data) & 0xffffffff).to_bytes(4, "little"))
 
 
+BGZF_EOF = bytes([0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 66, 67, 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0])
+
+
+def bgzf(data, level=6, block=60000, eof=True):
+    """The blocked gzip of htslib: members of <= 64 KiB with their compressed size in a 'BC' extra subfield."""
+    out = b""
+    for o in range(0, len(data), block):
+        ch = data[o:o + block]
+        c = zlib.compressobj(level, zlib.DEFLATED, -15)
+        raw = c.compress(ch) + c.flush()
+        tot = 18 + len(raw) + 8
+        out += (bytes([0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 66, 67, 2, 0, (tot - 1) & 255, (tot - 1) >> 8]) + raw
+                + (zlib.crc32(ch) & 0xffffffff).to_bytes(4, "little") + len(ch).to_bytes(4, "little"))
+    return out + (BGZF_EOF if eof else b"")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--streams", type=int, default=100000)
@@ -53,11 +69,16 @@ def main():
             raw = c.compress(t) + c.flush(zlib.Z_SYNC_FLUSH) + c.compress(b"x" * pad) + c.flush(zlib.Z_SYNC_FLUSH) + c.flush()
             w = t + b"x" * pad
             seeds.append(b"\x1f\x8b\x08\0\0\0\0\0\0\xff" + raw + (zlib.crc32(w) & 0xffffffff).to_bytes(4, "little") + len(w).to_bytes(4, "little"))
+    n_plain = len(seeds)
+    for t in texts[:3]:                                # BGZF: read by the parallel block reader (own=2) as well
+        seeds += [bgzf(t, 6, 700), bgzf(t, 1, 2000, eof=False), bgzf(t, 0, 512)]
+    for k, s in enumerate(seeds[n_plain:]):
+        assert _io.inflate_mem(s, own=2) == _io.inflate_mem(s, own=False) is not None, "BGZF seed %d" % k
     for k, s in enumerate(seeds):                      # the unmutated seeds must be accepted by both, identically
         a, b = _io.inflate_mem(s, own=True), _io.inflate_mem(s, own=False)
         assert a is not None and a == b, "seed %d: own %s zlib %s" % (k, a is None, b is None)
     t0 = time.time()
-    accepted = declined_both = own_declined_only = 0
+    accepted = declined_both = own_declined_only = bgzf_accepted = 0
     for i in range(args.streams):
         b = bytearray(seeds[int(rng.integers(0, len(seeds)))])
         kind = int(rng.integers(0, 8))
@@ -86,6 +107,15 @@ def main():
         if len(b) < 18:
             b = b + b"\0" * (18 - len(b))
         b = bytes(b)
+        blocked = _io.inflate_mem(b, own=2, cap=1 << 20)       # the BGZF reader: whatever it accepts, zlib must read the same
+        if blocked is not None:
+            theirs = _io.inflate_mem(b, own=False, cap=1 << 20)
+            if theirs is None or theirs != blocked:
+                Path("fuzz_counterexample.gz").write_bytes(b)
+                print("MISMATCH at stream %d (kind %d): the BGZF reader accepted %d bytes, zlib %s -> fuzz_counterexample.gz"
+                      % (i, kind, len(blocked), "declined" if theirs is None else "%d other bytes" % len(theirs)))
+                return 1
+            bgzf_accepted += 1
         mine = _io.inflate_mem(b, own=True, cap=1 << 20)
         if mine is None:
             theirs = _io.inflate_mem(b, own=False, cap=1 << 20)
@@ -100,7 +130,7 @@ def main():
             return 1
         accepted += 1
     print("fuzz_inflate: %d streams in %.1f s: %d accepted by both with equal bytes, %d declined by both, %d declined by the own "
-          "inflate only (zlib reads those); no mismatch" % (args.streams, time.time() - t0, accepted, declined_both, own_declined_only))
+          "inflate only (zlib reads those), %d accepted by the BGZF block reader; no mismatch" % (args.streams, time.time() - t0, accepted, declined_both, own_declined_only, bgzf_accepted))
     return 0
 
 

@@ -38,6 +38,7 @@ ap.add_argument("--also", default="", help="comma list of further saliencies to 
 ap.add_argument("--paired", action="store_true", help="also write the 379 + 342 column split as two groups and run -m paired (S1)")
 ap.add_argument("--ranks", type=int, default=0, help="also: a cold run WITHOUT the cache on this many ranks (`--gpus N`, gloo transport, the "
                                                    "ranks share the GPU) next to a cold one-rank run without the cache; thread census per rank")
+ap.add_argument("--bgzf", action="store_true", help="write the inputs as BGZF (blocked gzip): the reader inflates one file's blocks in parallel")
 ap.add_argument("--only-ranks", action="store_true", help="stop after the --ranks comparison")
 ap.add_argument("--timeline", action="store_true", help="per-part reader timeline and per-file reader phases of the cold runs (stderr of the CLI)")
 ap.add_argument("--pvals", action="store_true", help="with --paired: one more warm run with -n (null-distribution fit, p-values, BH)")
@@ -53,6 +54,8 @@ if a.paired:
 meta = base / "metadata.tsv"
 meta.write_text("zero_index\tone_index\tshort_name\n" + "".join("%d\t%d\tS%d\n" % (i, i + 1, i + 1) for i in range(S)))
 
+if a.bgzf:
+    os.environ["EPILOGOS_BGZF"] = "1"            # for the input writer below only
 # ---- inputs: states drawn on the GPU (bench.generate_shard: chr1 frequencies, fixed global chunk seeds), text by the native writer
 import torch  # noqa: E402
 import bench  # noqa: E402
@@ -74,6 +77,7 @@ for name, bp in HG19:
     rows[name] = R
     bin0 += R
     text_bytes += path.stat().st_size
+os.environ.pop("EPILOGOS_BGZF", None)
 total = bin0
 print("inputs: %d files, %d bins x %d biosamples, %.2f GB of .txt.gz written in %.1f s" % (len(HG19), total, N, text_bytes / 1e9, time.time() - t0), flush=True)
 torch.cuda.empty_cache()
