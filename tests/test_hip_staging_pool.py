@@ -57,10 +57,14 @@ def test_pool_serves_the_largest_waiting_file_first(eng):
         time.sleep(0.05)
         pool.release(buf)
     threads = [threading.Thread(target=want, args=(t,)) for t in (2, 1)]
-    threads[0].start()
-    time.sleep(0.2)                                                 # ticket 2 (100 bytes of input) waits first ...
-    threads[1].start()
-    time.sleep(0.2)                                                 # ... ticket 1 (1000 bytes) joins the queue
+    threads[0].start()                                              # ticket 2 (100 bytes of input) waits first ...
+    deadline = time.time() + 20
+    while 2 not in pool.waiting and time.time() < deadline:
+        time.sleep(0.01)
+    threads[1].start()                                              # ... ticket 1 (1000 bytes) joins the queue
+    while pool.waiting != {1, 2} and time.time() < deadline:
+        time.sleep(0.01)
+    assert pool.waiting == {1, 2}
     pool.release(first)
     for th in threads:
         th.join(timeout=10)
