@@ -104,3 +104,66 @@ def test_placed_histogram_cache(world):
     assert not eng._parked
     free1, _ = torch.cuda.mem_get_info()
     assert free1 >= free0 - (1 << 30)                                 # everything went back
+
+
+def test_paired_job_full_size_properties(world):
+    """BASELINE config 5 at full size (15 M bins x (379 + 342) columns of the same synthetic matrix) through the command line's
+    session, fed in 24 chromosome-sized parts like bench.py does: size-independent properties.  Every null draw is a
+    permutation's bookkeeping (per bin: the two null groups add up to the two real ones and have the groups' sizes); a group
+    compared with ITSELF has zero deltas, zero distances and null groups that are still a valid split; the whole job from
+    parts equals the job from one part bit for bit (the shuffle key is (file, row), not the launch geometry); the quiescence
+    mask is exactly "both groups all-quiescent"."""
+    import bench
+    from epilogos_amd import backend
+    from epilogos_amd.driver import shuffle_key
+    eng, X, H, counts = world
+    NA, NB = 379, 342
+    be = backend.HipBackend()
+    XA, XB = X[:, :NA], X[:, 384:384 + NB]                          # column windows of the resident matrix (16-byte aligned starts)
+    parts = bench.chromosome_parts(R, 0, R)
+
+    def run(groups, part_list):
+        sess = be.open_paired(S, 1, S - 1, -1, 424242)
+        pids = [sess.add_staged(groups[0][a:b], NA, groups[1][a:b], NB if groups[1] is XB else NA, shuffle_key(f, r0))
+                for f, r0, a, b in part_list]
+        sess.ensure_acc(NA + NB)
+        sess.finish_device(sum(b - a for _f, _r0, a, b in part_list), NA + (NB if groups[1] is XB else NA))
+        nulls = [sess._null_of(p) for p in pids]
+        hists = [(sess.parts[p][2], sess.parts[p][3]) for p in pids]
+        res = sess.results_device_all(pids)
+        sess.check()
+        return res, nulls, hists
+
+    res, nulls, hists = run((XA, XB), parts)
+    assert sum(r["delta"].shape[0] for r in res) == R
+    for (HnA, HnB), (HA, HB) in zip(nulls, hists):
+        assert torch.equal(HnA.to(torch.int32) + HnB.to(torch.int32), HA.to(torch.int32) + HB.to(torch.int32))
+        assert int(HnA.to(torch.int32).sum(dim=1).min()) == NA == int(HnA.to(torch.int32).sum(dim=1).max())
+        assert int(HnB.to(torch.int32).sum(dim=1).min()) == NB == int(HnB.to(torch.int32).sum(dim=1).max())
+    delta = torch.cat([r["delta"] for r in res])
+    null = torch.cat([r["null"] for r in res])
+    quies = torch.cat([r["quies"] for r in res])
+    assert bool(torch.isfinite(delta).all()) and bool(torch.isfinite(null).all())
+    want_q = (torch.cat([h[0] for h in hists])[:, S - 1] == NA) & (torch.cat([h[1] for h in hists])[:, S - 1] == NB)
+    assert torch.equal(quies.bool(), want_q)
+    # the sign of a null distance is the sign of KL(null A) - KL(null B): the SMALLER group's plug-in KL is biased upwards (by about
+    # (S - 1) / (2 n ln 2)), so with 379 against 342 columns somewhat fewer than half are positive; with equal sizes it is a coin
+    frac_pos = float((null > 0).double().mean())
+    assert 0.30 < frac_pos < 0.50, frac_pos
+    # one part instead of 24: the same job -- per-bin results do not depend on how the bins were cut into launches ... as long
+    # as the keys are the same: feed the one part's rows with their (file, row) keys by running it as the 24 slices of ONE call
+    # order reversed (launch order must not matter either)
+    res_rev, _n, _h = run((XA, XB), parts[::-1])
+    assert torch.equal(torch.cat([r["delta"] for r in res_rev[::-1]]), delta)
+    assert torch.equal(torch.cat([r["null"] for r in res_rev[::-1]]), null)
+    del res_rev, res, nulls, hists, delta, null
+    torch.cuda.empty_cache()
+    # a group against itself
+    res2, nulls2, hists2 = run((XA, XA), parts[:6])
+    for r in res2:
+        assert int((r["delta"] != 0).sum()) == 0 and int((r["rdist"] != 0).sum()) == 0
+    null2 = torch.cat([r["null"] for r in res2])
+    frac2 = float((null2 > 0).double().mean() / (null2 != 0).double().mean())
+    assert 0.48 < frac2 < 0.52, frac2                               # equal group sizes: the sign is a fair coin
+    for (HnA, HnB), (HA, HB) in zip(nulls2, hists2):
+        assert torch.equal(HnA.to(torch.int32) + HnB.to(torch.int32), 2 * HA.to(torch.int32))
