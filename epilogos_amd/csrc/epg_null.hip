@@ -410,6 +410,151 @@ __global__ __launch_bounds__(256) void k_null_hist_h(const u16* __restrict__ HA,
     }
 }
 
+// The same kernel for group sizes that do NOT fill the row (-g: ga + gb < n): a column joins A, B or neither, so there are two
+// thresholds ((need_A << 16) - 1 and ((need_A + need_B) << 16) - 1), two outcome bits per position and two bit strings; a draw is
+// 13 instructions on the speculative path (twice `v_mad_i32_i24` x, `v_cmp_le_i32`, `v_cndmask`, `v_mad_i32_i24` need; one `v_sub`
+// for "B = joined but not A"; two `v_lshl_or`; a share of `v_min3_u32`), a tie at either threshold sends the lane's call through
+// the careful path.  Same draws and tie rule as k_null_hist_h_seq: identical outputs.  Round 3 had tried this shape with byte-sized
+// draws and found it 5 % slower than the column-by-column kernel; with 16-bit draws: 4.7 -> 3.2 ms per 15 M bins (-g 100).
+__global__ __launch_bounds__(256) void k_null_hist_h2(const u16* __restrict__ HA, const u16* __restrict__ HB, long R, int S, int n_cols,
+                                                       int ga, int gb, u64 seed, long row0, u16* __restrict__ OA, u16* __restrict__ OB, int TR,
+                                                       int NW) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int rowb = 2 * S;
+    const size_t per_wave = (size_t)2 * TR * rowb + (size_t)2 * NW * 256;
+    char* sa = smem + (size_t)wave * per_wave;
+    char* sb = sa + TR * rowb;
+    u32* bitsA = reinterpret_cast<u32*>(sb + TR * rowb) + lane;   // [word][lane]
+    u32* bitsB = bitsA + NW * 64;
+    const long ntiles = (R + TR - 1) / TR;
+    for (long tile = (long)blockIdx.x * 4 + wave; tile < ntiles; tile += (long)gridDim.x * 4) {
+        const long r0 = tile * TR;
+        const int rows = (int)(R - r0 < TR ? R - r0 : TR);
+        nh_stage_in(sa, reinterpret_cast<const char*>(HA + r0 * S), rows * rowb, lane);
+        nh_stage_in(sb, reinterpret_cast<const char*>(HB + r0 * S), rows * rowb, lane);
+        __builtin_amdgcn_wave_barrier();
+        if (lane < rows) {
+            u16* pa = reinterpret_cast<u16*>(sa + lane * rowb);
+            u16* pb = reinterpret_cast<u16*>(sb + lane * rowb);
+            u32 best = 0;
+            int modal = 0;
+            for (int s = 0; s < S; ++s) {
+                const u32 h = (u32)pa[s] + pb[s];
+                pa[s] = (u16)h;
+                if (h > best) { best = h; modal = s; }
+            }
+            int Am1 = (int)(((u32)ga << 16) - 1u), ABm1 = (int)(((u32)(ga + gb) << 16) - 1u);
+            const u32 m = (u32)n_cols - best;
+            const u64 grow = (u64)(row0 + r0 + lane);
+            u32 calls = 0;
+            u32 a0w = 0, a1w = 0, a2w = 0, a3w = 0, ahave = 0, acalls = 0;
+            u32 wA = 0, wB = 0;
+            auto draw = [&](u32 v, u32 d) {                                               // the careful draw at position d
+                const int rem = n_cols - (int)d;
+                const int t = (int)__umul24(v, (u32)rem);
+                const int xA = Am1 - t, xAB = ABm1 - t;
+                bool a = xA >= rem - 1;                                                   // certainly A
+                bool b = xA < 0 && xAB >= rem - 1;                                        // certainly not A, certainly A or B
+                if ((!a && xA >= 0) || (xAB < rem - 1 && xAB >= 0)) {                     // the interval straddles a threshold
+                    if (ahave == 0) {
+                        u32 c[4] = {(u32)grow, (u32)(grow >> 32), acalls++, 0x74696573u};
+                        philox4x32_10(c, (u32)seed, (u32)(seed >> 32));
+                        a0w = c[0]; a1w = c[1]; a2w = c[2]; a3w = c[3];
+                        ahave = 4;
+                    }
+                    const u64 u48 = ((u64)v << 32) | a0w;
+                    a0w = a1w; a1w = a2w; a2w = a3w;
+                    --ahave;
+                    const u32 pick = (u32)((u48 * (u32)rem) >> 48);                       // uniform in [0, rem)
+                    a = pick < (((u32)Am1 + 1u) >> 16);
+                    b = !a && pick < (((u32)ABm1 + 1u) >> 16);
+                }
+                const u32 bit = 1u << (d & 31u);
+                wA |= a ? bit : 0u;
+                wB |= b ? bit : 0u;
+                Am1 -= a ? 65536 : 0;
+                ABm1 -= (a || b) ? 65536 : 0;
+            };
+            u32 d = 0;
+            for (; d + 8 <= m; d += 8) {
+                u32 c[4] = {(u32)grow, (u32)(grow >> 32), calls++, 0x6e756c6cu};
+                philox4x32_10(c, (u32)seed, (u32)(seed >> 32));
+                const int Am1_0 = Am1, ABm1_0 = ABm1;
+                const u32 wA_0 = wA, wB_0 = wB;
+                const int rem0 = __builtin_amdgcn_readfirstlane(n_cols - (int)d);
+                const int bit0 = __builtin_amdgcn_readfirstlane((int)(d & 31u));
+                u32 low = 0xffffffffu;
+#define NH_DRAW2(V, K)                                                                                                            \
+                {                                                                                                                 \
+                    u32 x0_, x1_, a_, ab_;                                                                                        \
+                    asm volatile(                                                                                                 \
+                        "v_mad_i32_i24 %[x0], %[v], %[nr], %[am]\n\t"                                                             \
+                        "v_mad_i32_i24 %[x1], %[v], %[nr], %[abm]\n\t"                                                            \
+                        "v_cmp_le_i32_e32 vcc, %[rm], %[x0]\n\t"                                                                  \
+                        "v_cndmask_b32_e64 %[a], 0, 1, vcc\n\t"                                                                   \
+                        "v_cmp_le_i32_e32 vcc, %[rm], %[x1]\n\t"                                                                  \
+                        "v_cndmask_b32_e64 %[ab], 0, 1, vcc\n\t"                                                                  \
+                        "v_lshl_or_b32 %[wa], %[a], %[b], %[wa]\n\t"                                                              \
+                        "v_mad_i32_i24 %[am], %[a], %[m64k], %[am]\n\t"                                                           \
+                        "v_mad_i32_i24 %[abm], %[ab], %[m64k], %[abm]\n\t"                                                        \
+                        "v_sub_u32_e32 %[ab], %[ab], %[a]\n\t"                                                                    \
+                        "v_lshl_or_b32 %[wb], %[ab], %[b], %[wb]\n\t"                                                             \
+                        "v_min3_u32 %[lo], %[x0], %[x1], %[lo]"                                                                   \
+                        : [x0] "=&v"(x0_), [x1] "=&v"(x1_), [a] "=&v"(a_), [ab] "=&v"(ab_), [wa] "+v"(wA), [wb] "+v"(wB),         \
+                          [am] "+v"(Am1), [abm] "+v"(ABm1), [lo] "+v"(low)                                                        \
+                        : [v] "v"(V), [nr] "s"((K) - rem0), [rm] "s"(rem0 - (K) - 1), [b] "s"(bit0 + (K)), [m64k] "s"(-65536)     \
+                        : "vcc");                                                                                                 \
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const u32 v = (k & 1) ? c[k >> 1] >> 16 : c[k >> 1] & 0xffffu;
+                    NH_DRAW2(v, k)
+                }
+#undef NH_DRAW2
+                if (low < (u32)rem0) {                                                    // a tie is possible in this call: repeat it carefully
+                    Am1 = Am1_0; ABm1 = ABm1_0;
+                    wA = wA_0; wB = wB_0;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) draw((k & 1) ? c[k >> 1] >> 16 : c[k >> 1] & 0xffffu, d + k);
+                }
+                if ((d & 31u) == 24u) {
+                    bitsA[(d >> 5) * 64] = wA;
+                    bitsB[(d >> 5) * 64] = wB;
+                    wA = 0;
+                    wB = 0;
+                }
+            }
+            if (d < m) {                                                                  // the last one to seven draws
+                u32 c[4] = {(u32)grow, (u32)(grow >> 32), calls++, 0x6e756c6cu};
+                philox4x32_10(c, (u32)seed, (u32)(seed >> 32));
+#pragma unroll
+                for (int k = 0; k < 7; ++k)
+                    if (d + k < m) draw((k & 1) ? c[k >> 1] >> 16 : c[k >> 1] & 0xffffu, d + k);
+            }
+            if (m & 31u) {
+                bitsA[(m >> 5) * 64] = wA;
+                bitsB[(m >> 5) * 64] = wB;
+            }
+            u32 o = 0;
+            for (int s = 0; s < S; ++s) {
+                const u32 h = s == modal ? 0u : (u32)pa[s];
+                pa[s] = (u16)nh_range_pop(bitsA, o, h);
+                pb[s] = (u16)nh_range_pop(bitsB, o, h);
+                o += h;
+            }
+            // positions o .. m - 1 are the columns without a state: drawn (they take places in the groups), not reported
+            const u32 needA = ((u32)Am1 + 1u) >> 16, needAB = ((u32)ABm1 + 1u) >> 16;
+            pa[modal] = (u16)needA;
+            pb[modal] = (u16)(needAB - needA);
+        }
+        __builtin_amdgcn_wave_barrier();
+        store_staged(sa, reinterpret_cast<char*>(OA + r0 * S), rows * rowb, lane);
+        store_staged(sb, reinterpret_cast<char*>(OB + r0 * S), rows * rowb, lane);
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 int null_hist_from_binhist_impl(const uint16_t* HA, const uint16_t* HB, int64_t R, int32_t S, int32_t n_cols, int32_t ga, int32_t gb,
                                 uint64_t seed, int64_t row0, uint16_t* OA, uint16_t* OB, hipStream_t st) {
     if (R < 0 || S < 1 || S > 127 || n_cols < 1 || n_cols > 65535) return fail(EPG_ERR_INVALID_ARG, "null_hist_from_binhist: bad shape");
@@ -429,6 +574,18 @@ int null_hist_from_binhist_impl(const uint16_t* HA, const uint16_t* HB, int64_t 
     const int NW = (n_cols + 31) / 32;
     const size_t bits_bytes = (size_t)NW * 256;
     const char* env = getenv("EPG_NULL_HIST");
+    if (!full && 2 * bits_bytes <= 24 * 1024 && !(env && env[0] == 's')) {      // -g: two thresholds, two bit strings
+        const size_t shmem = 4 * ((size_t)2 * TR * 2 * S + 2 * bits_bytes);
+        static bool attr2_set = false;
+        if (!attr2_set) {
+            EPG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_null_hist_h2), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            attr2_set = true;
+        }
+        hipLaunchKernelGGL(k_null_hist_h2, dim3((unsigned)blocks), dim3(256), shmem, st, HA, HB, (long)R, S, n_cols, ga, gb, (u64)seed,
+                           (long)row0, OA, OB, TR, NW);
+        EPG_LAUNCH_CHECK("k_null_hist_h2");
+        return EPG_OK;
+    }
     if (full && bits_bytes <= 24 * 1024 && !(env && env[0] == 's')) {
         const size_t shmem = 4 * ((size_t)2 * TR * 2 * S + bits_bytes);
         static bool attr_set = false;
