@@ -99,3 +99,78 @@ def test_paired_s1_random_shapes(eng, S, N, R, seed):
     res = eng.pair_scores_s1_parts(quads, S, NA, NB, NA, NB, tA, tB, tA, tB, qstate=S - 1)
     assert torch.equal(torch.cat([r["delta"] for r in res]), d) and torch.equal(torch.cat([r["null"] for r in res]), n)
     assert np.array_equal(torch.cat([r["quies"] for r in res]).cpu().numpy().astype(bool), onp.quiescent_mask(xa, xb, S - 1))
+
+
+def _driver_seeds():
+    import os
+    n = int(os.environ.get("EPG_RANDOM_DRIVER", 6))
+    return list(range(1, n + 1))
+
+
+@pytest.mark.parametrize("seed", _driver_seeds())
+def test_driver_random_inputs_against_oracle(tmp_path, seed):
+    """The genome driver on random inputs -- 1 to 4 files of 0 .. 700 rows (empty files and one-row files included), 2 .. 70
+    biosamples, 15 / 18 / 25 states, saliency 1 or 2, single or paired -- against the oracle on the concatenated matrix: exp_freq
+    exactly, every score of every file to the text's five decimals."""
+    import gzip
+    from epilogos_amd import driver
+    from tests.test_host_logic import write_tsv
+    rng = np.random.default_rng(seed)
+    S = int(rng.choice([15, 18, 25]))
+    N = int(rng.integers(2, 71))
+    sal = int(rng.choice([1, 2]))
+    paired = bool(rng.integers(0, 2))
+    nfiles = int(rng.integers(1, 5))
+    rows = [int(rng.choice([0, 1, 63, 64, 65, 200, 511, 700])) for _ in range(nfiles)]
+    if sum(rows) == 0:
+        rows[0] = 77
+    out = tmp_path / "out"
+    out.mkdir()
+    dirs = [tmp_path / "A", tmp_path / "B"] if paired else [tmp_path / "A"]
+    mats = []
+    for gi, dpath in enumerate(dirs):
+        dpath.mkdir()
+        n_g = N if gi == 0 else max(2, N - 3)
+        xs = []
+        for k, R in enumerate(rows):
+            x = synth_states(R, n_g, S=S, seed=seed * 100 + gi * 10 + k, uniform=bool(k % 2)) if R else np.zeros((0, n_g), dtype=np.int8)
+            if R == 0:
+                (dpath / ("m_chr%d.txt" % (k + 1))).write_text("")
+            else:
+                write_tsv(dpath / ("m_chr%d.txt" % (k + 1)), x, chrom="chr%d" % (k + 1))
+            xs.append(x)
+        mats.append(xs)
+    files = [sorted(d.glob("*")) for d in dirs]
+
+    def text(name):
+        with gzip.open(out / name, "rb") as fh:
+            t = fh.read().decode()
+        return np.array([[float(v) for v in l.split("\t")[3:]] for l in t.splitlines()], dtype=np.float64).reshape(-1, S)
+
+    if not paired:
+        q, _res = driver.run_single_group(files[0], S, sal, out, "t")
+        cat = np.concatenate(mats[0])
+        want_q = onp.normalise(onp.expected_s1(cat, S) if sal == 1 else onp.expected_s2(cat, S))
+        assert np.array_equal(q, want_q)
+        for k, x in enumerate(mats[0]):
+            got = text("scores_t_m_chr%d.txt.gz" % (k + 1))
+            ref = onp.score_s1(x, want_q, S) if sal == 1 else onp.score_s2(x, want_q, S)
+            assert got.shape == ref.shape
+            np.testing.assert_allclose(got, ref, atol=1.01e-5)
+    else:
+        q, _res = driver.run_paired_groups(files[0], files[1], S, sal, out, "t", S - 1, -1, 99)
+        cat = np.concatenate([np.concatenate([a, b], axis=1) for a, b in zip(mats[0], mats[1])])
+        want_q = onp.normalise(onp.expected_s1(cat, S) if sal == 1 else onp.expected_s2(cat, S))
+        assert np.array_equal(q, want_q)
+        for k, (xa, xb) in enumerate(zip(mats[0], mats[1])):
+            got = text("pairwiseDelta_t_m_chr%d.txt.gz" % (k + 1))
+            if sal == 1:
+                sa, sb = onp.score_s1(xa, want_q, S), onp.score_s1(xb, want_q, S)
+            else:
+                sa = onp.score_s2(xa, want_q, S, perms=xa.shape[1] * (xa.shape[1] - 1))
+                sb = onp.score_s2(xb, want_q, S, perms=xb.shape[1] * (xb.shape[1] - 1))
+            ref, _ = onp.pair_finish(sa.astype(np.float32), sb.astype(np.float32))
+            assert got.shape == ref.shape
+            np.testing.assert_allclose(got, ref, atol=2.01e-5)
+            qm = np.load(out / ("temp_quiescence_t_m_chr%d.npz" % (k + 1)))["quiescenceArr"]
+            assert np.array_equal(qm, onp.quiescent_mask(xa, xb, S - 1))
