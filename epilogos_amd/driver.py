@@ -473,8 +473,27 @@ def _redistribute(d, sess, plans, owner, mine, starts, widths):
     return [pid_of[(fi, lo)] for fi, lo, _hi in my], [loc_of[(fi, lo)] for fi, lo, _hi in my]
 
 
+_deferred = []
+
+
+def _wait_writes(writer, jobs):
+    try:
+        for j in jobs:
+            j.result()
+    finally:
+        writer.shutdown(wait=True)
+
+
+def finish_writes():
+    """Wait for the text writers a run with defer_writes=True left running (and re-raise what one of them raised)."""
+    while _deferred:
+        writer, jobs, tm, label = _deferred.pop()
+        _wait_writes(writer, jobs)
+        tm.lap(label)
+
+
 def run_single_group(files, numStates, saliency, outputDir, fileTag, verbose=False, backend=None, device=None,
-                     keep_temp_scores=True):
+                     keep_temp_scores=True, defer_writes=False):
     """STEP 1-3 for a single group over `files` (one per chromosome).  Returns (exp_freq float32, results) where results
     (rank 0 only, else None) maps file stem -> (chrName, float32 scores [R, S], _io.Locations) for an in-process STEP 4.
     keep_temp_scores writes the reference's temp_scores_{tag}_{stem}.npz (scores.py:166-169) for a STEP 4 run
@@ -528,8 +547,9 @@ def run_single_group(files, numStates, saliency, outputDir, fileTag, verbose=Fal
     payloads = []
     nwriters = min(2, _io.host_budget())               # two files are written at a time: half of this rank's cores each
     wthreads = max(1, _io.host_budget() // nwriters)
-    with ThreadPoolExecutor(max_workers=nwriters) as writer:
-        jobs = []
+    writer = ThreadPoolExecutor(max_workers=nwriters)
+    jobs = []
+    try:
         for k, (fi, lo, hi) in enumerate(my_parts):
             sc = sess.scores(pids[k])
             whole = lo == 0 and hi == rows[fi]
@@ -537,9 +557,16 @@ def run_single_group(files, numStates, saliency, outputDir, fileTag, verbose=Fal
             jobs.append(writer.submit(writeScores, sc, outputDir / name, locs[k], None, wthreads))
             payloads.append([sc, np.asarray(locs[k].blob), np.asarray(locs[k].offsets)])
         tm.lap("scores (kernels + download)")
-        for j in jobs:
-            j.result()
-    tm.lap("write text (overlapped tail)")
+    except BaseException:
+        writer.shutdown(wait=True)
+        raise
+    if defer_writes and d.world == 1:
+        # one process: the text goes on being formatted and compressed in the writer threads while the caller runs STEP 4 on the
+        # arrays (finish_writes() waits for them); several ranks need their part files complete before rank 0 assembles them
+        _deferred.append((writer, jobs, tm, "write text (under STEP 4)"))
+    else:
+        _wait_writes(writer, jobs)
+        tm.lap("write text (overlapped tail)")
     tm.note("H2D uploads: %d for %d part(s)" % (getattr(sess, "n_uploads", 0), len(my_parts)))
     d.barrier()
     got = _gather_parts(d, plans, payloads, 3)
@@ -568,7 +595,7 @@ def run_single_group(files, numStates, saliency, outputDir, fileTag, verbose=Fal
 
 
 def run_paired_groups(files1, files2, numStates, saliency, outputDir, fileTag, quiescentState, groupSize, nullSeed,
-                      verbose=False, backend=None, device=None, keep_temps=True):
+                      verbose=False, backend=None, device=None, keep_temps=True, defer_writes=False):
     """STEP 1-3 of paired mode (reference run.py:205-221,258-279 + scores.py:172-256) over the bin-range partition.
     Background counts are taken over the column concatenation [A|B] (helpers.py:173) -- from the two groups' own
     histograms, each group is uploaded once -- all-reduced once; each rank then scores A, B and the two shuffled null
@@ -643,8 +670,9 @@ def run_paired_groups(files1, files2, numStates, saliency, outputDir, fileTag, q
     payloads = []
     nwriters = min(2, _io.host_budget())
     wthreads = max(1, _io.host_budget() // nwriters)
-    with ThreadPoolExecutor(max_workers=nwriters) as writer:
-        wjobs = []
+    writer = ThreadPoolExecutor(max_workers=nwriters)
+    wjobs = []
+    try:
         for k, (fi, lo, hi) in enumerate(my_parts):
             res = sess.results(pids[k])
             whole = lo == 0 and hi == rows[fi]
@@ -654,9 +682,15 @@ def run_paired_groups(files1, files2, numStates, saliency, outputDir, fileTag, q
             payloads.append([np.asarray(res["null"], dtype=np.float32), np.asarray(res["quies"], dtype=np.bool_),
                              np.asarray(res["rdist"], dtype=np.float32), np.asarray(res["mdiff"], dtype=np.int32),
                              np.asarray(locs[k].blob), np.asarray(locs[k].offsets)])
-        for j in wjobs:
-            j.result()
-    tm.lap("scores, nulls, deltas + write text")
+    except BaseException:
+        writer.shutdown(wait=True)
+        raise
+    if defer_writes and d.world == 1:
+        tm.lap("scores, nulls, deltas (kernels + download)")
+        _deferred.append((writer, wjobs, tm, "write text (under STEP 4)"))
+    else:
+        _wait_writes(writer, wjobs)
+        tm.lap("scores, nulls, deltas + write text")
     tm.note("H2D uploads: %d for %d part(s) x 2 groups" % (getattr(sess, "n_uploads", 0), len(my_parts)))
     d.barrier()
     got = _gather_parts(d, plans, payloads, 6)

@@ -222,17 +222,20 @@ def main(mode, commandLineBool, inputDirectory, inputDirectory1, inputDirectory2
         say("\nSTEP 1-3: background counts -> all-reduce -> scores (bin-range partition over %d GPU(s))" % world)
         try:
             _, results = run_single_group(files, numStates, saliency, outputDirPath, fileTag, verbose=False, device=device,
-                                          keep_temp_scores=False)
+                                          keep_temp_scores=False, defer_writes=True)
         finally:
             driver.abort_early_readers()                         # (nothing to do once the stage driver has taken them over)
-        if rank == 0:
-            say("\nSTEP 4: Finding regions of interest", flush=True)
-            import time
-            t0 = time.perf_counter()
-            from .roiSingle import mainFromArrays as roiSingle
-            roiSingle(results, outputDirPath, stateInfo, fileTag, storedExpPath, roiWidth if roiWidth else 50, False)
-            if os.environ.get("EPILOGOS_TIMING"):
-                print("    [timing] %-34s %7.2f s" % ("STEP 4", time.perf_counter() - t0), flush=True)
+        try:
+            if rank == 0:
+                say("\nSTEP 4: Finding regions of interest", flush=True)
+                import time
+                t0 = time.perf_counter()
+                from .roiSingle import mainFromArrays as roiSingle
+                roiSingle(results, outputDirPath, stateInfo, fileTag, storedExpPath, roiWidth if roiWidth else 50, False)
+                if os.environ.get("EPILOGOS_TIMING"):
+                    print("    [timing] %-34s %7.2f s" % ("STEP 4", time.perf_counter() - t0), flush=True)
+        finally:
+            driver.finish_writes()                               # one process: the score text was still being written under STEP 4
     else:
         from .driver import run_paired_groups
         if nullSeed is None:
@@ -249,18 +252,23 @@ def main(mode, commandLineBool, inputDirectory, inputDirectory1, inputDirectory2
         say("\nSTEP 1-3: background counts over [A|B] -> all-reduce -> scores, null groups, deltas (%d GPU(s))" % world)
         try:
             _, results = run_paired_groups(files, files2, numStates, saliency, outputDirPath, fileTag, quiescentState, groupSize,
-                                           nullSeed, verbose=False, device=device, keep_temps=False)
+                                           nullSeed, verbose=False, device=device, keep_temps=False, defer_writes=True)
         finally:
             driver.abort_early_readers()
-        if rank == 0:
-            say("\nSTEP 4: Generating p-values & regions of interest (figures are not produced)", flush=True)
-            import time
-            t0 = time.perf_counter()
-            from .roiAndVisualPairwise import mainFromArrays as roiPairwise
-            roiPairwise(results, stateInfo, outputDirPath, fileTag, max(numProcesses, 1), pvalBool, numTrials, samplingSize,
-                        storedExpPath, roiWidth if roiWidth else 125, False)
-            if os.environ.get("EPILOGOS_TIMING"):
-                print("    [timing] %-34s %7.2f s" % ("STEP 4", time.perf_counter() - t0), flush=True)
+        if pvalBool and max(numProcesses, 1) > 1:
+            driver.finish_writes()                               # -n -c K forks a pool for the fits: not with writer threads running
+        try:
+            if rank == 0:
+                say("\nSTEP 4: Generating p-values & regions of interest (figures are not produced)", flush=True)
+                import time
+                t0 = time.perf_counter()
+                from .roiAndVisualPairwise import mainFromArrays as roiPairwise
+                roiPairwise(results, stateInfo, outputDirPath, fileTag, max(numProcesses, 1), pvalBool, numTrials, samplingSize,
+                            storedExpPath, roiWidth if roiWidth else 125, False)
+                if os.environ.get("EPILOGOS_TIMING"):
+                    print("    [timing] %-34s %7.2f s" % ("STEP 4", time.perf_counter() - t0), flush=True)
+        finally:
+            driver.finish_writes()
     from .helpers import flushCacheWrites
     flushCacheWrites()                                           # --cache-dir: files of first-time reads, written in the background
     if os.environ.get("EPILOGOS_TIMING") and rank == 0:
