@@ -349,10 +349,14 @@ def _assemble_text(outputDir, kind, final_name, fileTag, fi, owners, rows_fi):
 
 
 def _cat(arrs, empty):
+    if len(arrs) == 1:
+        return arrs[0]                                 # (a file that lies in one rank's range: no copy of its 70 B per bin)
     return np.concatenate(arrs) if arrs else empty
 
 
 def _cat_locations(locs):
+    if len(locs) == 1:
+        return locs[0]
     blobs = [np.asarray(l.blob) for l in locs]
     offs, base = [np.zeros(1, dtype=np.int64)], 0
     for l in locs:
