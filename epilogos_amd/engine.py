@@ -435,6 +435,7 @@ class PinnedPool:
         self.weights = {}
         self.target = 0
         self.waiting = set()
+        self.closed = False
 
     def hint(self, weights):
         """{ticket: bytes of the input file behind it}.  Page-locking memory is slow (~3 GB/s): a pool whose buffers grow to each
@@ -492,8 +493,29 @@ class PinnedPool:
 
     def release(self, buf):
         with self.cv:
+            if self.closed:
+                return                                   # (dropped: the memory goes back to the driver with this last reference)
             self.free.append(buf)
             self.cv.notify_all()
+
+    def close(self, background=True):
+        """Nothing more will be staged: give the page-locked buffers back now -- on a helper thread, so that un-locking ~9 GB
+        passes under the score pass and the writers instead of at process exit (0.3-0.4 s of a whole-genome run).  Buffers still
+        out with an upload in flight are dropped when they come back."""
+        import threading
+        with self.cv:
+            self.closed = True
+            bufs, self.free = [b for b in self.free if b is not None], []
+        if not bufs:
+            return
+
+        def work(bufs=bufs):
+            while bufs:
+                bufs.pop()
+        if background:
+            threading.Thread(target=work, name="epilogos-staging-close", daemon=True).start()
+        else:
+            work()
 
 
 def upload_states(pinned, R, ldx, copy_stream, device="cuda"):
