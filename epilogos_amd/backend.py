@@ -169,16 +169,8 @@ class _HipSession:
     def __init__(self, be, S, saliency):
         self.be, self.S, self.sal = be, S, saliency
         self.torch, self.eng, self.device = be.torch, be.engine, be.device
-        # staging buffers in flight; paired mode holds a part's A and B at once, so never fewer than two
-        # (first come, first served: the driver takes the parts as their parsers finish)
-        # A reader holds its buffer from the moment it knows its file's shape until the upload is over -- the parse runs straight
-        # into it -- so fewer buffers than readers serialise the parse stage (profiles/r04k: four buffers for sixteen readers,
-        # every reader waited 0.3-1.7 s).  Half as many as this rank may run parser threads, at most 8 (~1 GB of page-locked
-        # memory each for a whole-genome run).
-        from . import _io
-        self.pool = be.engine.PinnedPool(max(2, int(__import__("os").environ.get("EPILOGOS_PINNED_BUFFERS", min(8, max(4, _io.host_budget() // 2))))),
-                                         in_order=False)
-        self.copy_stream = self.torch.cuda.Stream(device=self.device)
+        self._pool = None                                # page-locked staging (lazily: a session fed device-resident parts has none)
+        self._copy_stream = None
         self.held = {}                                   # ticket -> pinned buffer handed to the parser
         self.acc = None
         self.q = None
@@ -191,6 +183,25 @@ class _HipSession:
         self.tables_patched = 0
         self._pending_check = None
         self._ws3 = None                                 # S3 expected pass: ONE workspace for all parts of the session
+
+    @property
+    def pool(self):
+        """Staging buffers in flight; paired mode holds a part's A and B at once, so never fewer than two (first come, first
+        served: the driver takes the parts as their parsers finish).  A reader holds its buffer from the moment it knows its
+        file's shape until the upload is over -- the parse runs straight into it -- so fewer buffers than readers serialise the
+        parse stage (profiles/r04k: four buffers for sixteen readers, every reader waited 0.3-1.7 s).  Half as many as this rank
+        may run parser threads, at most 8 (~1 GB of page-locked memory each for a whole-genome run)."""
+        if self._pool is None:
+            from . import _io
+            n = int(os.environ.get("EPILOGOS_PINNED_BUFFERS", min(8, max(4, _io.host_budget() // 2))))
+            self._pool = self.be.engine.PinnedPool(max(2, n), in_order=False)
+        return self._pool
+
+    @property
+    def copy_stream(self):
+        if self._copy_stream is None:
+            self._copy_stream = self.torch.cuda.Stream(device=self.device)
+        return self._copy_stream
 
     def alloc(self, ticket):
         """-> alloc(R, N) for _io.read_table / helpers.readTable: a pinned, row-padded destination for part `ticket`."""
