@@ -59,3 +59,31 @@ def test_gpus_flag_makes_bench_its_own_launcher(tmp_path):
     bad = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "3"], env=dict(env, WORLD_SIZE="2", RANK="0"),
                          capture_output=True, text=True, timeout=120)
     assert bad.returncode != 0 and "does not match" in bad.stderr
+
+
+def test_chromosome_parts_cover_a_ranks_range_exactly():
+    """bench.chromosome_parts (how bench.py feeds the paired session: one part per chromosome file in hg19's proportions, cut at
+    the rank's bin range): the parts of all ranks tile the genome without gaps or overlaps, a part never crosses a file border,
+    and (file, first row) -- what keys the null shuffle -- does not depend on the number of ranks."""
+    from epilogos_amd.driver import shuffle_key
+    R = 15_000_000
+    whole = bench.chromosome_parts(R, 0, R)
+    assert len(whole) == 24 and whole[0][2] == 0 and whole[-1][3] == R
+    assert all(a[3] == b[2] for a, b in zip(whole, whole[1:])) and all(p[1] == 0 for p in whole)
+    sizes = np.array([b - a for _f, _r, a, b in whole], dtype=np.float64)
+    want = np.array(bench.HG19_BP, dtype=np.float64)
+    assert np.abs(sizes / sizes.sum() - want / want.sum()).max() < 1e-6
+    first = {f: a for f, _r, a, _b in whole}
+    for world in (2, 3, 8):
+        seen = []
+        for rank in range(world):
+            lo, hi = rank * R // world, (rank + 1) * R // world
+            parts = bench.chromosome_parts(R, lo, hi)
+            assert parts[0][2] == lo and parts[-1][3] == hi
+            for f, r0, a, b in parts:
+                assert a < b and r0 == a - first[f]                      # the row in the file of the part's first bin
+                assert b <= first.get(f + 1, R)                          # never across a file border
+            seen += parts
+        assert all(a[3] == b[2] for a, b in zip(seen, seen[1:])) and seen[0][2] == 0 and seen[-1][3] == R
+    # the key is (file, row): rows of one file ascend, files do not collide below 2^40 rows
+    assert shuffle_key(3, 17) == (3 << 40) + 17 and shuffle_key(0, (1 << 40) - 1) < shuffle_key(1, 0)
