@@ -555,3 +555,30 @@ def test_paired_driver_15_states_odd_last_tile(tmp_path):
             side = np.load(out / ("temp_pairMetrics_t_%s.npz" % name[:-7]))
             rd, rm = onp.pair_metrics(got, roundtrip=False)
             assert np.array_equal(side["distances"], rd) and np.array_equal(side["maxDiff"], rm)
+
+
+def test_bench_eight_ranks_on_one_gpu(tmp_path):
+    """bench.py's N = 8 code path with all its configs (S2, S3, paired in chromosome parts, per-rank gather, all-reduce probe),
+    eight gloo ranks sharing cuda:0, small sizes: the numbers mean nothing (eight processes on one GPU), the line must be complete --
+    the first real 8-GPU run is the driver's, this is what can be checked before."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parents[1]
+    env = dict(os.environ, PYTHONPATH=str(root))
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR"):
+        env.pop(k, None)
+    cmd = [sys.executable, str(root / "bench.py"), "--gpus", "8", "--backend", "gloo", "--bins", "800008", "--s3-bins", "80000", "--steps", "3",
+           "--warmup", "1", "--config-reps", "1"]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=str(tmp_path))
+    assert res.returncode == 0, res.stdout + res.stderr[-3000:]
+    line = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 8 and line["scaling"] == "strong" and line["config"]["bins_per_gpu"] == 100001
+    assert len(line["per_rank"]["k_bin_hist_ms"]) == 8 and line["allreduce_probe"]["world"] == 8
+    for name in ("s2", "s3", "paired"):
+        cfg = line["configs"][name]
+        assert "error" not in cfg and cfg["job_ms"] > 0 and cfg["bins_total"] in (800008, 80000), cfg
+    assert line["configs"]["paired"]["outputs_finite"] and line["configs"]["s2"]["scores_finite"]
+    assert line["cpu_baseline"] is None and line["s1_paths"] is None
