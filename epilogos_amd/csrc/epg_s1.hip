@@ -248,6 +248,20 @@ __global__ __launch_bounds__(256) void k_normalise(const IT* __restrict__ C, lon
         q[i] = (float)((double)C[i] / tot);
 }
 
+// Short arrays -- the S1 and S2 count arrays (18 and 324 entries) -- in ONE block and ONE launch: the sum stays in the block, so
+// the memset and the two kernels above (three launches, ~15 us of a 0.45 ms S2 job on an eighth of the genome) become one.
+template <typename IT>
+__global__ __launch_bounds__(256) void k_normalise_small(const IT* __restrict__ C, int n, float* __restrict__ q) {
+    __shared__ long long s_part[4];
+    long long acc = 0;
+    for (int i = threadIdx.x; i < n; i += 256) acc += (long long)C[i];
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
+    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    const double tot = (double)(s_part[0] + s_part[1] + s_part[2] + s_part[3]);
+    for (int i = threadIdx.x; i < n; i += 256) q[i] = (float)((double)C[i] / tot);
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // host-side dispatch
 // ---------------------------------------------------------------------------------------------------------------
@@ -545,6 +559,11 @@ template <typename IT>
 static int normalise_impl(const IT* C, int64_t n, float* q, void* ws, int64_t ws_bytes, hipStream_t st) {
     if (n < 1 || !C || !q || !ws) return fail(EPG_ERR_INVALID_ARG, "normalise: bad argument");
     if (ws_bytes < 8) return fail(EPG_ERR_WORKSPACE, "normalise: workspace needs 8 bytes");
+    if (n <= 4096) {
+        hipLaunchKernelGGL((k_normalise_small<IT>), dim3(1), dim3(256), 0, st, C, (int)n, q);
+        EPG_LAUNCH_CHECK("k_normalise_small");
+        return EPG_OK;
+    }
     long long* total = reinterpret_cast<long long*>(ws);
     EPG_HIP(hipMemsetAsync(total, 0, 8, st));
     long blocks = (n + 255) / 256;
