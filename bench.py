@@ -28,9 +28,13 @@ of launches), each with its own roofline figure:
     "s3"     S3 expected pass (matrix-core contraction) and score pass (LDS gathers) on `--s3-bins` bins,
     "paired" paired S1 on 379 + 342 biosamples: two count passes, all-reduce, the hypergeometric null groups, then scores of
              the four groups, deltas, null distances and STEP 4's per-bin reduction in one pass, and the quiescence mask.
-`--configs none` skips them.  The headline step allocates like the product does (plain torch allocations); the effect of
-putting the histogram cache into another memory class than the matrix (engine.place_hist) is measured after
-the timed region and reported as the secondary field `placement_experiment`.
+    "s3" is the whole 15 M-bin genome (one repetition), "s3_small" the 2 M-bin job of earlier rounds.
+`--configs none` skips them.  The headline step is the product's: a fresh backend._HipSingleSession per job, whose add_device puts
+the histogram cache of a resident matrix into another memory class than the matrix (engine.alloc_hist, DESIGN.md 3: a one-off
+probe per process, reported as `placement.report`); the same jobs with a plain allocation (add_device(place=False)) are timed
+after the timed region and reported as `placement.unplaced`.  After the headline: the same step as ONE hipGraph replay
+(`graph_ms_per_step`), an RCCL self-test when there is a process group (`rccl_selftest`), the distribution variants of SURVEY.md
+8d (`dist_variants`).  A secondary measurement that hangs ends the run with exit code 3 AFTER the line has been printed.
 """
 import argparse
 import json
@@ -179,7 +183,8 @@ def _event_ms(torch, fn, reps=3):
 
 def bench_single(torch, be, d, sal, X, N, S, R, R_global, world, reps, fence):
     """One whole single-group job of saliency 2 or 3 per repetition, through the session the command line uses
-    (backend._HipSingleSession: add_device -> all_reduce -> finish_device -> scores_device), inputs resident.  Wall time
+    (backend._HipSingleSession: add_device -> all_reduce -> launch [= finish_device + the score passes]; its finish() -- count
+    check and exp_freq download, a host synchronisation -- after the clock), inputs resident.  Wall time
     between fences (max over ranks) and device time of the phases from events on the launch stream."""
     dev = X.device
     walls, phases = [], []
@@ -193,16 +198,17 @@ def bench_single(torch, be, d, sal, X, N, S, R, R_global, world, reps, fence):
         e[1].record()
         sess.ensure_acc(N)
         sess.all_reduce(d)                                        # the one collective: int64[S*S] or int32[N*N*S*S]
-        sess.finish_device(R_global, N)                           # STEP 2 (the count check is deferred to sess.check())
+        sess.finish_device(R_global, N)                           # STEP 2 (S3 checks its counts at once; S2: in finish())
         e[2].record()
-        o32 = sess.scores_device(pid)                             # STEP 3
+        sess.launch_scores([pid])                                 # STEP 3
+        o32 = sess.early_scores(pid)
         e[3].record()
         fence()
         wall = time.perf_counter() - t0
         if rep:
             walls.append(_max_over_ranks(torch, d, wall, dev))
             phases.append([e[i].elapsed_time(e[i + 1]) for i in range(3)])
-        sess.check()                                              # the deferred count check (S1 / S2; S3 checks at once)
+        sess.finish(R_global, N)                                  # the host side: count check, exp_freq download
         ok = bool(torch.isfinite(o32[:: max(R // 4096, 1)]).all()) if R else True
         del sess, o32
     wall_ms = float(np.median(walls)) * 1e3
@@ -215,7 +221,7 @@ def bench_single(torch, be, d, sal, X, N, S, R, R_global, world, reps, fence):
         # bytes the job has to move per bin: X read, H written, H read by the pair counts, H read + float32 scores written
         bpb = N + 2 * S + 2 * S + 2 * S + 4 * S
         eng = be.engine
-        H, _ = eng.bin_hist(X, N, S, want_counts=False)
+        H, _ = eng.bin_hist(X, N, S, want_counts=False, H=eng.alloc_hist(X, N, S))    # (where the session's jobs had it)
         c2 = eng.hist_s2_from_binhist(H, S)
         q2 = eng.normalise(c2)
         o = torch.empty((R, S), dtype=torch.float32, device=dev)
@@ -297,18 +303,19 @@ def bench_paired(torch, be, d, R, R_global, bin0, S, world, reps, fence, dev, di
         sess.all_reduce(d)
         sess.finish_device(R_global, NA + NB)
         e[2].record()
-        res = sess.results_device_all(pids)                    # one launch over all the parts (what sess.results() does first)
+        sess.launch_scores(pids)                               # one launch over all the parts
+        res = [sess._early[p] for p in pids]
         e[3].record()
         fence()
         wall = time.perf_counter() - t0
         if rep:
             walls.append(_max_over_ranks(torch, d, wall, dev))
             phases.append([e[i].elapsed_time(e[i + 1]) for i in range(3)])
-        sess.check()
+        sess.finish(R_global, NA + NB)                         # host side: count check, table verification
         ok = all(bool(torch.isfinite(r["delta"][:: max(r["delta"].shape[0] // 512, 1)]).all()) and
                  bool(torch.isfinite(r["null"][:: max(r["null"].shape[0] // 512, 1)]).all()) for r in res)
         nq = int(sum(int(r["quies"].sum().item()) for r in res))
-        patched = sess.verify_tables()
+        patched = sess.tables_patched
         del sess, res
     wall_ms = float(np.median(walls)) * 1e3
     exp_ms, comb_ms, res_ms = (float(v) for v in np.median(np.array(phases), axis=0))
@@ -330,6 +337,122 @@ def bench_paired(torch, be, d, R, R_global, bin0, S, world, reps, fence, dev, di
                          "what": "whole job (device time of the three phases on the main stream) against the bytes it has to move; the "
                                  "null groups are compute-bound (Philox + selection sampling), see DESIGN.md 3"},
             "path": "backend._HipPairedSession (the command line's session), device-resident"}
+
+
+def rank_identity(torch, dev, local_rank):
+    """Which GPU this rank really drives: HIP device index and name, PCI address, the NUMA node of that PCI device, the
+    *_VISIBLE_DEVICES variables, the cores the process may run on (the first 8-GPU run should explain itself)."""
+    who = {"local_rank": local_rank, "hip_device": dev.index, "pid": os.getpid(), "cores_allowed": len(os.sched_getaffinity(0))}
+    try:
+        pr = torch.cuda.get_device_properties(dev)
+        who["name"] = pr.name
+        who["gcn_arch"] = getattr(pr, "gcnArchName", None)
+        who["cus"] = pr.multi_processor_count
+        who["hbm_GiB"] = round(pr.total_memory / 2**30, 1)
+        dom, bus, devid = (getattr(pr, k, None) for k in ("pci_domain_id", "pci_bus_id", "pci_device_id"))
+        if bus is not None:
+            addr = "%04x:%02x:%02x.0" % (dom or 0, bus, devid or 0)
+            who["pci"] = addr
+            node = Path("/sys/bus/pci/devices") / addr / "numa_node"
+            who["numa_node"] = int(node.read_text()) if node.exists() else None
+    except Exception as e:
+        who["error"] = repr(e)[:120]
+    for k in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "GPU_DEVICE_ORDINAL"):
+        if k in os.environ:
+            who[k] = os.environ[k]
+    return who
+
+
+def rccl_selftest(torch, dist, dev, rank, world, N, S):
+    """Every collective the multi-rank command line uses, once, checked against numbers: the all-reduce of the S1 count vector
+    (int64[S]) and of the S3 count tensor at its real size (int32 [N, N, S, S], 899 MB at N = 833), the device-to-device
+    hand-over of border pieces (driver._redistribute: send/recv, here a ring), the broadcast of the null seed
+    (driver: int64[1]) and the all_gather bench.py itself uses.  -> {leg: {"ok", "ms"}}; a leg that raises is reported, not fatal."""
+    out = {"world": world, "backend": dist.get_backend()}
+    rccl = dist.get_backend() == "nccl"
+    full = N * N * S * S
+    if not rccl:                       # a host-side backend (the CPU / one-GPU tests): tensors on the host, the big one 1/64
+        dev, full = torch.device("cpu"), max(full // 64, 1 << 20)
+    sync = torch.cuda.synchronize if rccl else (lambda: None)
+
+    def leg(name, fn):
+        t0 = time.perf_counter()
+        try:
+            ok = bool(fn())
+            sync()
+            out[name] = {"ok": ok, "ms": round((time.perf_counter() - t0) * 1e3, 2)}
+        except Exception as e:
+            out[name] = {"ok": False, "error": repr(e)[:200]}
+
+    def ar_small():
+        t = torch.arange(S, dtype=torch.int64, device=dev) * (rank + 1)
+        dist.all_reduce(t)
+        return torch.equal(t.cpu(), torch.arange(S, dtype=torch.int64) * (world * (world + 1) // 2))
+
+    def ar_big():
+        n = full
+        t = torch.full((n,), rank + 1, dtype=torch.int32, device=dev)
+        t[::1000003] += 7 * rank
+        sync()
+        t0 = time.perf_counter()
+        dist.all_reduce(t)
+        sync()
+        ms = (time.perf_counter() - t0) * 1e3
+        out["allreduce_int32_%d_ms" % n] = round(ms, 3)
+        out["allreduce_int32_busbw_GBps"] = round(2 * (world - 1) / world * n * 4 / ms / 1e6, 1) if world > 1 else None
+        base = world * (world + 1) // 2
+        want = torch.full((n,), base, dtype=torch.int32, device=dev)
+        want[::1000003] += 7 * (world * (world - 1) // 2)
+        return torch.equal(t, want)
+
+    def ring():
+        if world == 1:
+            return True
+        n = 16 << 20                                                        # a 64 MB border piece of int32
+        mine = torch.full((n,), rank, dtype=torch.int32, device=dev)
+        got = torch.empty_like(mine)
+        nxt, prv = (rank + 1) % world, (rank - 1) % world
+        ops = [dist.P2POp(dist.isend, mine, nxt), dist.P2POp(dist.irecv, got, prv)]
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+        return bool((got == prv).all().item())
+
+    def plain_p2p():
+        if world == 1:
+            return True
+        # the driver's hand-over is plain send / recv between pairs (lazy communicator set-up on first use): even ranks send first
+        t = torch.full((1 << 20,), rank, dtype=torch.int16, device=dev)
+        g = torch.empty_like(t)
+        peer = rank ^ 1
+        if peer >= world:
+            return True
+        if rank % 2 == 0:
+            dist.send(t, peer)
+            dist.recv(g, peer)
+        else:
+            dist.recv(g, peer)
+            dist.send(t, peer)
+        return bool((g == peer).all().item())
+
+    def bcast():
+        t = torch.tensor([20240229 if rank == 0 else -1], dtype=torch.int64, device=dev)
+        dist.broadcast(t, 0)
+        return int(t.item()) == 20240229
+
+    def gather():
+        mine = torch.tensor([float(rank)], dtype=torch.float64, device=dev)
+        allv = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allv, mine)
+        return [int(v.item()) for v in allv] == list(range(world))
+
+    leg("all_reduce int64[%d]" % S, ar_small)
+    leg("all_reduce int32[%d] (the S3 count tensor%s)" % (full, "" if rccl else ", 1/64 of it: host backend"), ar_big)
+    leg("send/recv ring of 64 MB (batch_isend_irecv)", ring)
+    leg("send/recv pairs (driver._redistribute's hand-over)", plain_p2p)
+    leg("broadcast int64[1] (null seed)", bcast)
+    leg("all_gather float64[1]", gather)
+    out["ok"] = all(v.get("ok", True) for v in out.values() if isinstance(v, dict))
+    return out
 
 
 def launch_command(gpus, argv, port):
@@ -368,8 +491,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--packed", action="store_true", help="row pitch = biosamples (unaligned rows) instead of 16-byte padded")
     ap.add_argument("--dist", choices=["chr1", "uniform", "correlated"], default="chr1", help="synthetic state distribution")
-    ap.add_argument("--configs", default="s2,s3,paired", help="BASELINE configs 3-5 measured next to the headline: any of s2,s3,paired; none")
-    ap.add_argument("--s3-bins", type=int, default=2_000_000, help="bins of the S3 measurement (whole job, all ranks)")
+    ap.add_argument("--configs", default="s2,s3,s3_small,paired", help="BASELINE configs 3-5 measured next to the headline: any of s2,s3,s3_small,paired; none")
+    ap.add_argument("--s3-bins", type=int, default=0, help="bins of the S3 measurement (whole job, all ranks); 0 = the genome (--bins), one repetition")
+    ap.add_argument("--s3-small-bins", type=int, default=2_000_000, help="bins of the s3_small measurement (--config-reps repetitions)")
+    ap.add_argument("--dist-variants", type=int, default=1, help="one GPU: K1 / job time on the uniform and the row-correlated matrix (SURVEY 8d); 0 = skip")
+    ap.add_argument("--graph-leg", type=int, default=1, help="after the headline: the step as one hipGraph replay (graph_ms_per_step); 0 = skip")
     ap.add_argument("--config-reps", type=int, default=3)
     ap.add_argument("--extras-deadline", type=int, default=900,
                     help="seconds the measurements after the timed region (placement experiment, --configs) may take before rank 0 "
@@ -383,7 +509,7 @@ def main():
     ap.add_argument("--shard-bins", type=int, default=1_875_000, help="one GPU: both paths are also timed on a shard of this "
                                                                         "many bins (an eighth of the genome: the 8-GPU share); 0 = skip")
     ap.add_argument("--pg", action="store_true", help="one GPU: still join a one-rank RCCL process group, so that the step contains the all-reduce")
-    ap.add_argument("--placement-experiment", type=int, default=1, help="0: skip the histogram-placement experiment after the timed region")
+    ap.add_argument("--placement-experiment", type=int, default=1, help="0: skip the jobs with an unplaced histogram cache after the timed region")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to test the "
                                                       "multi-rank path on a box with one GPU, ranks then share cuda:0)")
     args = ap.parse_args()
@@ -451,7 +577,7 @@ def main():
     # the bare-ABI path works on buffers of its own; the session path allocates per job (nothing is held for it here)
     out32 = None if use_session else torch.empty((R, S), dtype=torch.float32, device=dev)
     ws_s1 = engine.workspace(1, 0, N, S, device=dev)
-    H = None if use_session else torch.empty((R, S), dtype=torch.int16, device=dev)
+    H = None if use_session else engine.alloc_hist(X, N, S)                # (the library's allocator for a resident matrix)
     last_counts = torch.zeros(S, dtype=torch.int64, device=dev)
 
     from epilogos_amd import backend as _backend
@@ -478,23 +604,27 @@ def main():
         if e is not None:
             e[3].record()
 
-    def step_session(Xs, e=None):
-        """One whole S1 job the way the command line runs it: a fresh session per job, the histogram cache, the count vector,
-        the tables and the scores allocated by the session (torch's caching allocator hands the previous job's blocks back)."""
+    def step_session(Xs, e=None, place=True, finish=False):
+        """One whole S1 job through the product's session: a fresh session per job, the histogram cache (placed by
+        engine.alloc_hist: the device's home block, found by the first job of the process), the count vector, the tables and the
+        scores allocated by the session (torch's caching allocator hands the previous job's blocks back)."""
+        last.clear()                                                       # (the previous job's session and scores are released first)
         sess = be.open_single(S, 1)
         if e is not None:
             e[0].record()
-        pid = sess.add_device(Xs, N)                                       # STEP 1: k_bin_hist (+ counts)
+        pid = sess.add_device(Xs, N, place=place)                          # STEP 1: k_bin_hist (+ counts)
         if e is not None:
             e[1].record()
         sess.ensure_acc(N)
         sess.all_reduce(d)                                                 # the single collective (144 bytes)
         if e is not None:
             e[2].record()
-        sess.finish_device(R_global, N)                                    # STEP 2 + the S1 table: k_s1_combine, no host sync
-        last["out"] = sess.scores_device(pid)                              # STEP 3
+        sess.launch(R_global, N, [pid])                                    # STEP 2 + the S1 table (k_s1_combine) + STEP 3, no host sync
+        last["out"] = sess.early_scores(pid)
         if e is not None:
             e[3].record()
+        if finish:
+            sess.finish(R_global, N)                                       # count check + table verification + exp_freq download
         last["sess"] = sess
 
     def fence():
@@ -503,11 +633,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def timed_steps(Xs, Hs, outs, steps, warmup, graph=False, events=True, session=False):
+    def timed_steps(Xs, Hs, outs, steps, warmup, graph=False, events=True, session=False, place=True, finish=False):
         """-> (wall seconds of `steps` steps, per-step event tuples or [], host enqueue times, this rank's own seconds:
         from the common start to the moment ITS last step was over, before the closing barrier)."""
         ev = [tuple(torch.cuda.Event(enable_timing=True) for _ in range(4)) for _ in range(steps)] if (events and not graph) else []
-        one = (lambda e=None: step_session(Xs, e)) if session else (lambda e=None: step_engine(Xs, Hs, outs, e))
+        one = (lambda e=None: step_session(Xs, e, place, finish)) if session else (lambda e=None: step_engine(Xs, Hs, outs, e))
         g = None
         if graph:
             # the whole step as ONE hipGraph launch: on a 1.9 M-bin shard the step is ~0.35 ms and the host side of three
@@ -549,8 +679,8 @@ def main():
     table_note = None
     if use_session:
         sess = last["sess"]
-        sess.check()                                                       # the deferred count check: sum == bins * biosamples
-        patched = sess.verify_tables()
+        sess.finish(R_global, N)                # the job's host side: count check (sum == bins * biosamples), table verification
+        patched = sess.tables_patched
         table_note = {"built_on": "device (k_s1_combine, in the launch that normalises)",
                       "float32_table_equals_numpy_reference_table": patched == 0}
         res = last["out"]
@@ -577,6 +707,15 @@ def main():
 
     # ---- several ranks: what every rank saw (K1 per launch, its own time for the K steps), gathered on rank 0
     per_rank = None
+    who = rank_identity(torch, dev, int(os.environ.get("LOCAL_RANK", "0")))
+    if world > 1:
+        whos = [None] * world
+        try:
+            dist.all_gather_object(whos, who)
+        except Exception as e:                                             # identity is a courtesy: never lose the line for it
+            whos = [who] + [{"error": repr(e)[:120]}] * (world - 1)
+    else:
+        whos = [who]
     if world > 1:
         mine = torch.tensor([hist_ms, own_dt * 1e3 / args.steps, ar_ms, rest_ms], dtype=torch.float64, device=dev)
         allv = [torch.zeros_like(mine) for _ in range(world)]
@@ -588,8 +727,11 @@ def main():
                     "skew_ms_per_step": round(float(allv[:, 1].max() - allv[:, 1].min()), 4),
                     "allreduce_ms": [round(float(v), 4) for v in allv[:, 2]],
                     "combine+score_ms": [round(float(v), 4) for v in allv[:, 3]],
+                    "ranks": whos,
                     "what": "own_ms_per_step = a rank's wall time from the common start until ITS last step had drained, over the "
                             "steps (the closing barrier excluded); skew = slowest - fastest rank"}
+    elif use_pg or os.environ.get("EPG_BENCH_WHO"):
+        per_rank = {"ranks": whos}
 
     # ---- one GPU: the other path on the same genome, and both paths on an eighth of it (the share of one of 8 GPUs)
     s1_paths = None
@@ -604,13 +746,14 @@ def main():
             # of one process can differ in that -- the comparison is about the code path, not about that draw.
             r = {}
             rows = Xs.shape[0]
-            for name, sessn in (("session", True), ("engine", False), ("session", True), ("engine", False)):
+            for name, sessn in (("session", True), ("engine", False), ("session_with_finish", True), ("session", True), ("engine", False),
+                                ("session_with_finish", True)):
                 last.clear()
                 Hs = outs = None
                 if not sessn:
-                    Hs = torch.empty((rows, S), dtype=torch.int16, device=dev)
+                    Hs = engine.alloc_hist(Xs, N, S)                       # the home the session's jobs used (free again by now)
                     outs = torch.empty((rows, S), dtype=torch.float32, device=dev)
-                t, evs, _, _ = timed_steps(Xs, Hs, outs, k, 3, session=sessn)
+                t, evs, _, _ = timed_steps(Xs, Hs, outs, k, 3, session=sessn, finish=name == "session_with_finish")
                 del Hs, outs
                 ms = round(t / k * 1e3, 4)
                 if name + "_ms_per_step" not in r or ms < r[name + "_ms_per_step"]:
@@ -619,9 +762,11 @@ def main():
             r["steps"] = k
             r["session_over_engine"] = round(r["session_ms_per_step"] / r["engine_ms_per_step"], 4)
             return r
-        s1_paths = {"what": "session = backend._HipSingleSession per job (the command line's calls and allocations); engine = bare ABI "
-                            "calls, counts re-zeroed by the score launch, on buffers taken from the allocator right after a session "
-                            "run (the same blocks: the comparison is about the code path, not about where the driver placed H)",
+        s1_paths = {"what": "session = backend._HipSingleSession per job (the product's calls and allocations: add_device, all_reduce, launch); "
+                            "session_with_finish = the same plus finish() inside every job (count check, S1 table verification against "
+                            "numpy, exp_freq download: the host synchronisation the command line has once per run); engine = bare ABI "
+                            "calls, counts re-zeroed by the score launch, histogram cache from engine.alloc_hist as well (the same "
+                            "home block: the comparison is about the code path, not about where H lies)",
                     "genome_%d_bins" % R: both(X, k)}
         rs = min(args.shard_bins, R)
         if 0 < rs < R:
@@ -651,7 +796,8 @@ def main():
     # configs 3-5) fills `placement` and `configs` in.  A watchdog on every rank bounds those extras: past --extras-deadline
     # seconds rank 0 prints the line with what it has and every rank leaves, so that a collective that never completes in a
     # secondary measurement cannot take the headline of a multi-GPU run with it.
-    placement = {"headline": ("a fresh backend._HipSingleSession per step: the command line's own calls and allocations (torch's caching allocator)"
+    placement = {"headline": ("a fresh backend._HipSingleSession per step; add_device takes the histogram cache of the resident matrix from "
+                              "engine.alloc_hist (another memory class than the matrix; found once per process, during the warm-up)"
                               if use_session else "bare ABI calls on preallocated plain torch allocations (--path engine / --graph)")}
     configs = {}
     line = None
@@ -685,7 +831,9 @@ def main():
                        "state_distribution": args.dist,
                        "row_pitch_bytes": int(X.stride(0)),
                        "step_launch": "hipGraph replay" if args.graph else "three launches + collective per step",
-                       "step_path": "session" if use_session else "engine",
+                       "step_path": ("session: add_device -> all_reduce -> launch, the sequence driver.run_single runs; its finish() (count check, "
+                                     "table verification, exp_freq download: a host sync) runs once after the timed steps -- "
+                                     "s1_paths.session_with_finish_ms_per_step has it inside every job") if use_session else "engine",
                        "partition": "contiguous bin ranges per GPU (helpers.splitRows rule), one RCCL all-reduce of int64[%d]" % S},
             "roofline": {"bound": "hbm", "kernel": "k_bin_hist", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": traffic_note,
@@ -719,51 +867,122 @@ def main():
             print(text, flush=True)
 
     def bail():
-        configs["deadline"] = "extras stopped after %d s (--extras-deadline)" % args.extras_deadline
+        # the headline is printed, then the process says what happened: exit code 3 (a hung collective in a secondary
+        # measurement must not look like a clean run); torch.distributed.run then ends the other ranks
+        configs["deadline"] = "extras stopped after %d s (--extras-deadline) in %r: exit code 3" % (args.extras_deadline, progress.get("leg"))
         emit()
         sys.stdout.flush()
-        os._exit(0)
+        sys.stderr.flush()
+        if rank != 0:
+            time.sleep(3)                                  # (the launcher ends every rank when one fails: let rank 0 print first)
+        os._exit(3)
 
+    progress = {"leg": None}
     watchdog = None
     if args.extras_deadline > 0:
         watchdog = threading.Timer(args.extras_deadline, bail)
         watchdog.daemon = True
         watchdog.start()
 
-    # ---- secondary: the histogram cache in another memory class than the matrix (not what the product does: DESIGN.md 3)
-    if args.placement_experiment and world == 1 and R * X.stride(0) >= (1 << 30) and not args.packed:   # a single-GPU experiment
+    def hang_hook(name):
+        progress["leg"] = name
+        if os.environ.get("EPG_BENCH_HANG_LEG") == name:               # tests: a secondary measurement that never returns
+            time.sleep(10 ** 6)
+
+    # ---- the same step as ONE hipGraph replay (K1, all-reduce, combine, score captured together): what is left of the step when
+    # the host side of three launches and a collective is taken out -- on an eighth of the genome that is 10 % of the step
+    if args.graph_leg and not args.graph and use_pg and args.backend != "nccl":
+        if line is not None:                                             # (a host-side backend syncs inside the collective)
+            line["graph_ms_per_step"], line["graph_error"] = None, "not captured: the %s backend's all-reduce cannot be part of a hipGraph" % args.backend
+    elif args.graph_leg and not args.graph:
+        hang_hook("graph")
         try:
-            Hp, rep = engine.place_hist(X, N, S, park=True)
-            out_p = out32 if out32 is not None else torch.empty((R, S), dtype=torch.float32, device=dev)
-            dtp, evp, _, _ = timed_steps(X, Hp, out_p, min(args.steps, 10), 2)
-            del out_p
-            rep["k_bin_hist_ms"] = round(float(np.mean([e[0].elapsed_time(e[1]) for e in evp])), 4)
-            rep["frac"] = round(R * N / (rep["k_bin_hist_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)
-            rep["ms_per_step"] = round(dtp / min(args.steps, 10) * 1e3, 4)
-            placement["experiment"] = rep
-            del Hp
+            Hg = engine.alloc_hist(X, N, S)
+            og = torch.empty((R, S), dtype=torch.float32, device=dev)
+            dtg, _, _, _ = timed_steps(X, Hg, og, args.steps, args.warmup, graph=True)
+            dtg = _max_over_ranks(torch, d, dtg, dev)
+            if line is not None:
+                line["graph_ms_per_step"] = round(dtg / args.steps * 1e3, 4)
+                line["graph_value"] = round(R_global * args.steps / dtg / 1e6, 3)
+            del Hg, og
+        except Exception as e:
+            if line is not None:
+                line["graph_ms_per_step"] = None
+                line["graph_error"] = repr(e)[:300]
+
+    # ---- RCCL self-test: every collective of the multi-rank command line against numbers (reported, never fatal)
+    if use_pg:
+        hang_hook("rccl_selftest")
+        st = rccl_selftest(torch, dist, dev, rank, world, N, S)
+        oks = torch.tensor([1 if st["ok"] else 0], dtype=torch.int32, device=dev)
+        try:
+            dist.all_reduce(oks, op=dist.ReduceOp.MIN)
+            st["ok_on_every_rank"] = bool(int(oks.item()))
+        except Exception as e:
+            st["ok_on_every_rank"] = False
+            st["error"] = repr(e)[:200]
+        if line is not None:
+            line["rccl_selftest"] = st
+
+    # ---- secondary: the same jobs with the histogram cache where a plain allocation puts it (add_device(place=False))
+    placement["report"] = engine.placement_report(dev)
+    if args.placement_experiment and world == 1 and R * X.stride(0) >= (1 << 30) and not args.packed and use_session:
+        hang_hook("unplaced")
+        try:
+            kk = min(args.steps, 10)
+            dtp, evp, _, _ = timed_steps(X, None, None, kk, 2, session=True, place=False)
+            k1p = float(np.mean([e[0].elapsed_time(e[1]) for e in evp]))
+            placement["unplaced"] = {"what": "the same jobs, histogram cache from a plain allocation (add_device(place=False): what "
+                                             "add_part's streamed parts get, and every job before round 5)", "steps": kk,
+                                     "k_bin_hist_ms": round(k1p, 4), "frac": round(R * N / (k1p * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                                     "ms_per_step": round(dtp / kk * 1e3, 4)}
+            last.clear()
         except Exception as e:                 # an experiment: never let it take the measurement down
-            placement["experiment"] = {"failed": repr(e)[:200]}
-        engine.release_parked()
+            placement["unplaced"] = {"failed": repr(e)[:200]}
 
     # ---- BASELINE configs 3-5 through the product's sessions
     want = [] if args.configs in ("none", "") else [c.strip() for c in args.configs.split(",") if c.strip()]
     if want:
         for name in want:
+            hang_hook(name)
             try:
                 if name == "s2":
                     configs["s2"] = bench_single(torch, be, d, 2, X, N, S, R, R_global, world, args.config_reps, fence)
-                elif name == "s3":
-                    r3g = min(args.s3_bins, R_global)
+                elif name in ("s3", "s3_small"):
+                    r3g = min(args.s3_small_bins, R_global) if name == "s3_small" else min(args.s3_bins or R_global, R_global)
                     lo, hi = rank * r3g // world, (rank + 1) * r3g // world
-                    configs["s3"] = bench_single(torch, be, d, 3, X[: hi - lo], N, S, hi - lo, r3g, world, args.config_reps, fence)
+                    reps3 = args.config_reps if name == "s3_small" else 1
+                    configs[name] = bench_single(torch, be, d, 3, X[: hi - lo], N, S, hi - lo, r3g, world, reps3, fence)
                 elif name == "paired":
                     configs["paired"] = bench_paired(torch, be, d, R, R_global, bin0, S, world, args.config_reps, fence, dev, args.dist)
                 else:
                     configs[name] = {"error": "unknown config"}
             except Exception as e:
                 configs[name] = {"error": repr(e)[:300]}
-            torch.cuda.empty_cache()
+
+    # ---- SURVEY 8d's distribution variants: the same job on a uniform matrix (the contention-free control) and on the
+    # row-correlated stress shape, generated into the SAME buffer (the headline's matrix is not needed any more)
+    if args.dist_variants and world == 1 and use_session and args.dist == "chr1" and line is not None:
+        hang_hook("dist_variants")
+        try:
+            dv = {"chr1 (headline)": {"k_bin_hist_ms": round(hist_ms, 4), "frac": round(R * N / (hist_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                                      "ms_per_step": round(dt / args.steps * 1e3, 4)}}
+            for name in ("uniform", "correlated", "chr1"):
+                generate_shard(torch, X, N, S, bin0, dist=name)
+                dtv, evv, _, _ = timed_steps(X, None, None, 5, 2, session=True)
+                last["sess"].finish(R_global, N)
+                k1v = float(np.mean([e[0].elapsed_time(e[1]) for e in evv]))
+                dv[name if name != "chr1" else "chr1 (again, after the variants)"] = {
+                    "k_bin_hist_ms": round(k1v, 4), "frac": round(R * N / (k1v * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                    "ms_per_step": round(dtv / 5 * 1e3, 4),
+                    "modal_state_share": round(float((X[:: max(R // 4096, 1), :N] == S - 1).float().mean().item()), 4)}
+                last.clear()
+            dv["what"] = ("5 whole S1 jobs each through the session on the same buffer (same placement): uniform states, and the "
+                          "row-correlated shape (41 % of the bins all-quiescent, 83 % of the rest copies of their predecessor); the counting "
+                          "core has no data-dependent control flow and no shared counters (csrc/epg_count.h)")
+            line["dist_variants"] = dv
+        except Exception as e:
+            line["dist_variants"] = {"error": repr(e)[:300]}
 
     if watchdog is not None:
         watchdog.cancel()

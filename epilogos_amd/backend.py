@@ -183,6 +183,8 @@ class _HipSession:
         self.tables_patched = 0
         self._pending_check = None
         self._ws3 = None                                 # S3 expected pass: ONE workspace for all parts of the session
+        self._launched = False                           # launch() ran: STEP 2 is on the device, STEP 3 of `_early` parts enqueued
+        self._early = {}                                 # part id -> its results, computed before the host-side checks
 
     @property
     def pool(self):
@@ -325,29 +327,52 @@ class _HipSession:
             self._pending_check = None
             self.be.check_counts(int(acc.sum(dtype=self.torch.int64).item()), total_rows, N, self.sal)
 
+    def launch(self, total_rows, N, pids):
+        """Everything of STEP 2 and STEP 3 that needs no host: exp_freq (and the S1 tables) on the device, then the score pass
+        of the parts `pids` -- all enqueued, no synchronisation.  finish() follows with the host side (count check, table
+        verification, exp_freq as a host array); scores() / results() then hand the parts' results out.  This is the one
+        sequence both the command line (driver.run_single / run_paired) and bench.py's step run."""
+        self.finish_device(total_rows, N)
+        self.launch_scores(pids)
+
+    def launch_scores(self, pids):
+        """The second half of launch() (for a caller that wants an event between STEP 2 and STEP 3)."""
+        self._launched = True
+        self._begin([p for p in pids if p is not None])
+
     def _finish(self, total_rows, N, shape):
-        q = self.finish_device(total_rows, N)
+        """The host side of STEP 2: the count check (the reference dies on a state outside the model, expected.py:113), the
+        device-built S1 tables against numpy's (a table that differs is replaced and the parts scored before are scored
+        again: never seen, tools/s1_table_probe.py), exp_freq as the host array that is saved."""
+        if not self._launched:
+            self.finish_device(total_rows, N)
+        self._launched = False
         self.check()
-        self.verify_tables()
-        return q.cpu().numpy().reshape(shape)
+        if self.verify_tables() and self._early:
+            self._begin(list(self._early))               # (the early results came from a table that was replaced)
+        self._settle()
+        return self.q.cpu().numpy().reshape(shape)
 
 
 class _HipSingleSession(_HipSession):
     def add_part(self, arr, N, ticket):
-        return self.add_device(self._upload(arr, N, ticket), N)
+        return self.add_device(self._upload(arr, N, ticket), N, place=False)
 
-    def add_device(self, X, N):
-        """Count pass over a RESIDENT part (what add_part does after its upload; bench.py enters here)."""
+    def add_device(self, X, N, place=True):
+        """Count pass over a RESIDENT part (bench.py and library callers enter here; add_part does after its upload).  place:
+        the histogram cache of a matrix of a GiB or more goes where engine.alloc_hist finds another memory class than the
+        matrix's (a process-lifetime home, one ~5 ms probe per device); add_part's matrices are staging copies of one file each
+        that come and go with their upload -- their histograms are plain allocations."""
         eng, S = self.eng, self.S
         self.N = max(getattr(self, "N", 0) or 0, N or 0)  # (an empty file has no width)
         if X.shape[0] == 0 or not N:                     # an empty part: nothing to count, and the ABI rejects a zero width
             self.parts.append(self.torch.empty((0, S), dtype=self.torch.int16, device=self.device) if self.sal < 3 else X)
             return len(self.parts) - 1
         if self.sal == 1:
-            H, _ = eng.bin_hist(X, N, S, counts=self._acc(S))
+            H, _ = eng.bin_hist(X, N, S, counts=self._acc(S), H=eng.alloc_hist(X, N, S) if place else None)
             self.parts.append(H)
         elif self.sal == 2:
-            H, _ = eng.bin_hist(X, N, S, want_counts=False)
+            H, _ = eng.bin_hist(X, N, S, want_counts=False, H=eng.alloc_hist(X, N, S) if place else None)
             eng.hist_s2_from_binhist(H, S, counts=self._acc(S * S))
             self.parts.append(H)
         elif self.sal == 3:
@@ -415,8 +440,22 @@ class _HipSingleSession(_HipSession):
     def _s1_widths(self):
         return [getattr(self, "N", None)]
 
+    def _begin(self, pids):
+        self._early = {pid: self.scores_device(pid, keep=True) for pid in pids if self.parts[pid] is not None}
+
+    def _settle(self):
+        for pid in self._early:                          # verified: the resident data of the scored parts can go
+            self.parts[pid] = None
+
+    def early_scores(self, pid):
+        """Device tensor of a part scored by launch() (bench.py: the scores stay in HBM)."""
+        return self._early[pid]
+
     def scores(self, pid):
         self.check()
+        if pid in self._early:
+            self.parts[pid] = None
+            return self._early.pop(pid).cpu().numpy()
         return self.scores_device(pid).cpu().numpy()
 
 
@@ -581,7 +620,7 @@ class _HipPairedSession(_HipSession):
         quies = eng.quiescent_from_binhist(HA, NA, HB, NB, S, self.qstate)
         return {"delta": delta, "null": null, "quies": quies, "rdist": rdist, "mdiff": mdiff}
 
-    def results_device_all(self, pids):
+    def results_device_all(self, pids, keep=False):
         """results_device of several parts at once.  Paired S1 (the tables fit a CU's LDS): ONE launch of the fused pass over all the
         parts' histograms, quiescence masks included (epg_pair_scores_s1_parts) -- a launch per chromosome file paid the copy of
         the tables into LDS, the ramp and the tail 24 times (1.5 against 1.0 ms per 15 M bins).  Otherwise part by part."""
@@ -601,14 +640,29 @@ class _HipPairedSession(_HipSession):
                 res = eng.pair_scores_s1_parts(quads, S, NA, NB, ga, gb, *tabs, qstate=self.qstate)
                 for pid, r in zip(live, res):
                     out[pid] = r
-                    self.parts[pid] = None
+                    if not keep:
+                        self.parts[pid] = None
             except eng.EpilogosHipError as e:
                 if e.code != -2:
                     raise
         for pid in pids:
             if pid not in out:
-                out[pid] = self.results_device(pid)
+                out[pid] = self.results_device(pid, keep=keep)
         return [out[pid] for pid in pids]
+
+    def _todo(self):
+        return [k for k, part in enumerate(self.parts) if part is not None and len(part) == 6 and (part[4] is not None or not part[2].shape[0])]
+
+    def _begin(self, pids):
+        todo = [pid for pid in pids if pid in set(self._todo())]
+        self._early = dict(zip(todo, self.results_device_all(todo, keep=True)))
+
+    def _settle(self):
+        for pid in self._early:
+            self.parts[pid] = None
+        if self._early:
+            self._ready = dict(self._early) if self._ready is None else dict(self._ready, **self._early)
+        self._early = {}
 
     def _s1_widths(self):
         NA, NB = getattr(self, "NA", None), getattr(self, "NB", None)
@@ -619,7 +673,7 @@ class _HipPairedSession(_HipSession):
         results_device_all); the parts are then downloaded one by one as the driver asks for them."""
         self.check()
         if self._ready is None:
-            todo = [k for k, part in enumerate(self.parts) if part is not None and len(part) == 6 and (part[4] is not None or not part[2].shape[0])]
+            todo = self._todo()
             self._ready = dict(zip(todo, self.results_device_all(todo)))
         r = self._ready.pop(pid) if pid in self._ready else self.results_device(pid)
         return {"delta": r["delta"].cpu().numpy(), "null": r["null"].cpu().numpy(), "quies": r["quies"].cpu().numpy().astype(bool),

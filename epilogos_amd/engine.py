@@ -39,86 +39,136 @@ def alloc_states(R, N, device="cuda"):
     return torch.empty((R, padded_width(N)), dtype=torch.int8, device=device)
 
 
-_parked = []
+# ---- where the histogram cache of a RESIDENT matrix goes
+PLACE_MIN_BYTES = 1 << 30           # a matrix under 1 GiB is counted in < 0.2 ms: not worth a probe
+PLACE_GOOD = 1.12                   # K1 with the H store / K1 counts only: <= this = "H is in another memory class than X"
+PLACE_BLOCK = 4 << 30               # candidates are the heads of blocks of this size (see alloc_hist)
+PLACE_TRIES = 16
+_placement = {}                     # device index -> {"key", "home", "report"}
 
 
-def place_hist(X, N, S, tries=None, block_bytes=None, park=False):
-    """The [R, S] uint16 histogram cache for a RESIDENT state matrix X, allocated in another memory CLASS than X.
+def _storage_users(t):
+    """Tensors (views included) alive on t's storage, or None when this torch cannot tell."""
+    f = getattr(torch._C, "_storage_Use_Count", None)
+    if f is None:
+        return None
+    return int(f(t.untyped_storage()._cdata)) - 1            # (the wrapper made by untyped_storage() counts as one)
+
+
+def _probe_slices(R, rows=1 << 20):
+    """Three row ranges of a matrix (head, middle, tail; a fifth of a genome in all) the class probe runs on: a matrix may
+    straddle two memory classes, a histogram cache is good only if it is in neither.  Starts are multiples of 32 bins (whole
+    super-tiles, 16-byte aligned histogram rows)."""
+    m = min(rows, R // 3) // 32 * 32
+    if m <= 0:
+        return [(0, R)]
+    return [(0, m), ((R - m) // 2 // 32 * 32, (R - m) // 2 // 32 * 32 + m), ((R - m) // 32 * 32, (R - m) // 32 * 32 + m)]
+
+
+def _probe_ms(X, N, S, Hflat, counts, slices, reps=3):
+    """Device time of k_bin_hist over `slices` of X, histogram rows into the same rows of the candidate `Hflat` (None = counts
+    only); one untimed pass first."""
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    H = None if Hflat is None else Hflat[:X.shape[0] * S * 2].view(torch.int16).view(X.shape[0], S)
+    for k in range(reps + 1):
+        if k == 1:
+            ev[0].record()
+        for lo, hi in slices:
+            bin_hist(X[lo:hi], N, S, counts=counts, H=None if H is None else H[lo:hi], want_hist=H is not None)
+    ev[1].record()
+    ev[1].synchronize()
+    return ev[0].elapsed_time(ev[1]) / reps
+
+
+def alloc_hist(X, N, S):
+    """The [R, S] uint16 histogram cache (int16 storage) for a RESIDENT state matrix X, in another memory CLASS than X.
+
     The 288 GB of an MI355X fall into three classes of a third each, in contiguous runs of 4-64 GiB of the driver's
-    allocation order (tools/placement_map.py, placement_map2.py; profiles/r02ae_*: 21 + 21 + 21 of 70 blocks of 4 GiB, the
-    rest straddle a boundary).  k_bin_hist reads X and writes H: with both in one class it runs 17 % slower (0.88 against
-    0.75 ms per 4 GiB block; 2.39-2.66 against 2.21-2.31 ms for 15 M x 833) whatever the offsets, the data or the other
-    buffers are -- a write burst into the class that is being read costs the reads more than one into another class -- while
-    a copy kernel sees 7 % and the score pass nothing.  HIP does not tell the class of an allocation, so the classifier is the
-    kernel itself: blocks of `block_bytes` (4 GiB; 1 GiB for a matrix under 4 GiB) are allocated one after the other -- held,
-    so that the driver walks on through its memory -- and the head of each is tried as H with four launches of the real kernel;
-    the first whose store costs < 13 % over the counts-only launch (or that is 7 % faster than an earlier block) is kept, else
-    the best; the other blocks go back to the driver.  H is a view of its block (the block's tail stays allocated with it).  Returns (H, report).
-    park=True keeps the other blocks allocated until `release_parked()`: device memory that goes back to the driver is scrubbed
-    in the background (~30 GB/s), and while that lasts every HBM-bound kernel runs ~5 % slower (bench.py: the first ~100 steps
-    after 8 GiB were returned, 2.45 against 2.32 ms) -- a measurement that follows the search should not pay for it.
-    EPILOGOS_PLACEMENT_TRIES overrides `tries` (default 40 blocks; 1 = a plain allocation); a matrix under 1 GiB is not worth it."""
+    allocation order (profiles/r02ae_k1_memory_class_map.txt).  k_bin_hist reads X and writes H: with both in one class the
+    launch is 13-17 % slower (2.6 against 2.3 ms for 15 M x 833) whatever the offsets, the data or the other buffers are.  HIP
+    does not tell the class of an allocation, so the classifier is the kernel itself, on three 1 M-bin slices of X (head,
+    middle, tail: 0.5 ms per pass): a candidate is good when the launches with the H store cost < 12 % over the counts-only
+    launches (measured: 1.06-1.10 in another class, 1.14-1.18 in the same, profiles/r05a_placement_spread.txt).
+    Candidates are the HEADS OF 4 GiB BLOCKS allocated one after the other and held during the search: the driver serves a
+    small allocation from the smallest free fragment that fits -- the crumbs the matrix's own allocation left behind, i.e.
+    next to the matrix whatever else is held (first version of this search: four H-sized candidates behind 8 / 16 / 32 GiB
+    spacers, all four in the matrix's class in two processes of six) -- while 4 GiB blocks make it walk through its memory.
+    The first good block becomes the HOME of this device's histogram caches for the life of the process (H is a view of its
+    head): every later job on the same matrix gets it without a probe, a job on another matrix after one probe (~2 ms).  The
+    blocks that were not picked go to torch's caching allocator the moment the search is over, from where the job's other
+    buffers are carved: nothing is returned to the driver (freed device memory is scrubbed in the background at every
+    HBM-bound kernel's expense), nothing is withheld from the process but the home block.
+    While a view of the home is alive (another session still holds its parts) the next request gets a plain allocation.
+    EPILOGOS_PLACEMENT=0 switches the search off; EPILOGOS_PLACEMENT_TRIES bounds it (default 16 blocks)."""
     import os
     R = X.shape[0]
     dev = X.device
-    if tries is None:
-        tries = int(os.environ.get("EPILOGOS_PLACEMENT_TRIES", "40"))
-    if tries <= 1 or X.numel() < (1 << 30):
-        return torch.empty((R, S), dtype=torch.int16, device=dev), {"tries": 1}
     hbytes = R * S * 2
-    if block_bytes is None:
-        block_bytes = (4 << 30) if X.numel() >= (4 << 30) else (1 << 30)
-    block_bytes = max(block_bytes, (hbytes + 4095) // 4096 * 4096)
+    plain = lambda: torch.empty((R, S), dtype=torch.int16, device=dev)
+    if X.numel() < PLACE_MIN_BYTES or os.environ.get("EPILOGOS_PLACEMENT", "1") == "0":
+        return plain()
+    st = _placement.get(dev.index)
+    stor = X.untyped_storage()
+    key = (stor.data_ptr(), stor.nbytes())
+    view = lambda home: home[:hbytes].view(torch.int16).view(R, S)
+    if st is not None and st["home"].numel() >= hbytes:
+        users = _storage_users(st["home"])
+        if users is None or users > 1:
+            st["report"]["plain_while_home_in_use"] = st["report"].get("plain_while_home_in_use", 0) + 1
+            return plain()
+        if st["key"] == key:
+            st["report"]["reuses"] += 1
+            return view(st["home"])
     counts = zeros_counts(S, device=dev)
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
-
-    def timed(H):
-        bin_hist(X, N, S, counts=counts, H=H, want_hist=H is not None)
-        ev[0].record()
-        for _k in range(3):
-            bin_hist(X, N, S, counts=counts, H=H, want_hist=H is not None)
-        ev[1].record()
-        torch.cuda.synchronize()
-        return ev[0].elapsed_time(ev[1]) / 3
-
-    base = timed(None)
-    blocks, times = [], []
-    for t in range(tries):
-        # the rest of the job (score output 2x H, tables) must still fit after the walk: keep 8x H + 4 GiB free
+    slices = _probe_slices(R)
+    base = _probe_ms(X, N, S, None, counts, slices)
+    tried = []
+    if st is not None and st["home"].numel() >= hbytes:      # another matrix: is the home good for it too?
+        ms = _probe_ms(X, N, S, st["home"], counts, slices)
+        if ms <= PLACE_GOOD * base:
+            st["key"] = key
+            st["report"].update(revalidated=st["report"].get("revalidated", 0) + 1, ratio=round(ms / base, 3))
+            return view(st["home"])
+        tried.append((st["home"], ms))
+    _placement.pop(dev.index, None)
+    block = max(PLACE_BLOCK, (hbytes + 4095) // 4096 * 4096)
+    cand = None
+    for k in range(int(os.environ.get("EPILOGOS_PLACEMENT_TRIES", PLACE_TRIES))):
         free, _total = torch.cuda.mem_get_info(dev)
-        if blocks and free < block_bytes + 8 * hbytes + (4 << 30):
+        if tried and free < block + 16 * hbytes + (8 << 30):   # the rest of the job must still fit after the walk
             break
         try:
-            blocks.append(torch.empty(block_bytes, dtype=torch.int8, device=dev))
-        except RuntimeError:                               # out of device memory: make do with what there is
+            cand = torch.empty(block, dtype=torch.int8, device=dev)
+        except RuntimeError:
             break
-        times.append(timed(blocks[-1][:hbytes].view(torch.int16).view(R, S)))
-        # good enough: the store costs < 13 % over the counts-only launch (wide matrices), or this block is clearly in another
-        # class than an earlier, slower one (narrow matrices, where the store is never that small against the reads)
-        if times[-1] < 1.13 * base or (len(times) >= 2 and times[-1] <= 0.93 * max(times)):
+        tried.append((cand, _probe_ms(X, N, S, cand, counts, slices)))
+        if tried[-1][1] <= PLACE_GOOD * base:
             break
-    if not blocks:
+    if not tried:
         raise RuntimeError("out of device memory for the histogram cache")
-    pick = min(range(len(blocks)), key=lambda i: times[i])
-    H = blocks[pick][:hbytes].view(torch.int16).view(R, S)
-    shown = times if len(times) <= 12 else times[:4] + times[-8:]
-    report = {"blocks_tried": len(blocks), "block_GiB": round(block_bytes / 2**30, 2), "picked": pick,
-              "ms_counts_only": round(base, 3), "ms_picked": round(times[pick], 3),
-              "ms_with_H" + ("" if len(times) <= 12 else "_first4_last8"): [round(v, 3) for v in shown]}
-    if park:
-        _parked.extend(b for i, b in enumerate(blocks) if i != pick)
-        report["parked_GiB"] = round(sum(b.numel() for b in _parked) / 2**30, 1)
-        del blocks, counts
-        return H, report
-    del blocks, counts
-    torch.cuda.empty_cache()
-    return H, report
+    pick = min(range(len(tried)), key=lambda i: tried[i][1])
+    home = tried[pick][0]
+    ratios = [round(ms / base, 3) for _c, ms in tried]
+    report = {"probe": "k_bin_hist over 3 x %d bins of the matrix, with the store into the candidate / counts only" % (slices[0][1] - slices[0][0]),
+              "ms_counts_only": round(base, 4), "blocks_tried": len(tried), "block_GiB": round(block / 2**30, 2),
+              "ratios": ratios if len(ratios) <= 12 else ratios[:4] + ["..."] + ratios[-6:], "picked": pick,
+              "good": bool(tried[pick][1] <= PLACE_GOOD * base), "ratio": round(tried[pick][1] / base, 3), "reuses": 0,
+              "left_in_torch_cache_GiB": round(sum(c.numel() for i, (c, _m) in enumerate(tried) if i != pick) / 2**30, 1)}
+    _placement[dev.index] = {"key": key, "home": home, "report": report}
+    del tried, cand                                          # the other blocks -> torch's cache (not the driver)
+    return view(home)
 
 
-def release_parked():
-    """Hand the blocks a `place_hist(..., park=True)` search did not keep back to the driver."""
-    _parked.clear()
-    torch.cuda.empty_cache()
+def placement_report(device=None):
+    """What alloc_hist did on this device (None: it never searched)."""
+    idx = torch.cuda.current_device() if device is None else torch.device(device).index
+    st = _placement.get(idx)
+    return None if st is None else dict(st["report"])
+
+
+def release_placement():
+    """Forget the home (its memory goes to torch's cache)."""
+    _placement.clear()
 
 
 def states_to_device(x, device="cuda"):

@@ -77,6 +77,9 @@ class _HostSession:
     def all_reduce(self, d):
         self.counts = d.all_reduce_counts(self.counts)
 
+    def launch(self, total_rows, N, pids):
+        pass                                           # (the host stand-in has nothing to enqueue ahead of its checks)
+
     def _finish(self, total_rows, N, shape):
         self.be.check_counts(self.counts, total_rows, N, self.sal)
         self.q = self.be.normalise(self.counts)

@@ -87,3 +87,38 @@ def test_chromosome_parts_cover_a_ranks_range_exactly():
         assert all(a[3] == b[2] for a, b in zip(seen, seen[1:])) and seen[0][2] == 0 and seen[-1][3] == R
     # the key is (file, row): rows of one file ascend, files do not collide below 2^40 rows
     assert shuffle_key(3, 17) == (3 << 40) + 17 and shuffle_key(0, (1 << 40) - 1) < shuffle_key(1, 0)
+
+
+def test_collective_selftest_two_gloo_ranks(tmp_path):
+    """bench.rccl_selftest (every collective the multi-rank command line uses, checked against numbers) on two gloo ranks,
+    host tensors: the leg that will explain the first real 8-GPU run must itself be right -- and must report a wrong
+    result instead of raising."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+    from tests.conftest import free_port
+    root = Path(bench.__file__).resolve().parent
+    script = tmp_path / "selftest.py"
+    script.write_text(
+        "import json, os, sys\n"
+        "sys.path.insert(0, %r)\n"
+        "import torch, torch.distributed as dist\n"
+        "import bench\n"
+        "dist.init_process_group(backend='gloo')\n"
+        "rank, world = dist.get_rank(), dist.get_world_size()\n"
+        "st = bench.rccl_selftest(torch, dist, torch.device('cpu'), rank, world, 61, 18)\n"
+        "open(os.path.join(%r, 'st_%%d.json' %% rank), 'w').write(json.dumps(st))\n"
+        "dist.destroy_process_group()\n" % (str(root), str(tmp_path)))
+    env = dict(os.environ, PYTHONPATH=str(root))
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR"):
+        env.pop(k, None)
+    res = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", str(free_port()), str(script)], env=env, capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stdout + res.stderr[-3000:]
+    sts = [json.loads((tmp_path / ("st_%d.json" % r)).read_text()) for r in range(2)]
+    for st in sts:
+        assert st["ok"] and st["world"] == 2 and st["backend"] == "gloo"
+        legs = [k for k, v in st.items() if isinstance(v, dict)]
+        assert len(legs) == 6 and all(st[k]["ok"] for k in legs)
