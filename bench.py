@@ -619,12 +619,13 @@ def main():
         sess.all_reduce(d)                                                 # the single collective (144 bytes)
         if e is not None:
             e[2].record()
-        sess.launch(R_global, N, [pid])                                    # STEP 2 + the S1 table (k_s1_combine) + STEP 3, no host sync
+        total = R_global if Xs.shape[0] == R else Xs.shape[0]              # (the one-GPU shard measurement is a job of its own)
+        sess.launch(total, N, [pid])                                       # STEP 2 + the S1 table (k_s1_combine) + STEP 3, no host sync
         last["out"] = sess.early_scores(pid)
         if e is not None:
             e[3].record()
         if finish:
-            sess.finish(R_global, N)                                       # count check + table verification + exp_freq download
+            sess.finish(total, N)                                       # count check + table verification + exp_freq download
         last["sess"] = sess
 
     def fence():
