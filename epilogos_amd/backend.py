@@ -466,6 +466,7 @@ class _HipPairedSession(_HipSession):
         super().__init__(be, S, saliency)
         self.qstate, self.groupSize, self.seed = quiescentState, groupSize, seed
         self._ready = None                               # results of all parts, computed at the first results() call
+        self._pending, self._pending_rows = [], 0        # parts whose count pass has not been launched yet (see add_staged)
         if getattr(be, "_null_stream", None) is None:    # one second stream per backend, not per session
             prio = os.environ.get("EPILOGOS_NULL_PRIORITY")
             be._null_stream = (self.torch.cuda.Stream(device=self.device) if prio is None else
@@ -478,67 +479,99 @@ class _HipPairedSession(_HipSession):
         return self._upload(arr, N, ticket)
 
     def set_row0(self, pid, row0):
+        self._flush()
         XA, XB, HA, HB, _, null = self.parts[pid]
         self.parts[pid] = (XA, XB, HA, HB, row0, null)
         if null is None and HA.shape[0]:
-            self._start_null(pid)
+            self._start_null([pid])
 
     def add_part(self, arrA, NA, ticketA, arrB, NB, ticketB, row0):
         return self.add_staged(self._upload(arrA, NA, ticketA), NA, self._upload(arrB, NB, ticketB), NB, row0)
 
+    # a batch of parts is counted in ONE launch (epg_bin_hist_parts over the A and the B matrices of all its parts) and its null
+    # groups are drawn in ONE launch on the second stream, under the count pass of the next batch (the sampler is VALU-bound,
+    # the count pass HBM-bound: tools/overlap_probe.py).  Round 4 launched per part: 2 x 24 count passes of ~80 us and 24 samplers
+    # for a genome, each with its ramp and tail -- the count phase of BASELINE config 5 ran at 0.36 of its bytes.
+    BATCH_ROWS = int(os.environ.get("EPILOGOS_PAIR_BATCH_ROWS", 2_000_000))
+
     def add_staged(self, XA, NA, XB, NB, row0):
-        """Count pass over one part's two groups.  row0 keys the null shuffle of the part's first row: the driver passes
-        (file ordinal << 40) + row in the file -- known the moment a file is parsed, whatever the partition -- so the null
-        groups are drawn at once, on a second stream, while the next part is counted (the sampler is VALU-bound, the count
-        pass HBM-bound: tools/overlap_probe.py)."""
-        eng, S = self.eng, self.S
+        """One part's two groups, resident.  row0 keys the null shuffle of the part's first row: the driver passes
+        (file ordinal << 40) + row in the file -- known the moment a file is parsed, whatever the partition.  The part joins
+        the pending batch; the batch is launched when it holds BATCH_ROWS rows (an eighth of a genome: a streaming run still
+        counts while it parses, a resident genome takes seven count launches and seven sampler launches instead of 48 + 24;
+        1 / 2 / 3 / 4 M rows measured 5.04 / 5.05 / 5.12 / 5.10 ms per 15 M-bin job, one batch 6.1) or when anything needs
+        its histograms."""
+        S = self.S
         # widths of the widest part seen: an empty file pair (no columns) must not be the one that is remembered
         self.NA, self.NB = max(getattr(self, "NA", 0) or 0, NA or 0), max(getattr(self, "NB", 0) or 0, NB or 0)
         if XA.shape[0] == 0 or not NA or not NB:         # nothing to count (and the ABI rejects a zero width)
             self.parts.append((XA, XB, self.torch.empty((0, S), dtype=self.torch.int16, device=self.device),
                                self.torch.empty((0, S), dtype=self.torch.int16, device=self.device), row0, None))
             return len(self.parts) - 1
-        if self.sal == 1:                                # counts over [A|B] = counts of A + counts of B (helpers.py:173)
-            HA, _ = eng.bin_hist(XA, NA, S, counts=self._acc(S))
-            HB, _ = eng.bin_hist(XB, NB, S, counts=self._acc(S))
-        else:
-            HA, _ = eng.bin_hist(XA, NA, S, want_counts=False)
-            HB, _ = eng.bin_hist(XB, NB, S, want_counts=False)
-            eng.hist_s2_from_binhist_pair(HA, HB, S, counts=self._acc(S * S))
-        self.parts.append((XA, XB, HA, HB, row0, None))
+        self.parts.append((XA, XB, None, None, row0, None))
         pid = len(self.parts) - 1
-        if row0 is not None:
-            self._start_null(pid)
+        self._pending.append((pid, NA, NB))
+        self._pending_rows += XA.shape[0]
+        if self._pending_rows >= self.BATCH_ROWS:
+            self._flush()
         return pid
 
-    def _start_null(self, pid):
-        """The null groups' histograms of part `pid` (multivariate hypergeometric, from the real groups' histograms; they do
-        not depend on exp_freq) on the session's second stream, behind the launches that produce HA / HB."""
+    def _flush(self):
+        """Count pass of the pending batch (one launch), then its null groups (one launch on the second stream)."""
+        if not self._pending:
+            return
+        eng, S = self.eng, self.S
+        batch, self._pending, self._pending_rows = self._pending, [], 0
+        XAs = [self.parts[pid][0] for pid, _na, _nb in batch]
+        XBs = [self.parts[pid][1] for pid, _na, _nb in batch]
+        widths = [na for _p, na, _nb in batch] + [nb for _p, _na, nb in batch]
+        k = len(batch)
+        if self.sal == 1:                                # counts over [A|B] = counts of A + counts of B (helpers.py:173)
+            Hs, _ = eng.bin_hist_parts(XAs + XBs, widths, S, counts=self._acc(S))
+        else:
+            Hs, _ = eng.bin_hist_parts(XAs + XBs, widths, S, counts=None)
+            for i in range(k):
+                eng.hist_s2_from_binhist_pair(Hs[i], Hs[k + i], S, counts=self._acc(S * S))
+        for i, (pid, _na, _nb) in enumerate(batch):
+            XA, XB, _ha, _hb, row0, null = self.parts[pid]
+            self.parts[pid] = (XA, XB, Hs[i], Hs[k + i], row0, null)
+        self._start_null([pid for pid, _na, _nb in batch if self.parts[pid][4] is not None])
+
+    def _start_null(self, pids):
+        """The null groups' histograms of the parts `pids` (multivariate hypergeometric, from the real groups' histograms; they
+        do not depend on exp_freq): one launch on the session's second stream, behind the launch that produced HA / HB."""
+        if not pids:
+            return
         t, eng = self.torch, self.eng
-        XA, XB, HA, HB, row0, _ = self.parts[pid]
         NA, NB = self.NA, self.NB
         ga, gb = (NA, NB) if self.groupSize == -1 else (self.groupSize, self.groupSize)
-        main = t.cuda.current_stream()
-        if self.null_stream is None or os.environ.get("EPILOGOS_NULL_OVERLAP", "1") == "0":
-            HnA, HnB = eng.null_hist_from_binhist(HA, HB, NA + NB, self.S, ga, gb, self.seed, row0)
-            self.parts[pid] = (XA, XB, HA, HB, row0, (HnA, HnB, None))
-            return
-        # outputs from the main stream's pool (a second stream has a pool of its own in torch's allocator: every new session
-        # would start with device mallocs), launch on the second stream between two events, no stream switch on the host
-        ready = t.cuda.Event()
-        ready.record(main)
-        self.null_stream.wait_event(ready)
-        HnA, HnB = eng.null_hist_from_binhist(HA, HB, NA + NB, self.S, ga, gb, self.seed, row0, stream=self.null_stream)
-        done = t.cuda.Event()
-        done.record(self.null_stream)
-        for x in (HA, HB, HnA, HnB):
-            x.record_stream(self.null_stream)            # used there: their memory must not be reused before it is through
-        self.parts[pid] = (XA, XB, HA, HB, row0, (HnA, HnB, done))
+        HAs, HBs = [self.parts[p][2] for p in pids], [self.parts[p][3] for p in pids]
+        row0s = [self.parts[p][4] for p in pids]
+        overlap = self.null_stream is not None and os.environ.get("EPILOGOS_NULL_OVERLAP", "1") != "0"
+        done = None
+        if overlap:
+            # outputs from the main stream's pool (a second stream has a pool of its own in torch's allocator: every new session
+            # would start with device mallocs), launch on the second stream between two events, no stream switch on the host
+            main = t.cuda.current_stream()
+            ready = t.cuda.Event()
+            ready.record(main)
+            self.null_stream.wait_event(ready)
+            HnAs, HnBs = eng.null_hist_from_binhist_parts(HAs, HBs, NA + NB, self.S, ga, gb, self.seed, row0s, stream=self.null_stream)
+            done = t.cuda.Event()
+            done.record(self.null_stream)
+            for x in (HAs[0], HBs[0], HnAs[0], HnBs[0]):
+                x.record_stream(self.null_stream)        # used there: their memory must not be reused before it is through
+        else:
+            HnAs, HnBs = eng.null_hist_from_binhist_parts(HAs, HBs, NA + NB, self.S, ga, gb, self.seed, row0s)
+        for i, p in enumerate(pids):
+            XA, XB, HA, HB, row0, _ = self.parts[p]
+            self.parts[p] = (XA, XB, HA, HB, row0, (HnAs[i], HnBs[i], done))
 
     def _null_of(self, pid):
         """(HnA, HnB) of part `pid`, ready for the current stream."""
+        self._flush()
         if self.parts[pid][5] is None:
-            self._start_null(pid)
+            self._start_null([pid])
         HnA, HnB, done = self.parts[pid][5]
         if done is not None:
             self.torch.cuda.current_stream().wait_event(done)
@@ -548,6 +581,7 @@ class _HipPairedSession(_HipSession):
     n_export = 2
 
     def slice_part(self, pid, lo, hi, row0=None):
+        self._flush()
         _XA, _XB, HA, HB, _, null = self.parts[pid]
         self.parts.append((None, None, _aligned_rows(HA, lo, hi), _aligned_rows(HB, lo, hi), row0, None))
         new = len(self.parts) - 1
@@ -558,6 +592,7 @@ class _HipPairedSession(_HipSession):
         return new
 
     def export_rows(self, pid, lo, hi):
+        self._flush()
         _XA, _XB, HA, HB, _, _null = self.parts[pid]
         return [HA[lo:hi], HB[lo:hi]]
 
@@ -566,14 +601,24 @@ class _HipPairedSession(_HipSession):
         self.parts.append((None, None, tensors[0].to(self.device), tensors[1].to(self.device), row0, None))
         pid = len(self.parts) - 1
         if row0 is not None and self.parts[pid][2].shape[0]:
-            self._start_null(pid)
+            self._start_null([pid])
         return pid
 
     def drop_part(self, pid):
+        self._flush()
         self.parts[pid] = None
 
     def ensure_acc(self, N):
+        self._flush()
         self._acc(self.S if self.sal == 1 else self.S * self.S)
+
+    def all_reduce(self, d):
+        self._flush()
+        super().all_reduce(d)
+
+    def finish_device(self, total_rows, N):
+        self._flush()
+        return super().finish_device(total_rows, N)
 
     def finish(self, total_rows, N):
         S = self.S
@@ -582,6 +627,7 @@ class _HipPairedSession(_HipSession):
     def results_device(self, pid, keep=False):
         """Scores of A, B and the two null groups, deltas, null distances, STEP 4's per-bin reduction and the quiescence mask
         of part `pid` from its resident histograms, as device tensors."""
+        self._flush()
         eng, S, NA, NB, q = self.eng, self.S, self.NA, self.NB, self.q
         XA, XB, HA, HB, row0, _null = self.parts[pid]
         if HA.shape[0] and row0 is None:
@@ -624,6 +670,7 @@ class _HipPairedSession(_HipSession):
         """results_device of several parts at once.  Paired S1 (the tables fit a CU's LDS): ONE launch of the fused pass over all the
         parts' histograms, quiescence masks included (epg_pair_scores_s1_parts) -- a launch per chromosome file paid the copy of
         the tables into LDS, the ramp and the tail 24 times (1.5 against 1.0 ms per 15 M bins).  Otherwise part by part."""
+        self._flush()
         eng, S, NA, NB = self.eng, self.S, getattr(self, "NA", None), getattr(self, "NB", None)
         out = {}
         live = [pid for pid in pids if self.parts[pid] is not None and self.parts[pid][2].shape[0]]
@@ -651,6 +698,7 @@ class _HipPairedSession(_HipSession):
         return [out[pid] for pid in pids]
 
     def _todo(self):
+        self._flush()
         return [k for k, part in enumerate(self.parts) if part is not None and len(part) == 6 and (part[4] is not None or not part[2].shape[0])]
 
     def _begin(self, pids):

@@ -57,6 +57,11 @@ int null_hist_from_binhist_impl(const uint16_t*, const uint16_t*, int64_t, int32
                                 uint16_t*, hipStream_t);
 
 int quiescent_from_binhist_impl(const uint16_t*, const uint16_t*, int64_t, int32_t, int32_t, int32_t, int32_t, uint8_t*, hipStream_t);
+int bin_hist_parts_impl(int32_t, const int8_t* const*, const int64_t*, const int32_t*, const int64_t*, int32_t, uint16_t* const*, int64_t*, hipStream_t);
+int null_hist_parts_impl(int32_t, const uint16_t* const*, const uint16_t* const*, const int64_t*, int32_t, int32_t, int32_t, int32_t, uint64_t,
+                         const int64_t*, uint16_t* const*, uint16_t* const*, hipStream_t);
+
+int g_force[FORCE_COUNT] = {0};
 
 }  // namespace epg
 
@@ -73,6 +78,12 @@ int epg_debug_set_variant(int variant, int blocks_per_cu) {
     return EPG_OK;
 }
 
+int epg_test_force(int32_t which, int32_t value) {
+    if (which < 0 || which >= FORCE_COUNT) return fail(EPG_ERR_INVALID_ARG, "test_force: unknown switch %d", which);
+    g_force[which] = value;
+    return EPG_OK;
+}
+
 int epg_version(void) { return EPG_ABI_VERSION; }
 const char* epg_last_error(void) { return g_err; }
 
@@ -84,6 +95,17 @@ int epg_device_cus(void) {
 
 int epg_bin_hist(const int8_t* X, int64_t R, int32_t N, int64_t ldx, int32_t S, uint16_t* H, int64_t* counts, void* stream) {
     return bin_hist_impl(X, R, N, ldx, S, H, counts, (hipStream_t)stream);
+}
+
+int epg_bin_hist_parts(int32_t nparts, const int8_t* const* X, const int64_t* R, const int32_t* N, const int64_t* ldx, int32_t S,
+                       uint16_t* const* H, int64_t* counts, void* stream) {
+    return bin_hist_parts_impl(nparts, X, R, N, ldx, S, H, counts, (hipStream_t)stream);
+}
+
+int epg_null_hist_from_binhist_parts(int32_t nparts, const uint16_t* const* HA, const uint16_t* const* HB, const int64_t* R, int32_t S,
+                                     int32_t n_cols, int32_t ga, int32_t gb, uint64_t seed, const int64_t* row0, uint16_t* const* OA,
+                                     uint16_t* const* OB, void* stream) {
+    return null_hist_parts_impl(nparts, HA, HB, R, S, n_cols, ga, gb, seed, row0, OA, OB, (hipStream_t)stream);
 }
 
 int epg_hist_s1(const int8_t* X, int64_t R, int32_t N, int64_t ldx, int32_t S, int64_t* counts, void* stream) {

@@ -16,6 +16,13 @@ namespace epg {
 int fail(int code, const char* fmt, ...);
 int num_cus();
 
+// Several entry points have a FALLBACK kernel that other shapes take (wider models, rows too long for the fast kernel's LDS
+// budget, calls too small for the reduced contraction ...).  The tests must be able to run a fallback on THEIR small shapes and
+// compare it with the default: epg_test_force(which, value) (epg_abi.hip; declared in the header as a test hook) sets one of
+// these, 0 = the library decides.  There is no environment variable in any dispatch path of the default build.
+enum Force { FORCE_NULL_SEQ = 0, FORCE_S3_SCORE_BINS, FORCE_S3_CONTRACTION, FORCE_S3_HIST_LDS, FORCE_COUNT };
+extern int g_force[FORCE_COUNT];
+
 #define EPG_HIP(expr)                                                                         \
     do {                                                                                      \
         hipError_t _e = (expr);                                                               \

@@ -192,6 +192,58 @@ __device__ __forceinline__ void tile_loop(const char* __restrict__ X, long R, in
     }
 }
 
+// The same loop over SEVERAL matrices ("parts": the chromosome files of a genome, both groups of a paired run) in one launch:
+// the parts' pointers and shapes travel in the kernel argument, super-tiles are numbered through the parts in order (a
+// super-tile never straddles two parts), a wave's super-tile index ascends, so its part only moves forward.  enter(part)
+// tells the caller which part the following epilogue / finish calls belong to.  Every part must have a width in the
+// instantiation's range (128 (NG - 1) < N <= 128 NG, or NG == 0).
+constexpr int KH_MAXP = 48;
+struct KhParts {
+    const char* x[KH_MAXP];
+    u16* h[KH_MAXP];                       // (not used by the loop: the caller's enter() picks it up)
+    long rows[KH_MAXP];
+    long ldx[KH_MAXP];
+    long st0[KH_MAXP + 1];                 // first super-tile (32 rows) of every part, and their total
+    int n_cols[KH_MAXP];
+    int n;
+};
+
+template <int S, int NG, int NW = 4, typename Enter, typename Epilogue, typename Finish>
+__device__ __forceinline__ void tile_loop_parts(const KhParts& pt, Enter&& enter, Epilogue&& epilogue, Finish&& finish) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int j = lane & 3, b = lane >> 2;
+    const long nsuper = pt.st0[pt.n];
+    int part = -1;
+    const char* X = nullptr;
+    long R = 0, ldx = 0, base = 0, next = 0;
+    RowGeom g = make_geom(16);
+    for (long st = (long)blockIdx.x * NW + wave; st < nsuper; st += (long)gridDim.x * NW) {
+        if (st >= next) {
+            do { ++part; next = pt.st0[part + 1]; } while (st >= next);
+            X = pt.x[part];
+            R = pt.rows[part];
+            ldx = pt.ldx[part];
+            base = pt.st0[part];
+            g = make_geom(pt.n_cols[part]);
+            enter(part);
+        }
+        const long lst = st - base;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const long row = lst * 32 + half * 16 + b;
+            const bool valid = row < R;
+            u32 cnt[S];
+#pragma unroll
+            for (int s = 0; s < S; ++s) cnt[s] = 0;
+            count_row<S, NG>(X + (valid ? row : R - 1) * ldx, j, g, cnt);
+            epilogue(half, row, valid, cnt);
+        }
+        const long row0 = lst * 32;
+        finish(lst, row0, (int)(R - row0 < 32 ? R - row0 : 32));
+    }
+}
+
 // Pack pairs of per-lane counts into uint16 halves and sum over the quad: d[m] = cnt[2m] | cnt[2m+1] << 16,
 // every lane of the quad gets the bin's totals (a total never exceeds N <= 65535, so halves cannot carry).
 // Half the DPP adds of an unpacked reduction, and d[] is already the uint16 row layout of H.

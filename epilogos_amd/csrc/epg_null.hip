@@ -7,6 +7,8 @@
 // depends only on (seed, row0 + row), never on the launch geometry or on which GPU owns the row.  gfx950 only.
 #include "epg_common.h"
 
+#include <string.h>
+
 #include <stdlib.h>
 
 namespace epg {
@@ -134,22 +136,54 @@ __global__ __launch_bounds__(256) void k_null_hist(const char* __restrict__ XA, 
 // the row's histograms) -- not of the launch geometry or of the GPU count.  A lane owns a row; rows are handed over through
 // LDS both ways so that loads and stores cover whole lines.
 // ---------------------------------------------------------------------------------------------------------------
+// Several parts (the chromosome files of a genome) in ONE launch: pointers, row counts and shuffle keys travel in the kernel
+// argument, tiles are numbered through the parts in order and never straddle two parts; a wave's tile index ascends, so its
+// part only moves forward (the pattern of k_pair_fused_s1 and k_bin_hist_parts).  A row's draws depend on (seed, key + row in
+// the part, the row's histograms) only -- the same numbers as a launch per part.
+constexpr int NH_MAXP = 48;
+struct NhParts {
+    const u16* ha[NH_MAXP];
+    const u16* hb[NH_MAXP];
+    u16* oa[NH_MAXP];
+    u16* ob[NH_MAXP];
+    long rows[NH_MAXP];
+    long key[NH_MAXP];                     // row0 of the part: the shuffle key of its first row
+    long t0[NH_MAXP + 1];                  // first tile (TR rows) of every part, and their total
+    int n;
+};
+
+#define NH_PART_STATE                                                                                                   \
+    const long ntiles = pt.t0[pt.n];                                                                                    \
+    int part = -1;                                                                                                      \
+    long next = 0, base = 0, R = 0, row0 = 0;                                                                           \
+    const u16* __restrict__ HA = nullptr;                                                                               \
+    const u16* __restrict__ HB = nullptr;                                                                               \
+    u16* __restrict__ OA = nullptr;                                                                                     \
+    u16* __restrict__ OB = nullptr;
+#define NH_PART_ENTER                                                                                                   \
+    if (tile >= next) {                                                                                                 \
+        do { ++part; next = pt.t0[part + 1]; } while (tile >= next);                                                    \
+        HA = pt.ha[part]; HB = pt.hb[part]; OA = pt.oa[part]; OB = pt.ob[part];                                         \
+        R = pt.rows[part]; row0 = pt.key[part]; base = pt.t0[part];                                                     \
+    }                                                                                                                   \
+    const long r0 = (tile - base) * TR;
+
 __device__ __forceinline__ void nh_stage_in(char* lds, const char* src, int nbytes, int lane) {
     const int nchunks = nbytes >> 4;
     for (int c = lane; c < nchunks; c += 64) *reinterpret_cast<uint4*>(lds + 16 * c) = *reinterpret_cast<const uint4*>(src + 16 * c);
     for (int o = (nchunks << 4) + 2 * lane; o + 2 <= nbytes; o += 128) *reinterpret_cast<u16*>(lds + o) = *reinterpret_cast<const u16*>(src + o);
 }
 
-__global__ __launch_bounds__(256) void k_null_hist_h_seq(const u16* __restrict__ HA, const u16* __restrict__ HB, long R, int S, int n_cols,
-                                                      int ga, int gb, u64 seed, long row0, u16* __restrict__ OA, u16* __restrict__ OB, int TR) {
+__global__ __launch_bounds__(256) void k_null_hist_h_seq(const NhParts pt, int S, int n_cols, int ga, int gb, u64 seed, int TR) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int rowb = 2 * S;
     char* sa = smem + (size_t)wave * 2 * TR * rowb;               // the wave's TR (64) rows of hA, later of the A group's counts
     char* sb = sa + TR * rowb;
-    const long ntiles = (R + TR - 1) / TR;
+    __builtin_amdgcn_s_setprio(3);                                // (see k_null_hist_h)
+    NH_PART_STATE
     for (long tile = (long)blockIdx.x * 4 + wave; tile < ntiles; tile += (long)gridDim.x * 4) {
-        const long r0 = tile * TR;
+        NH_PART_ENTER
         const int rows = (int)(R - r0 < TR ? R - r0 : TR);
         nh_stage_in(sa, reinterpret_cast<const char*>(HA + r0 * S), rows * rowb, lane);
         nh_stage_in(sb, reinterpret_cast<const char*>(HB + r0 * S), rows * rowb, lane);
@@ -276,19 +310,23 @@ __device__ __forceinline__ u32 nh_range_pop(const u32* __restrict__ bits, u32 o,
 // Same law, same Philox counters and tie rule as k_null_hist_h_seq (identical outputs, tests/test_hip_s3_null.py); the
 // arithmetic is signed 32-bit, hence rows of at most 32767 columns here (the bit strings limit the kernel to 3072 anyway).
 // Only the case the command line has without -g: ga + gb == n (a column that does not join A joins B, one bit string).
-__global__ __launch_bounds__(256) void k_null_hist_h(const u16* __restrict__ HA, const u16* __restrict__ HB, long R, int S, int n_cols,
-                                                      int ga, int gb, u64 seed, long row0, u16* __restrict__ OA, u16* __restrict__ OB, int TR,
-                                                      int NW) {
+__global__ __launch_bounds__(256) void k_null_hist_h(const NhParts pt, int S, int n_cols, int ga, int gb, u64 seed, int TR, int NW) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // The sampler is drawn on a second stream UNDER the count pass of the next batch of parts (backend._HipPairedSession): the two
+    // share every SIMD, the sampler needs ~80 % of the VALU slots and the count pass ~25 %.  At equal priority the count pass's
+    // older waves win the issue arbitration and the sampler, the longer of the two, takes 3.4 ms instead of 2.1 for 15 M bins;
+    // with its waves at priority 3 it runs at its own speed and the count pass takes what is left (3.2 instead of 2.5 ms):
+    // tools/overlap_probe.py, profiles/r05g_paired_overlap.txt.  Alone on the chip the priority changes nothing.
+    __builtin_amdgcn_s_setprio(3);
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int rowb = 2 * S;
     const size_t per_wave = (size_t)2 * TR * rowb + (size_t)NW * 256;
     char* sa = smem + (size_t)wave * per_wave;                    // the wave's TR rows of hA, later of the A group's counts
     char* sb = sa + TR * rowb;
     u32* bitsA = reinterpret_cast<u32*>(sb + TR * rowb) + lane;   // [word][lane]
-    const long ntiles = (R + TR - 1) / TR;
+    NH_PART_STATE
     for (long tile = (long)blockIdx.x * 4 + wave; tile < ntiles; tile += (long)gridDim.x * 4) {
-        const long r0 = tile * TR;
+        NH_PART_ENTER
         const int rows = (int)(R - r0 < TR ? R - r0 : TR);
         nh_stage_in(sa, reinterpret_cast<const char*>(HA + r0 * S), rows * rowb, lane);
         nh_stage_in(sb, reinterpret_cast<const char*>(HB + r0 * S), rows * rowb, lane);
@@ -416,20 +454,19 @@ __global__ __launch_bounds__(256) void k_null_hist_h(const u16* __restrict__ HA,
 // for "B = joined but not A"; two `v_lshl_or`; a share of `v_min3_u32`), a tie at either threshold sends the lane's call through
 // the careful path.  Same draws and tie rule as k_null_hist_h_seq: identical outputs.  Round 3 had tried this shape with byte-sized
 // draws and found it 5 % slower than the column-by-column kernel; with 16-bit draws: 4.7 -> 3.2 ms per 15 M bins (-g 100).
-__global__ __launch_bounds__(256) void k_null_hist_h2(const u16* __restrict__ HA, const u16* __restrict__ HB, long R, int S, int n_cols,
-                                                       int ga, int gb, u64 seed, long row0, u16* __restrict__ OA, u16* __restrict__ OB, int TR,
-                                                       int NW) {
+__global__ __launch_bounds__(256) void k_null_hist_h2(const NhParts pt, int S, int n_cols, int ga, int gb, u64 seed, int TR, int NW) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int rowb = 2 * S;
     const size_t per_wave = (size_t)2 * TR * rowb + (size_t)2 * NW * 256;
     char* sa = smem + (size_t)wave * per_wave;
     char* sb = sa + TR * rowb;
     u32* bitsA = reinterpret_cast<u32*>(sb + TR * rowb) + lane;   // [word][lane]
     u32* bitsB = bitsA + NW * 64;
-    const long ntiles = (R + TR - 1) / TR;
+    __builtin_amdgcn_s_setprio(3);                                // (see k_null_hist_h)
+    NH_PART_STATE
     for (long tile = (long)blockIdx.x * 4 + wave; tile < ntiles; tile += (long)gridDim.x * 4) {
-        const long r0 = tile * TR;
+        NH_PART_ENTER
         const int rows = (int)(R - r0 < TR ? R - r0 : TR);
         nh_stage_in(sa, reinterpret_cast<const char*>(HA + r0 * S), rows * rowb, lane);
         nh_stage_in(sb, reinterpret_cast<const char*>(HB + r0 * S), rows * rowb, lane);
@@ -555,54 +592,76 @@ __global__ __launch_bounds__(256) void k_null_hist_h2(const u16* __restrict__ HA
     }
 }
 
-int null_hist_from_binhist_impl(const uint16_t* HA, const uint16_t* HB, int64_t R, int32_t S, int32_t n_cols, int32_t ga, int32_t gb,
-                                uint64_t seed, int64_t row0, uint16_t* OA, uint16_t* OB, hipStream_t st) {
-    if (R < 0 || S < 1 || S > 127 || n_cols < 1 || n_cols > 65535) return fail(EPG_ERR_INVALID_ARG, "null_hist_from_binhist: bad shape");
+int null_hist_parts_impl(int32_t nparts, const uint16_t* const* HA, const uint16_t* const* HB, const int64_t* R, int32_t S, int32_t n_cols,
+                         int32_t ga, int32_t gb, uint64_t seed, const int64_t* row0, uint16_t* const* OA, uint16_t* const* OB, hipStream_t st) {
+    if (nparts < 0 || S < 1 || S > 127 || n_cols < 1 || n_cols > 65535) return fail(EPG_ERR_INVALID_ARG, "null_hist_from_binhist: bad shape");
     if (ga < 0 || gb < 0 || (long)ga + gb > n_cols)
         return fail(EPG_ERR_INVALID_ARG, "null_hist_from_binhist: group sizes %d + %d exceed the %d columns", ga, gb, n_cols);
-    if (R == 0) return EPG_OK;
-    if (!HA || !HB || !OA || !OB) return fail(EPG_ERR_INVALID_ARG, "null_hist_from_binhist: NULL argument");
-    if ((reinterpret_cast<uintptr_t>(HA) | reinterpret_cast<uintptr_t>(HB) | reinterpret_cast<uintptr_t>(OA) | reinterpret_cast<uintptr_t>(OB)) & 15)
-        return fail(EPG_ERR_INVALID_ARG, "null_hist_from_binhist: histogram arrays must be 16-byte aligned");
+    if (nparts && (!HA || !HB || !R || !row0 || !OA || !OB)) return fail(EPG_ERR_INVALID_ARG, "null_hist_from_binhist: NULL argument array");
+    for (int p = 0; p < nparts; ++p) {
+        if (R[p] < 0) return fail(EPG_ERR_INVALID_ARG, "null_hist_from_binhist: bad shape");
+        if (R[p] == 0) continue;
+        if (!HA[p] || !HB[p] || !OA[p] || !OB[p]) return fail(EPG_ERR_INVALID_ARG, "null_hist_from_binhist: NULL argument");
+        if ((reinterpret_cast<uintptr_t>(HA[p]) | reinterpret_cast<uintptr_t>(HB[p]) | reinterpret_cast<uintptr_t>(OA[p]) | reinterpret_cast<uintptr_t>(OB[p])) & 15)
+            return fail(EPG_ERR_INVALID_ARG, "null_hist_from_binhist: histogram arrays must be 16-byte aligned");
+    }
     const int TR = tile_rows(2 * 2 * S);
-    long blocks = ((R + TR - 1) / TR + 3) / 4;
-    static const long per_cu = [] { const char* e = getenv("EPG_NULL_BLOCKS_PER_CU"); return e && atoi(e) > 0 ? (long)atoi(e) : 8L; }();   // A/B
-    if (blocks > num_cus() * per_cu) blocks = num_cus() * per_cu;
     // the bit-string kernel while a lane's string fits the wave's share of LDS and the two groups fill the row (the command line
-    // without -g); otherwise, and with EPG_NULL_HIST=seq (A/B), the column-by-column kernel -- same draws, same outputs
+    // without -g); two bit strings with -g; otherwise the column-by-column kernel -- same draws, same outputs
     const bool full = ga + gb == n_cols;
     const int NW = (n_cols + 31) / 32;
     const size_t bits_bytes = (size_t)NW * 256;
-    const char* env = getenv("EPG_NULL_HIST");
-    if (!full && 2 * bits_bytes <= 24 * 1024 && !(env && env[0] == 's')) {      // -g: two thresholds, two bit strings
-        const size_t shmem = 4 * ((size_t)2 * TR * 2 * S + 2 * bits_bytes);
-        static bool attr2_set = false;
-        if (!attr2_set) {
-            EPG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_null_hist_h2), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            attr2_set = true;
+    for (int p0 = 0; p0 < nparts;) {
+        NhParts pt;
+        memset(&pt, 0, sizeof(pt));
+        long tiles = 0;
+        int p = p0;
+        for (; p < nparts && pt.n < NH_MAXP; ++p) {
+            if (R[p] == 0) continue;
+            const int k = pt.n++;
+            pt.ha[k] = HA[p]; pt.hb[k] = HB[p]; pt.oa[k] = OA[p]; pt.ob[k] = OB[p];
+            pt.rows[k] = R[p];
+            pt.key[k] = row0[p];
+            pt.t0[k] = tiles;
+            tiles += (R[p] + TR - 1) / TR;
         }
-        hipLaunchKernelGGL(k_null_hist_h2, dim3((unsigned)blocks), dim3(256), shmem, st, HA, HB, (long)R, S, n_cols, ga, gb, (u64)seed,
-                           (long)row0, OA, OB, TR, NW);
-        EPG_LAUNCH_CHECK("k_null_hist_h2");
-        return EPG_OK;
-    }
-    if (full && bits_bytes <= 24 * 1024 && !(env && env[0] == 's')) {
-        const size_t shmem = 4 * ((size_t)2 * TR * 2 * S + bits_bytes);
-        static bool attr_set = false;
-        if (!attr_set) {
-            EPG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_null_hist_h), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            attr_set = true;
+        pt.t0[pt.n] = tiles;
+        p0 = p;
+        if (pt.n == 0) break;
+        long blocks = (tiles + 3) / 4;
+        if (blocks > num_cus() * 8L) blocks = num_cus() * 8L;
+        const bool seq = g_force[FORCE_NULL_SEQ] != 0;          // (tests: the column-by-column kernel on shapes that fit the bit strings)
+        if (!seq && !full && 2 * bits_bytes <= 24 * 1024) {     // -g: two thresholds, two bit strings
+            const size_t shmem = 4 * ((size_t)2 * TR * 2 * S + 2 * bits_bytes);
+            static bool attr2_set = false;
+            if (!attr2_set) {
+                EPG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_null_hist_h2), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                attr2_set = true;
+            }
+            hipLaunchKernelGGL(k_null_hist_h2, dim3((unsigned)blocks), dim3(256), shmem, st, pt, S, n_cols, ga, gb, (u64)seed, TR, NW);
+            EPG_LAUNCH_CHECK("k_null_hist_h2");
+        } else if (!seq && full && bits_bytes <= 24 * 1024) {
+            const size_t shmem = 4 * ((size_t)2 * TR * 2 * S + bits_bytes);
+            static bool attr_set = false;
+            if (!attr_set) {
+                EPG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_null_hist_h), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                attr_set = true;
+            }
+            hipLaunchKernelGGL(k_null_hist_h, dim3((unsigned)blocks), dim3(256), shmem, st, pt, S, n_cols, ga, gb, (u64)seed, TR, NW);
+            EPG_LAUNCH_CHECK("k_null_hist_h");
+        } else {
+            const size_t shmem = (size_t)4 * 2 * TR * 2 * S;
+            hipLaunchKernelGGL(k_null_hist_h_seq, dim3((unsigned)blocks), dim3(256), shmem, st, pt, S, n_cols, ga, gb, (u64)seed, TR);
+            EPG_LAUNCH_CHECK("k_null_hist_h_seq");
         }
-        hipLaunchKernelGGL(k_null_hist_h, dim3((unsigned)blocks), dim3(256), shmem, st, HA, HB, (long)R, S, n_cols, ga, gb, (u64)seed,
-                           (long)row0, OA, OB, TR, NW);
-        EPG_LAUNCH_CHECK("k_null_hist_h");
-        return EPG_OK;
     }
-    const size_t shmem = (size_t)4 * 2 * TR * 2 * S;
-    hipLaunchKernelGGL(k_null_hist_h_seq, dim3((unsigned)blocks), dim3(256), shmem, st, HA, HB, (long)R, S, n_cols, ga, gb, (u64)seed,
-                       (long)row0, OA, OB, TR);
-    EPG_LAUNCH_CHECK("k_null_hist_h");
     return EPG_OK;
+}
+
+int null_hist_from_binhist_impl(const uint16_t* HA, const uint16_t* HB, int64_t R, int32_t S, int32_t n_cols, int32_t ga, int32_t gb,
+                                uint64_t seed, int64_t row0, uint16_t* OA, uint16_t* OB, hipStream_t st) {
+    if (R > 0 && (!HA || !HB || !OA || !OB)) return fail(EPG_ERR_INVALID_ARG, "null_hist_from_binhist: NULL argument");
+    return null_hist_parts_impl(1, &HA, &HB, &R, S, n_cols, ga, gb, seed, &row0, &OA, &OB, st);
 }
 
 // quiescent from cached histograms of the two real groups (scores.py:294-303): every column of A and of B holds the

@@ -3,6 +3,7 @@
 #include "epg_count.h"
 
 #include <stdlib.h>
+#include <string.h>
 
 namespace epg {
 
@@ -14,9 +15,11 @@ namespace epg {
 // state model's size = columns of H.  A model between two instantiations runs on the next larger one and only its own
 // columns are stored (an occurrence of a state >= Sout is "not a state", like in the reference's inputs it cannot occur).
 // FULL: Sout == SC at compile time (the reference's 15-, 18- and 25-state models).
-template <int SC, int NG, bool FULL>
-__global__ __launch_bounds__(256) void k_bin_hist(const char* __restrict__ X, long R, int N, long ldx, int Sout_,
-                                                   u16* __restrict__ H, u64* __restrict__ counts) {
+// The body is shared by the one-matrix kernel and the several-parts kernel: `loop(enter, epilogue, finish)` runs the tile loop,
+// enter(H) names the histogram array the following tiles belong to; nmax = the widest part (how often the packed uint16
+// running counts must be flushed).
+template <int SC, bool FULL, typename Loop>
+__device__ __forceinline__ void bin_hist_body(int Sout_, u64* __restrict__ counts, int nmax, Loop&& loop) {
     constexpr int S = SC;
     constexpr int ND = (S + 1) / 2;
     const int Sout = FULL ? S : Sout_;
@@ -27,12 +30,13 @@ __global__ __launch_bounds__(256) void k_bin_hist(const char* __restrict__ X, lo
     const int j = lane & 3, b = lane >> 2;
     if (threadIdx.x <= S) s_cnt[threadIdx.x] = 0;
     __syncthreads();
+    u16* H = nullptr;
 
     // running state counts of this lane's bins, as packed uint16 pairs; flushed to LDS before a half can overflow
     u32 accp[ND];
 #pragma unroll
     for (int m = 0; m < ND; ++m) accp[m] = 0;
-    const int flush_every = 65535 / N > 1 ? 65535 / N - 1 : 1;
+    const int flush_every = 65535 / nmax > 1 ? 65535 / nmax - 1 : 1;
     int since = 0;
     auto flush = [&]() {
         if (j == 0) {
@@ -48,6 +52,7 @@ __global__ __launch_bounds__(256) void k_bin_hist(const char* __restrict__ X, lo
         since = 0;
     };
 
+    auto enter = [&](u16* Hpart) { H = Hpart; };
     auto epilogue = [&](int half, long row, bool valid, u32 (&cnt)[S]) {
         u32 d[ND];
         pack_reduce<S>(cnt, d);
@@ -79,13 +84,31 @@ __global__ __launch_bounds__(256) void k_bin_hist(const char* __restrict__ X, lo
     auto finish = [&](long st, long row0, int rows) {
         if (H) store_staged(s_stage[wave], reinterpret_cast<char*>(H) + row0 * ROWB, rows * ROWB, lane);
     };
-    tile_loop<S, NG>(X, R, N, ldx, epilogue, finish);
+    loop(enter, epilogue, finish);
 
     if (counts) {
         flush();
         __syncthreads();
         if ((int)threadIdx.x < Sout && s_cnt[threadIdx.x]) atomicAdd(&counts[threadIdx.x], s_cnt[threadIdx.x]);
     }
+}
+
+template <int SC, int NG, bool FULL>
+__global__ __launch_bounds__(256) void k_bin_hist(const char* __restrict__ X, long R, int N, long ldx, int Sout_,
+                                                   u16* __restrict__ H, u64* __restrict__ counts) {
+    bin_hist_body<SC, FULL>(Sout_, counts, N, [&](auto&& enter, auto&& epilogue, auto&& finish) {
+        enter(H);
+        tile_loop<SC, NG>(X, R, N, ldx, epilogue, finish);
+    });
+}
+
+// Several matrices in ONE launch (epg_bin_hist_parts): the 2 x 24 chromosome parts of a paired genome are 48 launches of ~80 us
+// otherwise, each with its ramp and tail (round 4: the count phase of BASELINE config 5 ran at 0.36 of its bytes).
+template <int SC, int NG, bool FULL>
+__global__ __launch_bounds__(256) void k_bin_hist_parts(const KhParts pt, int Sout_, u64* __restrict__ counts, int nmax) {
+    bin_hist_body<SC, FULL>(Sout_, counts, nmax, [&](auto&& enter, auto&& epilogue, auto&& finish) {
+        tile_loop_parts<SC, NG>(pt, [&](int part) { enter(pt.h[part]); }, epilogue, finish);
+    });
 }
 
 // Any S <= 127, any N, any alignment, never reads past a row's N bytes: one wave per bin, LDS atomics.
@@ -354,6 +377,100 @@ int bin_hist_impl(const int8_t* X8, int64_t R, int32_t N, int64_t ldx, int32_t S
     if (Rf < R) {
         hipLaunchKernelGGL(k_bin_hist_safe, dim3((unsigned)((R - Rf + 3) / 4 < 1024 ? (R - Rf + 3) / 4 : 1024)), dim3(256), 0, st, X, Rf, (long)R, N, ldx, S, H, cnt);
         EPG_LAUNCH_CHECK("k_bin_hist_safe");
+    }
+    return EPG_OK;
+}
+
+// ---- several matrices, one launch
+template <int S, int NG>
+static void launch_bin_hist_parts(const KhParts& pt, int Sout, u64* counts, int nmax, hipStream_t st) {
+    constexpr bool FULL = NG > 0 && (S & 1) == 0;          // (the any-width instantiation stores column by column, like launch_bin_hist_any)
+    const long nsuper = pt.st0[pt.n];
+    hipLaunchKernelGGL((k_bin_hist_parts<S, NG, FULL>), dim3(grid_for_tiles(nsuper * 32)), dim3(256), 0, st, pt, Sout, counts, nmax);
+}
+
+template <int S>
+static void dispatch_bin_hist_parts(int ng, const KhParts& pt, int Sout, u64* counts, int nmax, hipStream_t st) {
+    switch (ng) {
+        case 1: launch_bin_hist_parts<S, 1>(pt, Sout, counts, nmax, st); break;
+        case 2: launch_bin_hist_parts<S, 2>(pt, Sout, counts, nmax, st); break;
+        case 3: launch_bin_hist_parts<S, 3>(pt, Sout, counts, nmax, st); break;
+        case 4: launch_bin_hist_parts<S, 4>(pt, Sout, counts, nmax, st); break;
+        case 5: launch_bin_hist_parts<S, 5>(pt, Sout, counts, nmax, st); break;
+        case 6: launch_bin_hist_parts<S, 6>(pt, Sout, counts, nmax, st); break;
+        case 7: launch_bin_hist_parts<S, 7>(pt, Sout, counts, nmax, st); break;
+        case 8: launch_bin_hist_parts<S, 8>(pt, Sout, counts, nmax, st); break;
+        default: launch_bin_hist_parts<S, 0>(pt, Sout, counts, nmax, st); break;
+    }
+}
+
+// epg_bin_hist over `nparts` matrices in as few launches as their widths allow: parts whose widths share a load schedule
+// (the same number of 128-byte groups per row; more than eight: the any-width loop) go into one launch, KH_MAXP at a time.  The
+// same integers as nparts calls of bin_hist_impl (tests/test_hip_parity.py); restates the per-file loop of run.py:236-257 +
+// expected.py:111-113 for resident files.
+int bin_hist_parts_impl(int32_t nparts, const int8_t* const* X, const int64_t* R, const int32_t* N, const int64_t* ldx, int32_t S,
+                        uint16_t* const* H, int64_t* counts, hipStream_t st) {
+    if (nparts < 0 || (nparts && (!X || !R || !N || !ldx))) return fail(EPG_ERR_INVALID_ARG, "bin_hist_parts: NULL argument array");
+    if (S < 1 || S > 127) return fail(EPG_ERR_UNSUPPORTED, "bin_hist_parts: S=%d outside 1..127", S);
+    for (int p = 0; p < nparts; ++p) {
+        if (R[p] < 0 || (R[p] && (N[p] < 1 || ldx[p] < N[p]))) return fail(EPG_ERR_INVALID_ARG, "bin_hist_parts: bad shape of part %d", p);
+        if (R[p] && N[p] > 65535) return fail(EPG_ERR_UNSUPPORTED, "bin_hist_parts: N=%d > 65535 (uint16 per-bin counts)", N[p]);
+        if (R[p] && !X[p]) return fail(EPG_ERR_INVALID_ARG, "bin_hist_parts: X of part %d is NULL", p);
+        if (H && H[p] && (reinterpret_cast<uintptr_t>(H[p]) & 15)) return fail(EPG_ERR_INVALID_ARG, "bin_hist_parts: H of part %d must be 16-byte aligned", p);
+    }
+    if (S > 31) {                                  // the wide models: part by part
+        for (int p = 0; p < nparts; ++p) {
+            const int rc = bin_hist_impl(X[p], R[p], N[p], ldx[p], S, H ? H[p] : nullptr, counts, st);
+            if (rc) return rc;
+        }
+        return EPG_OK;
+    }
+    u64* cnt = reinterpret_cast<u64*>(counts);
+    // schedule class of a part: groups per row (1..8), 0 = any width; classes are launched one after the other
+    auto cls = [](int n) { const int ng = (n + 127) / 128; return ng <= 8 ? ng : 0; };
+    bool seen[9] = {false, false, false, false, false, false, false, false, false};
+    for (int p = 0; p < nparts; ++p)
+        if (R[p]) seen[cls(N[p])] = true;
+    const bool generic = !(S == 15 || S == 18 || S == 25);      // another model size: the any-width loop of the next larger core
+    for (int c = 0; c <= 8; ++c) {
+        if (!seen[c]) continue;
+        for (int p0 = 0; p0 < nparts;) {
+            KhParts pt;
+            memset(&pt, 0, sizeof(pt));
+            long supers = 0;
+            int nmax = 1, p = p0;
+            for (; p < nparts && pt.n < KH_MAXP; ++p) {
+                if (!R[p] || cls(N[p]) != c) continue;
+                const long Rf = fast_rows(R[p], N[p], ldx[p]);
+                if (Rf < R[p]) {                   // trailing rows the 16-byte loads could run past: byte-granular kernel
+                    hipLaunchKernelGGL(k_bin_hist_safe, dim3((unsigned)((R[p] - Rf + 3) / 4 < 1024 ? (R[p] - Rf + 3) / 4 : 1024)), dim3(256), 0, st,
+                                       reinterpret_cast<const char*>(X[p]), Rf, (long)R[p], N[p], (long)ldx[p], S, H ? H[p] : nullptr, cnt);
+                    EPG_LAUNCH_CHECK("k_bin_hist_safe");
+                }
+                if (Rf == 0) continue;
+                const int k = pt.n++;
+                pt.x[k] = reinterpret_cast<const char*>(X[p]);
+                pt.h[k] = H ? H[p] : nullptr;
+                pt.rows[k] = Rf;
+                pt.ldx[k] = ldx[p];
+                pt.n_cols[k] = N[p];
+                pt.st0[k] = supers;
+                supers += (Rf + 31) / 32;
+                if (N[p] > nmax) nmax = N[p];
+            }
+            pt.st0[pt.n] = supers;
+            p0 = p;
+            if (pt.n == 0) break;
+            const int ng = generic ? 0 : c;
+            if (S == 15) dispatch_bin_hist_parts<15>(ng, pt, S, cnt, nmax, st);
+            else if (S == 18) dispatch_bin_hist_parts<18>(ng, pt, S, cnt, nmax, st);
+            else if (S == 25) dispatch_bin_hist_parts<25>(ng, pt, S, cnt, nmax, st);
+            else if (S < 15) launch_bin_hist_parts<15, 0>(pt, S, cnt, nmax, st);
+            else if (S < 18) launch_bin_hist_parts<18, 0>(pt, S, cnt, nmax, st);
+            else if (S < 25) launch_bin_hist_parts<25, 0>(pt, S, cnt, nmax, st);
+            else launch_bin_hist_parts<31, 0>(pt, S, cnt, nmax, st);
+            EPG_LAUNCH_CHECK("k_bin_hist_parts");
+        }
     }
     return EPG_OK;
 }

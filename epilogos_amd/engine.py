@@ -204,6 +204,52 @@ def bin_hist(X, N, S, want_hist=True, counts=None, want_counts=True, H=None):
     return H, counts
 
 
+def _ptr_array(ts):
+    return (C.c_void_p * len(ts))(*[t.data_ptr() if t is not None and t.numel() else None for t in ts])
+
+
+def hist_rows_alloc(rows, S, device):
+    """One allocation for the [R_p, S] uint16 histograms of several parts; -> list of views.  Every part starts 16-byte
+    aligned (its first row at a multiple of 8 rows: 8 rows of any S are a multiple of 16 bytes)."""
+    starts, at = [], 0
+    for r in rows:
+        starts.append(at)
+        at += (r + 7) // 8 * 8
+    flat = torch.empty((max(at, 1), S), dtype=torch.int16, device=device)
+    return [flat[a:a + r] for a, r in zip(starts, rows)]
+
+
+def bin_hist_parts(Xs, Ns, S, counts=None, want_hist=True, Hs=None):
+    """K1 over several resident matrices in as few launches as their widths allow (epg_bin_hist_parts; one launch when all
+    widths have the same number of 128-byte groups per row): -> (list of H [R_p, S] int16-stored uint16, counts), all parts'
+    state counts added into the one `counts` (None: no counts)."""
+    n = len(Xs)
+    if n == 0:
+        return [], counts
+    shapes = [_check_states(X, N) if X.shape[0] else (0, max(N, 1)) for X, N in zip(Xs, Ns)]
+    dev = Xs[0].device
+    if Hs is None and want_hist:
+        Hs = hist_rows_alloc([r for r, _l in shapes], S, dev)
+    _abi.call("epg_bin_hist_parts", n, _ptr_array(Xs), (C.c_int64 * n)(*[r for r, _l in shapes]), (C.c_int32 * n)(*[int(N or 1) for N in Ns]),
+              (C.c_int64 * n)(*[l for _r, l in shapes]), S, _ptr_array(Hs) if Hs is not None else None, _ptr(counts), _stream())
+    return Hs, counts
+
+
+def null_hist_from_binhist_parts(HAs, HBs, n_cols, S, ga, gb, seed, row0s, stream=None):
+    """epg_null_hist_from_binhist for several parts in one launch (bit-identical to a call per part); outputs from ONE allocation
+    per group.  -> (list of OA, list of OB)."""
+    n = len(HAs)
+    if n == 0:
+        return [], []
+    rows = [h.shape[0] for h in HAs]
+    dev = HAs[0].device
+    OAs, OBs = hist_rows_alloc(rows, S, dev), hist_rows_alloc(rows, S, dev)
+    _abi.call("epg_null_hist_from_binhist_parts", n, _ptr_array(HAs), _ptr_array(HBs), (C.c_int64 * n)(*rows), S, n_cols, ga, gb, seed,
+              (C.c_int64 * n)(*[int(r) for r in row0s]), _ptr_array(OAs), _ptr_array(OBs),
+              _stream() if stream is None else C.c_void_p(stream.cuda_stream))
+    return OAs, OBs
+
+
 def hist_s2_from_binhist(H, S, counts=None):
     if counts is None:
         counts = zeros_counts(S * S, device=H.device)

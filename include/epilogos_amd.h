@@ -60,6 +60,13 @@ int epg_device_cus(void);
 int epg_bin_hist(const int8_t* X, int64_t R, int32_t N, int64_t ldx, int32_t S,
                  uint16_t* H, int64_t* counts, void* stream);
 
+/* epg_bin_hist over `nparts` resident matrices (the chromosome files of a genome; both groups of a paired run) in as few
+ * launches as their widths allow (one when every N[p] has the same number of 128-byte groups per row), all parts' state
+ * counts into the same counts[S].  X, R, N, ldx, H are HOST arrays of nparts entries (H, or single entries of it, may be NULL).
+ * The same integers as nparts calls of epg_bin_hist.  Replaces the per-file loop of run.py:236-257 / expected.py:100-113. */
+int epg_bin_hist_parts(int32_t nparts, const int8_t* const* X, const int64_t* R, const int32_t* N, const int64_t* ldx,
+                       int32_t S, uint16_t* const* H, int64_t* counts, void* stream);
+
 /* ---- expected-frequency pass (STEP 1) ---------------------------------------------------------------------
  * S1: counts[S]   += state counts                                   -- expected.py:90-116  s1Calc
  * S2: counts[S*S] += sum_b h_i*h_j (i != j), h_i*(h_i-1) (i == j)   -- expected.py:119-162 s2Calc
@@ -184,8 +191,20 @@ int epg_null_hist(const int8_t* XA, int32_t NA, int64_t ldxa, const int8_t* XB, 
  * frequent state taking the remainder without a draw.  n_cols = NA + NB (columns without a state, n_cols - sum h, take
  * part in the shuffle and are not reported).  Same seeding contract as epg_null_hist, a DIFFERENT random stream: the two
  * entry points agree in distribution, not draw by draw.  OA / OB may not alias HA / HB. */
+/* (epg_null_hist_from_binhist_parts below: the same for several parts -- host arrays of nparts pointers, row counts and
+ * shuffle keys row0 -- in one launch; bit-identical to a call per part.) */
 int epg_null_hist_from_binhist(const uint16_t* HA, const uint16_t* HB, int64_t R, int32_t S, int32_t n_cols, int32_t ga,
                                int32_t gb, uint64_t seed, int64_t row0, uint16_t* OA, uint16_t* OB, void* stream);
+int epg_null_hist_from_binhist_parts(int32_t nparts, const uint16_t* const* HA, const uint16_t* const* HB, const int64_t* R,
+                                     int32_t S, int32_t n_cols, int32_t ga, int32_t gb, uint64_t seed, const int64_t* row0,
+                                     uint16_t* const* OA, uint16_t* const* OB, void* stream);
+
+/* ---- test hook (tests/ only; nothing in the package calls it) ----------------------------------------------
+ * Several entry points have a fallback kernel that other shapes take; epg_test_force(which, value) makes the next calls take it
+ * on any shape so that the tests can compare it with the default on theirs.  which: 0 = the column-by-column null sampler
+ * (value 1), 1 = the bin-per-lane S3 score kernel (1), 2 = the S3 contraction (1 = over all S states, 2 = the reduced one
+ * whatever the call's size), 3 = the LDS-counter S3 count kernel (1).  value 0 = the library decides (the default). */
+int epg_test_force(int32_t which, int32_t value);
 
 #ifdef __cplusplus
 }

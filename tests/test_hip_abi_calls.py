@@ -191,3 +191,97 @@ def test_combine_score_s1_long_table(abi):
     counts = c.clone()
     q, o32, _ = engine.combine_score_s1(counts, H, N, S_, rezero=True)
     assert torch.equal(q, q_ref) and torch.equal(o32, o32_ref) and int(counts.abs().sum()) == 0
+
+
+@pytest.mark.parametrize("S_", [18, 15, 20, 40])
+def test_bin_hist_parts_equals_a_call_per_part(abi, S_):
+    """epg_bin_hist_parts straight through ctypes: parts of different row counts (empty, one row, not a multiple of 32), widths
+    in several load-schedule classes (1 .. 8 groups per row and the any-width loop), padded and packed row pitches, with and
+    without histograms -- the integers of one epg_bin_hist call per part, and of the oracle."""
+    from epilogos_amd import engine
+    rng = np.random.default_rng(100 + S_)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    shapes = [(0, 40), (1, 40), (95, 379), (64, 342), (33, 379), (200, 120), (7, 1100), (129, 833), (31, 833), (50, 342)]
+    xs = [synth_states(r, n, S=S_, seed=int(rng.integers(1 << 30)), uniform=S_ > 18) for r, n in shapes]
+    Xs = []
+    for k, x in enumerate(xs):
+        if k % 3 == 2 and x.shape[0]:                       # a packed matrix (row pitch = width, unaligned rows)
+            flat = torch.full((x.size + 64,), -1, dtype=torch.int8, device="cuda")
+            v = flat[:x.size].view(x.shape)
+            v.copy_(torch.from_numpy(x))
+            Xs.append(v)
+        else:
+            Xs.append(engine.states_to_device(x) if x.shape[0] else torch.empty((0, 48), dtype=torch.int8, device="cuda"))
+    n = len(Xs)
+    arr = lambda ts: (C.c_void_p * n)(*[t.data_ptr() if t is not None and t.numel() else None for t in ts])
+    R = (C.c_int64 * n)(*[x.shape[0] for x in xs])
+    N = (C.c_int32 * n)(*[x.shape[1] for x in xs])
+    ldx = (C.c_int64 * n)(*[X.stride(0) if X.shape[0] else 48 for X in Xs])
+    Hs = engine.hist_rows_alloc([x.shape[0] for x in xs], S_, "cuda")
+    counts = torch.zeros(S_, dtype=torch.int64, device="cuda")
+    abi.call("epg_bin_hist_parts", n, arr(Xs), R, N, ldx, S_, arr(Hs), _p(counts), st)
+    want = np.zeros(S_, dtype=np.int64)
+    for x, X, H in zip(xs, Xs, Hs):
+        if not x.shape[0]:
+            continue
+        h = onp.bin_hist(x, S_)
+        assert np.array_equal(engine.hist_to_numpy(H).astype(np.int64), h), x.shape
+        H1, _ = engine.bin_hist(X, x.shape[1], S_, want_counts=False)
+        assert torch.equal(H1, H)
+        want += h.sum(axis=0)
+    assert np.array_equal(counts.cpu().numpy(), want)
+    counts.zero_()
+    abi.call("epg_bin_hist_parts", n, arr(Xs), R, N, ldx, S_, None, _p(counts), st)          # counts only
+    assert np.array_equal(counts.cpu().numpy(), want)
+    Hs2, c2 = engine.bin_hist_parts(Xs, [x.shape[1] for x in xs], S_, counts=None)             # the engine wrapper, histograms only
+    assert c2 is None and all(torch.equal(a, b) for a, b in zip(Hs, Hs2))
+    abi.call("epg_bin_hist_parts", 0, None, None, None, None, S_, None, _p(counts), st)      # no parts: nothing happens
+    with pytest.raises(abi.EpilogosHipError) as e:
+        bad = (C.c_int64 * n)(*[8] * n)                       # row pitch smaller than the width
+        abi.call("epg_bin_hist_parts", n, arr(Xs), R, N, bad, S_, arr(Hs), _p(counts), st)
+    assert e.value.code == -1
+
+
+def test_bin_hist_parts_more_parts_than_one_launch_holds(abi):
+    """More parts than the kernel argument holds (48): several launches, same integers."""
+    from epilogos_amd import engine
+    rng = np.random.default_rng(7)
+    xs = [synth_states(int(rng.integers(1, 90)), 61, seed=k) for k in range(110)]
+    Xs = [engine.states_to_device(x) for x in xs]
+    counts = torch.zeros(S, dtype=torch.int64, device="cuda")
+    Hs, _ = engine.bin_hist_parts(Xs, [61] * len(Xs), S, counts=counts)
+    allx = np.concatenate(xs)
+    assert np.array_equal(counts.cpu().numpy(), onp.expected_s1(allx, S))
+    assert np.array_equal(np.concatenate([engine.hist_to_numpy(H) for H in Hs]).astype(np.int64), onp.bin_hist(allx, S))
+
+
+@pytest.mark.parametrize("ga_gb", [None, (20, 20), (60, 60)])
+def test_null_hist_parts_equals_a_call_per_part(abi, ga_gb):
+    """epg_null_hist_from_binhist_parts: the null groups of several parts in one launch are, bit for bit, those of a call per
+    part with the part's shuffle key (all three sampler kernels: the bit-string one, the two-string one of -g, and -- forced
+    through the test hook -- the column-by-column one)."""
+    from epilogos_amd import engine
+    NA, NB = 70, 53
+    ga, gb = ga_gb or (NA, NB)
+    rows = [0, 1, 63, 64, 65, 300, 17]
+    rng = np.random.default_rng(3)
+    HAs, HBs = [], []
+    for r in rows:
+        xa, xb = synth_states(r, NA, seed=int(rng.integers(1 << 30))), synth_states(r, NB, seed=int(rng.integers(1 << 30)))
+        HAs.append(engine.bin_hist(engine.states_to_device(xa), NA, S, want_counts=False)[0] if r else torch.empty((0, S), dtype=torch.int16, device="cuda"))
+        HBs.append(engine.bin_hist(engine.states_to_device(xb), NB, S, want_counts=False)[0] if r else torch.empty((0, S), dtype=torch.int16, device="cuda"))
+    keys = [(k << 40) + 1000 * k for k in range(len(rows))]
+    for force in (0, 1):
+        abi.call("epg_test_force", 0, force)
+        try:
+            OAs, OBs = engine.null_hist_from_binhist_parts(HAs, HBs, NA + NB, S, ga, gb, 4242, keys)
+            for HA, HB, OA, OB, key in zip(HAs, HBs, OAs, OBs, keys):
+                if not HA.shape[0]:
+                    continue
+                A1, B1 = engine.null_hist_from_binhist(HA, HB, NA + NB, S, ga, gb, 4242, key)
+                assert torch.equal(A1, OA) and torch.equal(B1, OB)
+                assert int(OA.to(torch.int32).sum(dim=1).min()) == ga == int(OA.to(torch.int32).sum(dim=1).max())
+        finally:
+            abi.call("epg_test_force", 0, 0)
+    with pytest.raises(abi.EpilogosHipError):
+        abi.call("epg_test_force", 99, 1)

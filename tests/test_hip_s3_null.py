@@ -351,7 +351,7 @@ def test_null_hist_from_binhist_large_categories_follow_the_hypergeometric_law(e
 def test_null_hist_bit_string_kernel_equals_the_column_by_column_kernel(eng, monkeypatch):
     """Round 3 took the state bookkeeping out of the histogram-based sampler's draw loop (one outcome bit per position, range
     popcounts afterwards).  The draws themselves -- Philox counters, one byte per position, the tie rule -- are those of the
-    round-2 kernel (EPG_NULL_HIST=seq), so the same seed must give the SAME null groups: default group sizes, -g, columns
+    round-2 kernel (epg_test_force(0, 1)), so the same seed must give the SAME null groups: default group sizes, -g, columns
     without a state, wide rows, narrow rows, rows of one state, a 31-state model."""
     rng = np.random.default_rng(8)
     for S_, R_, na, nb, ga, gb in ((S, 5000, 379, 342, 379, 342), (S, 3000, 379, 342, 100, 100), (15, 777, 65, 62, 65, 62),
@@ -363,11 +363,12 @@ def test_null_hist_bit_string_kernel_equals_the_column_by_column_kernel(eng, mon
         yb[R_ // 3, :] = 1                                   # ... and of B too: nothing to draw
         Ha, _ = eng.bin_hist(eng.states_to_device(ya), na, S_, want_counts=False)
         Hb, _ = eng.bin_hist(eng.states_to_device(yb), nb, S_, want_counts=False)
-        monkeypatch.delenv("EPG_NULL_HIST", raising=False)
         Oa, Ob = eng.null_hist_from_binhist(Ha, Hb, na + nb, S_, ga, gb, seed=77, row0=123456789012)
-        monkeypatch.setenv("EPG_NULL_HIST", "seq")
-        Qa, Qb = eng.null_hist_from_binhist(Ha, Hb, na + nb, S_, ga, gb, seed=77, row0=123456789012)
-        monkeypatch.delenv("EPG_NULL_HIST")
+        eng._abi.call("epg_test_force", 0, 1)                # the column-by-column kernel (what rows beyond 3072 columns take)
+        try:
+            Qa, Qb = eng.null_hist_from_binhist(Ha, Hb, na + nb, S_, ga, gb, seed=77, row0=123456789012)
+        finally:
+            eng._abi.call("epg_test_force", 0, 0)
         assert torch.equal(Oa, Qa) and torch.equal(Ob, Qb), (S_, R_, na, nb, ga, gb)
         assert (eng.hist_to_numpy(Oa).astype(np.int64).sum(axis=1)[np.arange(R_) != R_ // 2] == ga).all()
 
@@ -386,6 +387,9 @@ def test_null_hist_from_binhist_row_widths_around_the_kernel_switch(eng, monkeyp
     Oa, Ob = eng.null_hist_from_binhist(Ha, Hb, na + nb, S, na, nb, seed=5)
     oa, ob = eng.hist_to_numpy(Oa).astype(np.int64), eng.hist_to_numpy(Ob).astype(np.int64)
     assert np.array_equal(oa + ob, tot) and (oa.sum(axis=1) == na).all() and (ob.sum(axis=1) == nb).all()
-    monkeypatch.setenv("EPG_NULL_HIST", "seq")
-    Qa, Qb = eng.null_hist_from_binhist(Ha, Hb, na + nb, S, na, nb, seed=5)
+    eng._abi.call("epg_test_force", 0, 1)
+    try:
+        Qa, Qb = eng.null_hist_from_binhist(Ha, Hb, na + nb, S, na, nb, seed=5)
+    finally:
+        eng._abi.call("epg_test_force", 0, 0)
     assert torch.equal(Oa, Qa) and torch.equal(Ob, Qb)

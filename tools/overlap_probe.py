@@ -63,3 +63,33 @@ print("%d bins x (%d + %d): two count passes %.3f ms, null sampler %.3f ms, both
     R, NA, NB, ta, tb, tab, ta + tb, max(ta, tb)), flush=True)
 tba = timed(sampler, counts)
 print("   sampler enqueued first: %.3f ms" % tba, flush=True)
+
+
+def counts_only():
+    engine.bin_hist(XA, NA, S, counts=cA, want_hist=False)
+    engine.bin_hist(XB, NB, S, counts=cB, want_hist=False)
+
+
+def each(fn_a, fn_b, reps=5):
+    """Duration of fn_a on s1 and of fn_b on s2 when both start together (events per stream)."""
+    out = []
+    for _ in range(reps + 1):
+        torch.cuda.synchronize()
+        e0 = torch.cuda.Event(enable_timing=True)
+        ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        s1.wait_event(e0); s2.wait_event(e0)
+        with torch.cuda.stream(s1):
+            fn_a(); ea.record()
+        with torch.cuda.stream(s2):
+            fn_b(); eb.record()
+        torch.cuda.synchronize()
+        out.append((e0.elapsed_time(ea), e0.elapsed_time(eb)))
+    return tuple(float(np.median([o[k] for o in out[1:]])) for k in (0, 1))
+
+
+tc = timed(counts_only, None)
+a1, b1 = each(counts_only, sampler)
+a2, b2 = each(counts, sampler)
+print("   counts-only passes (a pure read stream) alone %.3f ms; with the sampler beside them: reads %.3f ms, sampler %.3f ms" % (tc, a1, b1), flush=True)
+print("   count passes with the H store beside the sampler: count %.3f ms, sampler %.3f ms" % (a2, b2), flush=True)
