@@ -71,6 +71,8 @@ def load():
     lib.epgio_set_reader_plan.argtypes = [i32]
     lib.epgio_default_threads.restype = i32
     lib.epgio_default_threads.argtypes = []
+    lib.epgio_set_host_threads.restype = None
+    lib.epgio_set_host_threads.argtypes = [i32]
     lib.epgio_thread_census.restype = None
     lib.epgio_thread_census.argtypes = [C.POINTER(i32), C.POINTER(i32), i32]
     _lib = lib
@@ -94,6 +96,9 @@ def node_cores():
     return n
 
 
+_budget_told = None
+
+
 def host_budget():
     """Native threads THIS rank may keep busy: the node's cores (node_cores), capped by the reference's -c/--num-cores when the
     user gave one (EPILOGOS_NUM_CORES; run.py:36,148 -- there it sizes the worker pool), divided by the ranks that share the
@@ -111,7 +116,15 @@ def host_budget():
     except ValueError:
         local_world = 1
     b = max(1, n // local_world)
-    os.environ["EPILOGOS_HOST_THREADS"] = str(b)
+    # the native library gets the value through a setter, not through the environment: its reader threads must never read
+    # `environ` while this thread (or torch, imported next to the early readers) writes it.  The variable is still exported, once
+    # per value, for child processes (the launcher's ranks) and the thread census.
+    global _budget_told
+    if _budget_told != b:
+        _budget_told = b
+        load().epgio_set_host_threads(b)
+        if os.environ.get("EPILOGOS_HOST_THREADS") != str(b):
+            os.environ["EPILOGOS_HOST_THREADS"] = str(b)
     return b
 
 

@@ -9,7 +9,7 @@ ROOT = PKG.parent
 CSRC = PKG / "csrc"
 LIB_DIR = PKG / "_lib"
 LIB_PATH = LIB_DIR / "libepilogos_hip.so"
-SOURCES = ["epg_abi.hip", "epg_s1.hip", "epg_s2.hip", "epg_s3.hip", "epg_s3_mfma.hip", "epg_s3_gemm.hip", "epg_s3_lanes.hip", "epg_s3_sparse.hip", "epg_null.hip", "epg_wide.hip"]
+SOURCES = ["epg_abi.hip", "epg_s1.hip", "epg_s2.hip", "epg_s3.hip", "epg_s3_mfma.hip", "epg_s3_gemm.hip", "epg_s3_lanes.hip", "epg_null.hip", "epg_wide.hip"]
 HEADERS = [CSRC / "epg_common.h", CSRC / "epg_count.h", ROOT / "include" / "epilogos_amd.h"]
 ARCH = "gfx950"
 
@@ -76,7 +76,11 @@ def _compile_one(src, obj, extra_flags, verbose):
 
 def build_library(force=False, verbose=False, extra_flags=()):
     """Compile every HIP source into one shared library (one object per source, the stale ones in parallel, then one
-    link).  Returns the path."""
+    link).  Returns the path.  EPILOGOS_BUILD_EXPERIMENTS=1 in the environment builds with -DEPILOGOS_BUILD_EXPERIMENTS: the
+    measurement switches of the kernels (EPG_S3_DBG, EPG_S3_SCORE_DBG, EPG_S3_KC, EPG_S3_AHEAD, EPG_S3_MFMA, EPG_PAIR_WAVES) then
+    read the environment; the default library never does."""
+    if os.environ.get("EPILOGOS_BUILD_EXPERIMENTS") == "1":
+        extra_flags = tuple(extra_flags) + ("-DEPILOGOS_BUILD_EXPERIMENTS",)
     if not force and not is_stale():
         return LIB_PATH
     from concurrent.futures import ThreadPoolExecutor

@@ -20,6 +20,15 @@ int num_cus();
 // budget, calls too small for the reduced contraction ...).  The tests must be able to run a fallback on THEIR small shapes and
 // compare it with the default: epg_test_force(which, value) (epg_abi.hip; declared in the header as a test hook) sets one of
 // these, 0 = the library decides.  There is no environment variable in any dispatch path of the default build.
+// Measurement switches (EPG_*_DBG, chunk sizes ...) exist only in a library built with EPILOGOS_BUILD_EXPERIMENTS=1
+// (python -m epilogos_amd.build reads the variable): the default library never looks at the environment.
+#ifdef EPILOGOS_BUILD_EXPERIMENTS
+#include <stdlib.h>
+static inline const char* exp_env(const char* name) { return getenv(name); }
+#else
+static inline const char* exp_env(const char*) { return nullptr; }
+#endif
+
 enum Force { FORCE_NULL_SEQ = 0, FORCE_S3_SCORE_BINS, FORCE_S3_CONTRACTION, FORCE_S3_HIST_LDS, FORCE_COUNT };
 extern int g_force[FORCE_COUNT];
 

@@ -73,12 +73,21 @@ void join_all(std::vector<std::thread>& th) {
 // threads to use when the caller says 0: EPILOGOS_HOST_THREADS when set (the share of the host the driver gives this rank: a
 // node's cores divided by the ranks on it, capped by -c), else the hardware threads, capped by the cgroup CPU quota (a container
 // may see 256 hardware threads and be allowed 16 of them at a time) and by 64
+// The budget is held in an atomic: reader threads ask for it while Python (or torch, importing next to the early readers) may
+// be changing the environment, and a getenv beside a setenv is undefined before glibc 2.40.  The variable is read ONCE, when the
+// library first needs a budget; after that only epgio_set_host_threads changes it (the binding calls it from host_budget()).
+static std::atomic<int> g_host_threads{-1};      // -1: not looked at yet; 0: no budget given (hardware threads / cgroup quota)
 int n_threads(int32_t req) {
     if (req > 0) return req;
-    if (const char* e = getenv("EPILOGOS_HOST_THREADS")) {
-        const int v = atoi(e);
-        if (v > 0) return std::min(v, 64);
+    int b = g_host_threads.load(std::memory_order_relaxed);
+    if (b < 0) {
+        const char* e = getenv("EPILOGOS_HOST_THREADS");
+        const int v = e ? atoi(e) : 0;
+        int expect = -1;
+        g_host_threads.compare_exchange_strong(expect, v > 0 ? v : 0);
+        b = g_host_threads.load(std::memory_order_relaxed);
     }
+    if (b > 0) return std::min(b, 64);
     static const int cached = [] {
         unsigned hc = std::thread::hardware_concurrency();
         if (!hc) hc = 4;
@@ -342,7 +351,9 @@ bool inflate_bgzf(const unsigned char* in, size_t flen, Text& t, int32_t threads
                     epginflate::Out o{scratch.data(), 0, 65536};
                     auto no_grow = [](size_t) { return false; };
                     const size_t used = epginflate::inflate_raw(in + b.in_off, b.in_len, o, no_grow);
-                    if (used != b.in_len || o.pos != b.isize || epgcrc::crc32_fast(0, scratch.data(), b.isize) != b.crc) { bad.store(1); return; }
+                    // (inflate_raw returns 0 for "not a deflate stream": a member whose payload is EMPTY must not pass as 0 == 0 --
+                    // raw deflate needs two bytes at least, the BGZF end-of-file block has exactly two -- zlib rejects it too)
+                    if (b.in_len < 2 || used == 0 || used != b.in_len || o.pos != b.isize || epgcrc::crc32_fast(0, scratch.data(), b.isize) != b.crc) { bad.store(1); return; }
                     memcpy(t.heap + b.out_off, scratch.data(), b.isize);
                 }
             }
@@ -588,6 +599,7 @@ void epgio_thread_census(int32_t* live, int32_t* peak, int32_t reset) {
 }
 
 int32_t epgio_default_threads(void) { return n_threads(0); }
+void epgio_set_host_threads(int32_t n) { g_host_threads.store(n > 0 ? n : 0, std::memory_order_relaxed); }
 
 
 int64_t epgio_inflate_mem(const void* in, int64_t n, void* out, int64_t cap, int32_t own) {

@@ -524,9 +524,8 @@ static int check_score_from_hist_args(const uint16_t* H, const double* out64, co
 template <typename OT>
 static int launch_score_s1_from_hist_t(const uint16_t* H, long total, int32_t S, const OT* T, int nent, OT* out, u64* zero_counts, hipStream_t st) {
     const size_t tbytes = (size_t)nent * sizeof(OT);
-    static const bool no_lds = [] { const char* e = getenv("EPG_S1_SCORE"); return e && e[0] == 'g'; }();   // A/B: gather from memory
-    static const int rev = [] { const char* e = getenv("EPG_S1_SCORE_ORDER"); return (e && e[0] == 'f') ? 0 : 1; }();   // A/B: "forward"
-    if (tbytes <= 150 * 1024 && !no_lds) {             // the table in LDS: blocks of 16 waves, as many per CU as tables fit (<= 2)
+    const int rev = 1;      // the grid walks H from its last row to the first: what the count pass wrote last is still cached
+    if (tbytes <= 150 * 1024) {             // the table in LDS: blocks of 16 waves, as many per CU as tables fit (<= 2)
         const int per_cu = tbytes <= 75 * 1024 ? 2 : 1;
         long nb = (total / 4 + 4095) / 4096;
         if (nb > (long)num_cus() * per_cu) nb = (long)num_cus() * per_cu;

@@ -8,146 +8,23 @@ namespace epg {
 
 // ---------------------------------------------------------------------------------------------------------------
 // S2 expected: C[i,j] += sum_b h_i*h_j (i != j), h_i*(h_i - 1) (i == j)      (expected.py:146-158 s2Calc)
-// The matrix is symmetric, so one thread per UNORDERED state pair i <= j (171 at S = 18) plus one per state for
-// sum_b h_i (the diagonal's correction).  A batch of 128 bins is staged in LDS as bin PAIRS -- word (i, k) = counts of
-// state i in bins 2k and 2k+1 as two u16 -- so that one v_dot2_u32_u16 adds two bins' products to a 32-bit partial
-// sum: with counts < 4096 (any real N) 128 products stay below 2^32 and the partial sum goes to the u64 accumulator
-// once per batch.  A batch with a larger count takes the plain u64 path.  Exact integer arithmetic either way.
-// Reads 2*S bytes per bin; 15 M bins x 18 states: 0.43 ms (the per-ordered-pair u64 version took 1.5 ms).
+// The matrix is symmetric: unordered state pairs i <= j plus sum_b h_i per state (the diagonal's correction).  Exact integers.
+// (Round 1's block-wide kernel -- one thread per pair, three block barriers per 128 bins: 70 % of the wave cycles waiting -- was
+// replaced by the wave-level kernel below in round 2 and deleted in round 5.)
 // ---------------------------------------------------------------------------------------------------------------
-constexpr int S2H_BATCH = 128;
-constexpr int S2H_PAIRS = S2H_BATCH / 2;
-constexpr int S2H_ROLES = 3;                 // 256 threads x 3 >= S(S+1)/2 + S for S <= 31
-constexpr int S2H_LD = S2H_PAIRS + 1;        // row stride of the pair matrix in words: odd, rows start on different banks
 typedef unsigned short v2u16 __attribute__((ext_vector_type(2)));
 
-// H2 (may be NULL): a second histogram array of the same shape, added bin by bin before the products -- the counts of the
-// column concatenation [A|B] of paired mode (helpers.py:173) from the two groups' histograms (halves cannot carry: a
-// bin's count over both groups is at most N_A + N_B <= 65535).
-__global__ __launch_bounds__(256) void k_s2_hist_from_binhist(const u16* __restrict__ H, const u16* __restrict__ H2, long R, int S,
-                                                               u64* __restrict__ counts) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    u16* s_raw = reinterpret_cast<u16*>(smem);                                   // [S2H_BATCH][S]
-    u32* s_p = reinterpret_cast<u32*>(smem + (((size_t)S2H_BATCH * S * 2 + 15) & ~(size_t)15));   // [S][S2H_LD]
-    // roles: pair (i <= j) for role < npair, row sum of state role - npair for the next S roles; up to S2H_ROLES per thread
-    const int npair = S * (S + 1) / 2;
-    int ti[S2H_ROLES], tj[S2H_ROLES];
-    u64 acc[S2H_ROLES];
-#pragma unroll
-    for (int q = 0; q < S2H_ROLES; ++q) {
-        const int role = threadIdx.x + 256 * q;
-        ti[q] = -1;
-        tj[q] = 0;
-        acc[q] = 0;
-        if (role < npair) {
-            int t = role, i = 0;
-            while (t >= S - i) { t -= S - i; ++i; }
-            ti[q] = i;
-            tj[q] = i + t;
-        } else if (role < npair + S) {
-            ti[q] = role - npair;
-            tj[q] = -1;                                                          // sum of h_ti
-        }
-    }
-    // a batch is 256*S bytes = 16*S 16-byte words: at most two per thread, requested one batch ahead
-    const long nb = (R + S2H_BATCH - 1) / S2H_BATCH;
-    const int nw = 16 * S;
-    const long total_bytes = R * S * 2;
-    auto fetch = [&](long batch, int w) -> uint4 {
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (batch >= nb || w >= nw) return v;
-        const long off = batch * (256L * S) + 16L * w;
-        const char* src = reinterpret_cast<const char*>(H) + off;
-        if (off + 16 <= total_bytes) {
-            v = *reinterpret_cast<const uint4*>(src);
-            if (H2) {
-                const uint4 v2 = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(H2) + off);
-                v.x += v2.x; v.y += v2.y; v.z += v2.z; v.w += v2.w;
-            }
-            return v;
-        }
-        u16 t[8] = {0, 0, 0, 0, 0, 0, 0, 0};                                       // the words around the end of H
-        for (int k = 0; k < 8; ++k)
-            if (off + 2 * k < total_bytes) {
-                t[k] = *reinterpret_cast<const u16*>(src + 2 * k);
-                if (H2) t[k] = (u16)(t[k] + *reinterpret_cast<const u16*>(reinterpret_cast<const char*>(H2) + off + 2 * k));
-            }
-        return make_uint4(t[0] | (u32)t[1] << 16, t[2] | (u32)t[3] << 16, t[4] | (u32)t[5] << 16, t[6] | (u32)t[7] << 16);
-    };
-    uint4 pre0 = fetch(blockIdx.x, threadIdx.x), pre1 = fetch(blockIdx.x, threadIdx.x + 256);
-    for (long batch = blockIdx.x; batch < nb; batch += gridDim.x) {
-        const long r0 = batch * S2H_BATCH;
-        const int rows = (int)((R - r0) < S2H_BATCH ? (R - r0) : S2H_BATCH);
-        __syncthreads();
-        int big = 0;
-        {
-            uint4* dst = reinterpret_cast<uint4*>(s_raw);
-            if ((int)threadIdx.x < nw) dst[threadIdx.x] = pre0;
-            if ((int)threadIdx.x + 256 < nw) dst[threadIdx.x + 256] = pre1;
-            const u32 m = pre0.x | pre0.y | pre0.z | pre0.w | pre1.x | pre1.y | pre1.z | pre1.w;
-            big = (m & 0xF000F000u) != 0;
-            pre0 = fetch(batch + gridDim.x, threadIdx.x);                         // lands while this batch is counted
-            pre1 = fetch(batch + gridDim.x, threadIdx.x + 256);
-        }
-        big = __syncthreads_or(big);
-        if (!big) {
-            for (int e = threadIdx.x; e < S * S2H_PAIRS; e += 256) {
-                const int i = e / S2H_PAIRS, k = e - i * S2H_PAIRS;
-                s_p[i * S2H_LD + k] = (u32)s_raw[(2 * k) * S + i] | ((u32)s_raw[(2 * k + 1) * S + i] << 16);
-            }
-            __syncthreads();
-#pragma unroll
-            for (int q = 0; q < S2H_ROLES; ++q) {
-                if (ti[q] < 0) continue;
-                const u32* pi = s_p + ti[q] * S2H_LD;
-                u32 part = 0;
-                if (tj[q] >= 0) {
-                    const u32* pj = s_p + tj[q] * S2H_LD;
-#pragma unroll 8
-                    for (int k = 0; k < S2H_PAIRS; ++k)
-                        part = __builtin_amdgcn_udot2(__builtin_bit_cast(v2u16, pi[k]), __builtin_bit_cast(v2u16, pj[k]), part, false);
-                } else {
-#pragma unroll 8
-                    for (int k = 0; k < S2H_PAIRS; ++k)
-                        part = __builtin_amdgcn_udot2(__builtin_bit_cast(v2u16, pi[k]), __builtin_bit_cast(v2u16, 0x00010001u), part, false);
-                }
-                acc[q] += part;
-            }
-        } else {                                                                 // counts >= 4096: 64-bit products
-#pragma unroll
-            for (int q = 0; q < S2H_ROLES; ++q) {
-                if (ti[q] < 0) continue;
-                u64 a = 0;
-                for (int r = 0; r < rows; ++r) {
-                    const u64 hi = s_raw[r * S + ti[q]];
-                    a += tj[q] >= 0 ? hi * (u64)s_raw[r * S + tj[q]] : hi;
-                }
-                acc[q] += a;
-            }
-        }
-    }
-    // C[i,j] = C[j,i] = sum h_i h_j;  C[i,i] = sum h_i^2 - sum h_i
-#pragma unroll
-    for (int q = 0; q < S2H_ROLES; ++q) {
-        if (ti[q] < 0 || !acc[q]) continue;
-        if (tj[q] < 0) atomicAdd(&counts[ti[q] * S + ti[q]], (u64)0 - acc[q]);    // two's complement: adds -sum h_i
-        else {
-            atomicAdd(&counts[ti[q] * S + tj[q]], acc[q]);
-            if (ti[q] != tj[q]) atomicAdd(&counts[tj[q] * S + ti[q]], acc[q]);
-        }
-    }
-}
-
 // ---------------------------------------------------------------------------------------------------------------
-// The same counts, every WAVE on its own (round 2).  PMC of the block-wide kernel above: SQ_WAIT_ANY 70 % of the wave
-// cycles, VALU 9 % -- three block barriers per 128 bins with little work between them.  Here a wave owns tiles of 64 bins:
+// Every WAVE on its own.  A wave owns tiles of 64 bins:
 // it fetches a tile's 128*S bytes one tile ahead with whole-line loads, parks them in its own LDS slot, re-packs them as
 // bin PAIRS per state (word (i, k) = counts of state i in bins 2k and 2k+1, row stride 33 words) and contracts them with
 // v_dot2_u32_u16 in REGISTER TILES: a lane owns a 3 x 3 block of state pairs (groups gi <= gj of three states) and every
 // third pair-word k, so six LDS words feed nine dot products (the one-pair-per-thread form read two words per product).
 // Diagonal blocks also sum their three states' counts (the -sum h_i of the diagonal).  Only wave-level barriers.
 // Exact: a lane's partial sums are < 2^32 while counts are < 4096 (11 words x 2 products); a tile holding a larger count
-// takes a plain u64 path.  H2: optional second histogram array added bin by bin (paired mode, see above).
+// takes a plain u64 path.  H2 (may be NULL): a second histogram array of the same shape, added bin by bin before the products --
+// the counts of the column concatenation [A|B] of paired mode (helpers.py:173) from the two groups' histograms (halves cannot
+// carry: a bin's count over both groups is at most N_A + N_B <= 65535).
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int S2W_LD = 33;                   // pair-matrix row stride in words
 // S2W_MAXPASS = ceil(#block roles / 64): 1 for S <= 30 (55 roles), 2 for S = 31 (66)
@@ -390,74 +267,6 @@ __global__ __launch_bounds__(256) void k_score_s2_from_hist(const u16* __restric
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// S2 score when no q[i,j] is zero (every whole-genome background): the sum over i is linear in the bin's counts once the
-// logs are split,
-//     sum_i h_i * other_ij * (LH[h_i] + L_ij - LPQ[i,j])
-//   = h_j * [ sum_i h_i * (LH[h_i] - LPQ[i,j]) + LH[h_j] * sum_i h_i ]   (all i as if i != j)
-//     - h_j * h_j * (2 LH[h_j] - LPQ[j,j]) + h_j * (h_j - 1) * (LH[h_j] + LH[h_j - 1] - LPQ[j,j])   (the diagonal put right)
-// so a lane (bin, j) keeps column j of LPQ in registers and does one subtract and one fma per i on the bin's
-// (h_i, LH[h_i]) pairs, which sit in LDS and are broadcast to the S lanes of the bin: ~2 float64 operations per term
-// instead of ~8 instructions with a per-term mask.  Same masked-zero semantics: h_i == 0 and h_j == 0 give exact zeros.
-// Float64 throughout; the order of the sum differs from the reference's, the result by ~1e-13 relative.
-// ---------------------------------------------------------------------------------------------------------------
-template <int S, typename OT, bool LDS_LH>
-__global__ __launch_bounds__(256) void k_score_s2_fast(const u16* __restrict__ H, long R, double inv_perms, int maxc,
-                                                        const double* __restrict__ gLH, const double* __restrict__ gLPQ,
-                                                        OT* __restrict__ out) {
-    if (gLPQ[S * S] != 0.0) return;                  // some q == 0: the general kernel runs instead
-    constexpr int BPW = 64 / S;
-    __shared__ double2 s_hl[4][BPW * S];
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    double* s_LH = reinterpret_cast<double*>(smem);  // log2 table in LDS when it fits (maxc < 4096): the gather per count
-    if (LDS_LH) {                                    // is then ~100 cycles instead of an L2 round trip on the critical path
-        for (int e = threadIdx.x; e <= maxc; e += 256) s_LH[e] = gLH[e];
-        __syncthreads();
-    }
-    const double* LH = LDS_LH ? s_LH : gLH;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int bsub = lane / S, j = lane - bsub * S;
-    const bool active = bsub < BPW;
-    double lpq[S];
-#pragma unroll
-    for (int i = 0; i < S; ++i) lpq[i] = gLPQ[i * S + (active ? j : 0)];
-    const double lpqjj = gLPQ[(active ? j : 0) * (S + 1)];
-    const double2* hl = &s_hl[wave][(active ? bsub : 0) * S];
-    const long ngroups = (R + BPW - 1) / BPW;
-    const long stride = (long)gridDim.x * 4;
-    long grp = (long)blockIdx.x * 4 + wave;
-    auto load_h = [&](long g) -> u32 {
-        const long row = g * BPW + bsub;
-        return (g < ngroups && active && row < R) ? (u32)H[row * S + j] : 0u;
-    };
-    u32 hnext = load_h(grp);
-    for (; grp < ngroups; grp += stride) {
-        const long row = grp * BPW + bsub;
-        const bool valid = active && row < R;
-        u32 hj = hnext;
-        hnext = load_h(grp + stride);                // the next group's counts travel while this one is scored
-        if (hj > (u32)maxc) hj = (u32)maxc;
-        const double lj = LH[hj];
-        const double ljm1 = LH[hj ? hj - 1 : 0];
-        const double dj = (double)hj;
-        __builtin_amdgcn_wave_barrier();
-        if (active) s_hl[wave][bsub * S + j] = make_double2(dj, lj);
-        __builtin_amdgcn_wave_barrier();
-        double t = 0.0, n = 0.0;
-#pragma unroll
-        for (int i = 0; i < S; ++i) {
-            const double2 v = hl[i];
-            t = fma(v.x, v.y - lpq[i], t);
-            n += v.x;
-        }
-        const double all = fma(lj, n, t);
-        const double diag_as_off = dj * (2.0 * lj - lpqjj);
-        const double diag = (dj - 1.0) * (lj + ljm1 - lpqjj);
-        const double sc = hj ? dj * inv_perms * (all - diag_as_off + diag) : 0.0;
-        if (valid) out[row * S + j] = (OT)sc;
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------------------
 // S2 score, one LANE per bin (no q == 0; S = 15 / 18 / 25).  With p = num / P and log2(p/q) = log2(num) - LPQ[i,j]
 // (LPQ = log2(P q)), num = h_i h_j (i != j) or h_j (h_j - 1) (i == j), the sum over i collapses to
 //     score[j] = h_j / P * ( A - G_j + LPQ[j,j] + LH[h_j] (n - h_j - 1) + (h_j - 1) LH[h_j - 1] )
@@ -466,8 +275,8 @@ __global__ __launch_bounds__(256) void k_score_s2_fast(const u16* __restrict__ H
 // S x S matrix-vector product G = h . LPQ.  LPQ does not depend on the bin, so with a lane per bin its entries are
 // WAVE-UNIFORM: they are read with scalar loads (column j of LPQ = 8*S contiguous bytes of the transposed copy) and enter
 // v_fma_f64 as SGPR operands -- one float64 FMA per (i, j) and nothing else in the inner loop: no LDS broadcast, no idle
-// lanes (the (bin, j)-per-lane kernel above runs 54 of 64 lanes and spends three float64 operations plus one LDS read per
-// term: 1.40 ms for 15 M bins at S = 18).  A lane reads its bin's 2*S bytes of H directly (the wave's rows are one
+// lanes (round 1's (bin, j)-per-lane kernel ran 54 of 64 lanes and spent three float64 operations plus one LDS read per
+// term: 1.40 ms for 15 M bins at S = 18; deleted in round 5).  A lane reads its bin's 2*S bytes of H directly (the wave's rows are one
 // contiguous span) one iteration ahead, gathers LH[h_i] from the log table in LDS, and stages its S outputs in LDS so
 // that the wave writes whole lines.  Float64 throughout; differs from the reference's i-ascending sum by ~1e-13 relative.
 // ---------------------------------------------------------------------------------------------------------------
@@ -901,7 +710,7 @@ int pair_scores_s1_parts_impl(int32_t nparts, const uint16_t* const* HA, const u
     int waves = (int)((160 * 1024 - tab) / per_wave);
     if (waves > PF_WAVES_MAX) waves = PF_WAVES_MAX;
     {
-        const char* e = getenv("EPG_PAIR_WAVES");                                     // A/B measurements
+        const char* e = exp_env("EPG_PAIR_WAVES");                                    // (experiments build only)
         if (e && atoi(e) >= 1 && atoi(e) < waves) waves = atoi(e);
     }
     const size_t shmem = tab + (size_t)waves * per_wave;
@@ -964,17 +773,7 @@ int hist_s2_from_binhist_impl(const uint16_t* H, const uint16_t* H2, int64_t R, 
     if (R == 0) return EPG_OK;
     if (!H || !counts) return fail(EPG_ERR_INVALID_ARG, "hist_s2: NULL argument");
     if (S > 31) return wide_hist_s2_from_binhist(H, H2, R, S, counts, st);          // the wide models: epg_wide.hip
-    const long nb = (R + S2H_BATCH - 1) / S2H_BATCH;
     if ((reinterpret_cast<uintptr_t>(H) & 15) || (reinterpret_cast<uintptr_t>(H2) & 15)) return fail(EPG_ERR_INVALID_ARG, "hist_s2: H must be 16-byte aligned");
-    static const bool use_block = [] { const char* e = getenv("EPG_S2_HIST"); return e && e[0] == 'b'; }();   // A/B: round-1 kernel
-    if (use_block) {
-        long blocks = nb < num_cus() * 8L ? nb : num_cus() * 8L;
-        const size_t shmem = (((size_t)S2H_BATCH * S * 2 + 15) & ~(size_t)15) + (size_t)S * S2H_LD * 4;
-        hipLaunchKernelGGL(k_s2_hist_from_binhist, dim3((int)blocks), dim3(256), shmem, st, H, H2, (long)R, S,
-                           reinterpret_cast<u64*>(counts));
-        EPG_LAUNCH_CHECK("k_s2_hist_from_binhist");
-        return EPG_OK;
-    }
     const long ntiles = (R + 63) / 64;
     long blocks = (ntiles + 3) / 4;
     if (blocks > num_cus() * 8L) blocks = num_cus() * 8L;
@@ -1014,8 +813,6 @@ int score_s2_from_hist_impl(const uint16_t* H, int64_t R, int32_t N, int32_t S, 
     EPG_LAUNCH_CHECK("k_score_s2_from_hist");
     const bool lds_lh = N < 4096;
     const size_t lh_bytes = lds_lh ? (size_t)(N + 1) * 8 : 0;
-    // EPG_S2_SCORE=pair selects the older (bin, j)-per-lane kernel for A/B measurements; default: one lane per bin
-    static const bool use_pair = [] { const char* e = getenv("EPG_S2_SCORE"); return e && e[0] == 'p'; }();
     const long ntiles = (R + 63) / 64;
     long bblocks = (ntiles + 3) / 4;
     if (bblocks > num_cus() * 4L) bblocks = num_cus() * 4L;
@@ -1023,21 +820,15 @@ int score_s2_from_hist_impl(const uint16_t* H, int64_t R, int32_t N, int32_t S, 
     // only while both fit the 64 KB a workgroup gets without asking (S = 25 with float64 outputs: N <= 1791)
     const bool lds32 = lds_lh && (size_t)256 * S * 4 + lh_bytes <= 65536, lds64 = lds_lh && (size_t)256 * S * 8 + lh_bytes <= 65536;
 #define EPG_S2_FAST(SV)                                                                                                         \
-    if (S == SV && !use_pair) {                                                                                                 \
+    if (S == SV) {                                                                                                              \
         if (out32 && lds32) hipLaunchKernelGGL((k_score_s2_bin<SV, float, true>), dim3((int)bblocks), dim3(256), lh_bytes, st, H, (long)R, inv, N, LH, LPQ, out32);   \
         if (out32 && !lds32) hipLaunchKernelGGL((k_score_s2_bin<SV, float, false>), dim3((int)bblocks), dim3(256), 0, st, H, (long)R, inv, N, LH, LPQ, out32);         \
         if (out64 && lds64) hipLaunchKernelGGL((k_score_s2_bin<SV, double, true>), dim3((int)bblocks), dim3(256), lh_bytes, st, H, (long)R, inv, N, LH, LPQ, out64);  \
         if (out64 && !lds64) hipLaunchKernelGGL((k_score_s2_bin<SV, double, false>), dim3((int)bblocks), dim3(256), 0, st, H, (long)R, inv, N, LH, LPQ, out64);        \
-    } else if (S == SV && lds_lh) {                                                                                             \
-        if (out32) hipLaunchKernelGGL((k_score_s2_fast<SV, float, true>), dim3((int)blocks), dim3(256), lh_bytes, st, H, (long)R, inv, N, LH, LPQ, out32);   \
-        if (out64) hipLaunchKernelGGL((k_score_s2_fast<SV, double, true>), dim3((int)blocks), dim3(256), lh_bytes, st, H, (long)R, inv, N, LH, LPQ, out64);  \
-    } else if (S == SV) {                                                                                                       \
-        if (out32) hipLaunchKernelGGL((k_score_s2_fast<SV, float, false>), dim3((int)blocks), dim3(256), 0, st, H, (long)R, inv, N, LH, LPQ, out32);   \
-        if (out64) hipLaunchKernelGGL((k_score_s2_fast<SV, double, false>), dim3((int)blocks), dim3(256), 0, st, H, (long)R, inv, N, LH, LPQ, out64);  \
     }
     EPG_S2_FAST(15) EPG_S2_FAST(18) EPG_S2_FAST(25)
 #undef EPG_S2_FAST
-    EPG_LAUNCH_CHECK("k_score_s2_fast");
+    EPG_LAUNCH_CHECK("k_score_s2_bin");
     return EPG_OK;
 }
 

@@ -294,10 +294,6 @@ int64_t s3_lanes_ws_bytes(int64_t R, int N, int S);
 int score_s3_lanes(const int8_t* X8, int64_t R, int32_t N, int64_t ldx, int32_t S, const float* q, double* out64, float* out32, void* ws,
                    int64_t ws_bytes, hipStream_t st);
 
-bool s3_sparse_ok(int N, int S);
-int64_t s3_sparse_ws_bytes(int64_t R, int N, int S);
-int score_s3_sparse(const int8_t* X8, int64_t R, int32_t N, int64_t ldx, int32_t S, const float* q, double* out64, float* out32, void* ws,
-                    int64_t ws_bytes, hipStream_t st, bool forced);
 
 int wide_hist_s3(const int8_t* X, int64_t R, int32_t N, int64_t ldx, int32_t S, int32_t* counts, hipStream_t st);
 int wide_score_s3(const int8_t* X, int64_t R, int32_t N, int64_t ldx, int32_t S, const float* q, double* out64, float* out32, void* ws,
@@ -311,7 +307,6 @@ int64_t s3_ws_bytes(int64_t R, int N, int S) {
     // precomputed fp4 one-hot operand for the default kernel)
     int64_t score = s3_table_bytes(N, S) + s3_mfma_ws_bytes(R, N) + align_up(R * S * 8, 256);
     if (s3_lanes_ok(N, S) && s3_lanes_ws_bytes(R, N, S) > score) score = s3_lanes_ws_bytes(R, N, S);
-    if (s3_sparse_ok(N, S) && s3_sparse_ws_bytes(R, N, S) > score) score = s3_sparse_ws_bytes(R, N, S);
     const int64_t expected = s3_gemm_ws_bytes(R, N, S);
     return score > expected ? score : expected;
 }
@@ -324,12 +319,11 @@ int hist_s3_impl(const int8_t* X8, int64_t R, int32_t N, int64_t ldx, int32_t S,
     if (!X8 || !counts) return fail(EPG_ERR_INVALID_ARG, "hist_s3: NULL argument");
     if (S > 31) return wide_hist_s3(X8, R, N, ldx, S, counts, st);                      // the wide models: epg_wide.hip
     // matrix-core path when the caller gave room for the transposed matrix (S <= 30: padding rows use pattern 30);
-    // EPG_S3_HIST=lds forces the LDS-atomic kernel (A/B measurements, and the fallback for S = 31 / no workspace)
-    static const bool force_lds = [] { const char* e = getenv("EPG_S3_HIST"); return e && e[0] == 'l'; }();
-    // default: the precomputed-operand contraction (epg_s3_gemm.hip) when the workspace holds a chunk of the operand;
-    // EPG_S3_MFMA = f / e / b selects one of the build-in-kernel variants of epg_s3_mfma.hip (A/B measurements)
-    static const char mfma_choice = [] { const char* e = getenv("EPG_S3_MFMA"); return e ? e[0] : 'g'; }();
-    if (!force_lds && S <= 30 && ws && mfma_choice == 'g' && ws_bytes >= s3_gemm_ws_min_bytes(R, N, S))
+    // the LDS-counter kernel is the fallback for S = 31 / no workspace (epg_test_force(3, 1): on any shape);
+    // default: the precomputed-operand contraction (epg_s3_gemm.hip) when the workspace holds a chunk of the operand, else the
+    // build-in-kernel contraction of epg_s3_mfma.hip (a workspace that holds the transposed matrix only)
+    const bool force_lds = g_force[FORCE_S3_HIST_LDS] != 0;
+    if (!force_lds && S <= 30 && ws && ws_bytes >= s3_gemm_ws_min_bytes(R, N, S))
         return hist_s3_gemm(reinterpret_cast<const char*>(X8), R, N, ldx, S, counts, ws, ws_bytes, st);
     if (!force_lds && S <= 30 && ws && ws_bytes >= s3_mfma_ws_bytes(R, N))
         return hist_s3_mfma(reinterpret_cast<const char*>(X8), R, N, ldx, S, counts, ws, st);
@@ -353,20 +347,11 @@ int score_s3_impl(const int8_t* X8, int64_t R, int32_t N, int64_t ldx, int32_t S
     if (R == 0) return EPG_OK;
     if (!X8 || !q || !ws) return fail(EPG_ERR_INVALID_ARG, "score_s3: NULL argument");
     if (S > 31) return wide_score_s3(X8, R, N, ldx, S, q, out64, out32, ws, ws_bytes, st);   // the wide models: epg_wide.hip
-    // default: the biosample-lane kernel (epg_s3_lanes.hip, S <= 21) when the workspace holds its table;
-    // EPG_S3_SCORE=bins selects k_s3_score below (A/B measurements; the path for S > 21)
-    const char* env = getenv("EPG_S3_SCORE");      // read per call: the tests run the kernels in one process
-    const bool force_bins = env && env[0] == 'b';
-    // EPG_S3_SCORE=sparse: the modal-state kernel (epg_s3_sparse.hip) -- the same integers as the dense kernel from ~1/3 of
-    // its gathers, and SLOWER on this chip (56 against 39 ms per 500 K bins at N = 833: a SIMD pays ~3.7 cycles per wave
-    // instruction of any kind, and steering a gather to a data-dependent accumulator register costs more instructions than
-    // the gathers it saves; epg_s3_sparse.hip, tools/ubench/gpr_idx.hip).  Kept selectable; not the default.
-    // It returns 1 for a matrix it cannot take (bytes that are not states): the dense kernel runs then.
-    const bool force_sparse = env && env[0] == 's';
-    if (force_sparse && s3_sparse_ok(N, S) && ws_bytes >= s3_sparse_ws_bytes(R, N, S) - (out64 ? align_up(R * S * 8, 256) : 0)) {
-        const int rc = score_s3_sparse(X8, R, N, ldx, S, q, out64, out32, ws, ws_bytes, st, true);
-        if (rc != 1) return rc;
-    }
+    // default: the biosample-lane kernel (epg_s3_lanes.hip, S <= 21) when the workspace holds its table; k_s3_score below is the
+    // path for S > 21 and smaller workspaces (epg_test_force(1, 1): on any shape).  Round 3's modal-state kernel (per-biosample base
+    // table + gathers only for biosamples off the modal state: the same integers from ~1/3 of the gathers, 1.43 x SLOWER -- a SIMD
+    // pays ~3.7 cycles per wave instruction of any kind, tools/ubench/gpr_idx.hip) was deleted in round 5.
+    const bool force_bins = g_force[FORCE_S3_SCORE_BINS] != 0;
     if (!force_bins && s3_lanes_ok(N, S) && ws_bytes >= s3_lanes_ws_bytes(R, N, S) - (out64 ? align_up(R * S * 8, 256) : 0))
         return score_s3_lanes(X8, R, N, ldx, S, q, out64, out32, ws, ws_bytes, st);
     const int64_t tb = s3_table_bytes(N, S), xtb = s3_mfma_ws_bytes(R, N);

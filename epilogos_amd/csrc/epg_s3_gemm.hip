@@ -335,180 +335,9 @@ __global__ __launch_bounds__(64 * G_NW, 2) void k_s3_syrk_fp4(const char* __rest
     g_epilogue(acc, smem, w, lane, bm, bn, N, S, counts, marg);
 }
 
-// ---- the same contraction with the two waves of a SIMD in opposite phases ("ping-pong", round 3; EPG_S3_SYRK=pp) -----------
-// In k_s3_syrk_fp4 all eight waves of the workgroup run the same phase at the same time.  Here waves 0-3 ("X") and their SIMD
-// partners 4-7 ("Y") alternate half a stage apart, a barrier after every half:
-//     half 2t     X: the 18 MFMAs of stage t (both k-steps sit in 48 registers)      Y: ds_read stage t, DMA its share of stage t - 1 + R
-//     half 2t + 1 X: ds_read stage t + 1, DMA its share of stage t + R               Y: the 18 MFMAs of stage t
-// The 36 tiles of a stage are fetched by X (5 per wave) and Y (4 per wave) with no surplus load; the ring holds R = 4 stages:
-// the slot of stage t is free once Y has read it (end of half 2t) and takes stage t + R in the next two halves, which X reads
-// in half 2t + 2R - 1 -- every wave waits for its own pieces at the end of a load half with the two most recent batches still
-// in flight (a batch has four halves, about two stages, to land).  Past the last stage the same instructions fetch stage 0
-// into the scrap.
-// MEASURED (profiles/r03p_s3_syrk_pingpong.txt): same counts, 0-1.5 % faster than k_s3_syrk_fp4 depending on the box -- not
-// the default.  The segment trace (EPG_S3_DBG & 32: s_memtime at the segment boundaries of one workgroup) shows why the
-// schedule cannot pay: a wave's 18 MFMAs take ~570 cycles to ISSUE (issue blocks on the pipe, 32 cycles each), and its load
-// half -- twelve ds_read_b128 and four or five DMA pieces -- takes 650-950 cycles while the partner's MFMAs run (400 with the
-// matrix pipe idle), whatever the priorities (none, MFMAs at 1, loads at 1) and wherever the DMA pieces go (moved behind the
-// MFMAs of the compute half they simply add to it: 810 cycles).  A wave's own instructions issue in order, so a stage costs
-// every wave its MFMA issue time plus its load time, ~1700 cycles; two waves per SIMD is all the registers allow (144
-// accumulators + 48 operand registers each), and the matrix pipe (2 x 576 cycles per stage) waits a third of the time.
-// the main loop of one role (ROLE 0: compute first; ROLE 1: load first), NL = pieces of a stage this wave fetches
-template <int R, int ROLE, bool TRACE>
-__device__ __forceinline__ void g_pp_loop(v16f (&acc)[3][3], char* smem, char* scrap, const char* src0, long stage_stride, const u32 (&soff)[5],
-                                          const u32 (&doff)[5], u32 baseA, u32 baseB, int G, bool active, int dbg, u32* trace) {
-    constexpr int NL = ROLE == 0 ? 5 : 4;
-    // TRACE (EPG_S3_DBG & 32, measurements only): the shader clock at the four segment boundaries of the first 64 stages
-    int tn = 0, tcur = 0;
-    auto stamp = [&]() {
-        if (TRACE && tcur >= 1000 && tn < 256) {                                       // 64 stages in steady state
-            const u32 c = (u32)__builtin_readcyclecounter();
-            if ((threadIdx.x & 63) == 0) trace[tn] = c;
-            ++tn;
-        }
-    };
-    auto dma = [&](int gs, int sl) {
-        const bool real = gs < G && !(dbg & 16);
-        const char* lsrc = src0 + (real ? (long)gs * stage_stride : 0L);              // wave-uniform base, 32-bit lane offsets
-        char* ldst = smem + sl * G_STAGE_BYTES;
-#pragma unroll
-        for (int j = 0; j < NL; ++j) {
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(lsrc + soff[j]),
-                                             (__attribute__((address_space(3))) void*)(real ? ldst + doff[j] : scrap), 16, 0, 0);
-        }
-    };
-    GOps o0, o1;
-    if (ROLE == 0) {
-        g_read<0>(o0, baseA, baseB);
-        g_read<1>(o1, baseA, baseB);
-        g_wait_lds(o0);
-        g_wait_lds(o1);
-    }
-    int slot = 0, slot_prev = R - 1;
-    for (int t = 0; t < G; ++t) {
-        const int slot1 = slot == R - 1 ? 0 : slot + 1;
-        tcur = t;
-        if (ROLE == 0) {
-            stamp();
-            g_mfma(o0, active, acc);
-            g_mfma(o1, active, acc);
-            __builtin_amdgcn_sched_barrier(0);
-            stamp();
-            __builtin_amdgcn_s_barrier();
-            __builtin_amdgcn_sched_barrier(0);
-            stamp();
-            const u32 sn = (u32)(t + 1 < G ? slot1 : slot) * G_STAGE_BYTES;            // past the end: a harmless re-read
-            g_read<0>(o0, baseA + sn, baseB + sn);
-            g_read<1>(o1, baseA + sn, baseB + sn);
-            dma(t + R, slot);                                          // the slot of stage t is free now
-            g_wait_lds(o0);
-            g_wait_lds(o1);
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NL) : "memory");
-            __builtin_amdgcn_sched_barrier(0);
-            stamp();
-            __builtin_amdgcn_s_barrier();
-            __builtin_amdgcn_sched_barrier(0);
-        } else {
-            stamp();
-            const u32 so = (u32)slot * G_STAGE_BYTES;
-            g_read<0>(o0, baseA + so, baseB + so);
-            g_read<1>(o1, baseA + so, baseB + so);
-            dma(t > 0 ? t - 1 + R : G, slot_prev);   // t = 0: stage R - 1 came with the prologue; a dummy keeps the count
-            g_wait_lds(o0);
-            g_wait_lds(o1);
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NL) : "memory");
-            __builtin_amdgcn_sched_barrier(0);
-            stamp();
-            __builtin_amdgcn_s_barrier();
-            __builtin_amdgcn_sched_barrier(0);
-            stamp();
-            g_mfma(o0, active, acc);
-            g_mfma(o1, active, acc);
-            __builtin_amdgcn_sched_barrier(0);
-            stamp();
-            __builtin_amdgcn_s_barrier();
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        slot_prev = slot;
-        slot = slot1;
-    }
-}
-
-template <int R, bool TRACE>
-__global__ __launch_bounds__(64 * G_NW, 2) void k_s3_syrk_pp(const char* __restrict__ E4, int NT, long nstages, long stages_per_split,
-                                                        const int* __restrict__ tasks, int ntasks, int N, int S,
-                                                        int* __restrict__ counts, int dbg, const int* __restrict__ gate, int want,
-                                                        int* __restrict__ marg) {
-    static_assert(G_NW == 8 && G_STAGE_TILES == 36, "2 x 4 waves: X fetches 4 x 5 tiles of a stage, Y 4 x 4");
-    if (gate && *gate != want) return;
-    extern __shared__ __attribute__((aligned(1024))) char smem[];
-    const int lane = threadIdx.x & 63;
-    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int wm = w / G_WN, wn = w % G_WN;
-    const int role = w >> 2;                                // waves w and w + 4 share a SIMD (MI355X_MICROARCH.md, LDS section)
-    const int xcd = blockIdx.x & 7, q8 = ntasks >> 3, r8 = ntasks & 7;
-    const int tix = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (blockIdx.x >> 3);
-    const int task = tasks[tix];
-    const int P = task & 0xffff, Q = task >> 16;
-    const int bm = G_WM * P + wm, bn = G_WN * Q + wn;
-    const bool active = bm <= bn && !(dbg & 8);
-    const long g0 = (long)blockIdx.y * stages_per_split;
-    const int G = (int)(nstages - g0 < stages_per_split ? nstages - g0 : stages_per_split);
-    if (G <= 0) return;
-
-    u32 soff[5], doff[5];                                   // byte offsets inside a stage of the operand (< 2 NT KiB) / of the ring slot
-    char* const scrap = smem + R * G_STAGE_BYTES + w * 1024;
-#pragma unroll
-    for (int j = 0; j < 5; ++j) {
-        const int s = role == 0 ? w * 5 + j : (j < 4 ? 20 + (w - 4) * 4 + j : 0);       // Y has no fifth piece
-        const int ks = s / (G_TA + G_TB), t = s - ks * (G_TA + G_TB);
-        const int gt = (dbg & 1) ? t : (t < G_TA ? P * G_TA + t : Q * G_TB + (t - G_TA));
-        soff[j] = (u32)(ks * NT + gt) * 1024u + (u32)lane * 16u;
-        doff[j] = (u32)s * 1024;
-    }
-    const char* src0 = E4 + g0 * G_KS * (long)NT * 1024;
-    const long stage_stride = (long)G_KS * NT * 1024;
-
-    v16f acc[3][3];
-#pragma unroll
-    for (int a = 0; a < 3; ++a)
-#pragma unroll
-        for (int b = 0; b < 3; ++b)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-
-    const u32 lds0 = (u32)(uintptr_t)smem + (u32)lane * 16;
-    const u32 baseA = lds0 + (u32)(wm * 3) * 1024, baseB = lds0 + (u32)(G_TA + wn * 3) * 1024;
-    // prologue: the first R stages, everything landed, one barrier
-#pragma unroll
-    for (int s = 0; s < R; ++s) {
-        const bool real = s < G;
-        const char* lsrc = src0 + (real ? (long)s * stage_stride : 0L);
-#pragma unroll
-        for (int j = 0; j < 5; ++j)
-            if (j < 4 || role == 0)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(lsrc + soff[j]),
-                                                 (__attribute__((address_space(3))) void*)(real ? smem + s * G_STAGE_BYTES + doff[j] : scrap), 16, 0, 0);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    u32* trace = reinterpret_cast<u32*>(smem + g_lds_bytes(R)) + w * 256;           // TRACE: 1 KiB per wave past the ring
-    if (role == 0)
-        g_pp_loop<R, 0, TRACE>(acc, smem, scrap, src0, stage_stride, soff, doff, baseA, baseB, G, active, dbg, trace);
-    else
-        g_pp_loop<R, 1, TRACE>(acc, smem, scrap, src0, stage_stride, soff, doff, baseA, baseB, G, active, dbg, trace);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the tail's dummy loads
-    __builtin_amdgcn_s_barrier();
-    if (TRACE && blockIdx.x == 96 && blockIdx.y == 0 && lane == 0 && (w == 0 || w == 4)) {   // task (P 0, Q 3): all eight waves active
-        // X: [before MFMAs, after MFMAs, after barrier, after loads] per stage; Y: [before loads, after loads, after barrier, after MFMAs]
-        // X: [MFMAs issued | barrier | load segment || barrier]   Y: [load segment | barrier | MFMAs issued || barrier]
-        for (int i = 0; i + 5 <= 256; i += 4)
-            printf("trace w%d stage %d: %u %u %u || %u\n", w, i / 4, trace[i + 1] - trace[i], trace[i + 2] - trace[i + 1], trace[i + 3] - trace[i + 2],
-                   trace[i + 4] - trace[i + 3]);
-    }
-    if (!active || (dbg & 2)) return;
-    g_epilogue(acc, smem, w, lane, bm, bn, N, S, counts, marg);
-}
+// (Round 3 built this contraction three more ways -- a ring of four stages, a ping-pong schedule of the SIMD partners with a
+// cycle trace of its segments, a one-wave-per-SIMD shape with 4 x 4 tiles -- each bit-identical and within +-3 % of this kernel
+// (profiles/r03p_*, r03s_*).  They were deleted in round 5: the library holds one schedule.)
 
 int transpose_states(const char* X, int64_t R, int32_t N, int64_t ldx, int32_t S, char* XT, int64_t Rp, int shift, hipStream_t st);
 
@@ -636,12 +465,12 @@ static int hist_s3_gemm_run(const char* XT, long Rp, int N, int S, int32_t* coun
 
 int hist_s3_gemm(const char* X, int64_t R, int32_t N, int64_t ldx, int32_t S, int32_t* counts, void* ws, int64_t ws_bytes,
                  hipStream_t st) {
-    static const int dbg_env = [] { const char* e = getenv("EPG_S3_DBG"); return e ? atoi(e) : 0; }();
-    // EPG_S3_REDUCED (read per call: the tests run both in one process): 0 = full contraction only, 1 = the reduced one whenever
-    // the workspace allows; default: from G_REDUCED_MIN_BINS bins on -- its fixed cost per call (zeroing and re-expanding a
-    // 0.8 GB count array: ~1.4 ms at N = 833) is what it saves on ~260 K bins
-    const char* red_env = getenv("EPG_S3_REDUCED");
-    const bool no_reduced = red_env ? red_env[0] == '0' : R < G_REDUCED_MIN_BINS;
+    static const int dbg_env = [] { const char* e = exp_env("EPG_S3_DBG"); return e ? atoi(e) : 0; }();   // (experiments build only)
+    // the reduced contraction from G_REDUCED_MIN_BINS bins on -- its fixed cost per call (zeroing and re-expanding a 0.8 GB count
+    // array: ~1.4 ms at N = 833) is what it saves on ~260 K bins; epg_test_force(2, 1 / 2): the full / the reduced one whatever
+    // the call's size (the tests compare the two on their small shapes)
+    const int forced = g_force[FORCE_S3_CONTRACTION];
+    const bool no_reduced = forced == 1 ? true : forced == 2 ? false : R < G_REDUCED_MIN_BINS;
     const long Rp = align_up(R, 512);                  // whole stages; padded bins hold 31, which matches no row
     const int NS = N * S, NSP = g_rows_padded(NS), NT = NSP / 32, NQ = NSP / G_BN;
     const int ntasks = g_ntasks(NQ);
@@ -651,23 +480,18 @@ int hist_s3_gemm(const char* X, int64_t R, int32_t N, int64_t ldx, int32_t S, in
     static bool attr_set = false;
     if (dbg_env & 4) {
         int nblk = -1;
-        hipOccupancyMaxActiveBlocksPerMultiprocessor(&nblk, reinterpret_cast<const void*>(k_s3_syrk_fp4<G_RING_DEFAULT>), 64 * G_NW,
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nblk, reinterpret_cast<const void*>(k_s3_syrk_fp4<G_RING_DEFAULT>), 64 * G_NW,
                                                      g_lds_bytes(G_RING_DEFAULT));
         fprintf(stderr, "k_s3_syrk_fp4: %d workgroups of %d threads per CU with %d bytes of LDS\n", nblk, 64 * G_NW, g_lds_bytes(G_RING_DEFAULT));
     }
     if (!attr_set) {
-        EPG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_s3_syrk_fp4<3>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    g_lds_bytes(3)));
-        EPG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_s3_syrk_fp4<4>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    g_lds_bytes(4)));
-        EPG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_s3_syrk_pp<4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, g_lds_bytes(4)));
-        EPG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_s3_syrk_pp<4, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    g_lds_bytes(4) + G_NW * 1024));
+        EPG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_s3_syrk_fp4<G_RING_DEFAULT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    g_lds_bytes(G_RING_DEFAULT)));
         attr_set = true;
     }
     // chunk = as many bins of the operand as the caller's workspace holds (every chunk ends in one epilogue of ~2 atomics
     // per cell of counts, so fewer, longer chunks are better); EPG_S3_KC overrides for measurements
-    static const long kc_env = [] { const char* e = getenv("EPG_S3_KC"); return e ? atol(e) / 512 * 512 : 0L; }();
+    static const long kc_env = [] { const char* e = exp_env("EPG_S3_KC"); return e ? atol(e) / 512 * 512 : 0L; }();   // (experiments build only)
     auto chunk_bins = [&](int64_t bytes_for_e4) {
         long KC = bytes_for_e4 / ((int64_t)NT * 1024) * 64 / 512 * 512;
         if (kc_env > 0 && kc_env < KC) KC = kc_env;
@@ -749,25 +573,8 @@ static int hist_s3_gemm_run(const char* XT, long Rp, int N, int S, int32_t* coun
         if (splits > 65535) splits = 65535;
         const long per = (nstages + splits - 1) / splits;
         const long nsplit = (nstages + per - 1) / per;
-        // EPG_S3_RING=3|4: depth of the LDS ring the operand stages are prefetched into (A/B measurements)
-        // (read per call: the tests switch schedules inside one process)
-        const char* ring_env = getenv("EPG_S3_RING");
-        const int ring = ring_env && (atoi(ring_env) == 3 || atoi(ring_env) == 4) ? atoi(ring_env) : G_RING_DEFAULT;
-        // EPG_S3_SYRK=pp: the ping-pong schedule (k_s3_syrk_pp; EPG_S3_DBG & 32: with the segment trace of one workgroup)
-        const char* syrk_env = getenv("EPG_S3_SYRK");
-        const bool pp = syrk_env && syrk_env[0] == 'p';
-        if (pp && (dbg_env & 32))
-            hipLaunchKernelGGL((k_s3_syrk_pp<4, true>), dim3((unsigned)ntasks, (unsigned)nsplit), dim3(64 * G_NW), g_lds_bytes(4) + G_NW * 1024, st,
-                               E4, NT, nstages, per, tasks, ntasks, N, S, counts, dbg_env, gate, want, marg);
-        else if (pp)
-            hipLaunchKernelGGL((k_s3_syrk_pp<4, false>), dim3((unsigned)ntasks, (unsigned)nsplit), dim3(64 * G_NW), g_lds_bytes(4), st, E4, NT, nstages,
-                               per, tasks, ntasks, N, S, counts, dbg_env, gate, want, marg);
-        else if (ring == 4)
-            hipLaunchKernelGGL(k_s3_syrk_fp4<4>, dim3((unsigned)ntasks, (unsigned)nsplit), dim3(64 * G_NW), g_lds_bytes(4), st, E4, NT, nstages,
-                               per, tasks, ntasks, N, S, counts, dbg_env, gate, want, marg);
-        else
-            hipLaunchKernelGGL(k_s3_syrk_fp4<3>, dim3((unsigned)ntasks, (unsigned)nsplit), dim3(64 * G_NW), g_lds_bytes(3), st, E4, NT, nstages,
-                               per, tasks, ntasks, N, S, counts, dbg_env, gate, want, marg);
+        hipLaunchKernelGGL(k_s3_syrk_fp4<G_RING_DEFAULT>, dim3((unsigned)ntasks, (unsigned)nsplit), dim3(64 * G_NW), g_lds_bytes(G_RING_DEFAULT), st, E4, NT,
+                           nstages, per, tasks, ntasks, N, S, counts, dbg_env, gate, want, marg);
         EPG_LAUNCH_CHECK("k_s3_syrk_fp4");
     }
     return EPG_OK;

@@ -409,8 +409,8 @@ int score_s3_lanes(const int8_t* X8, int64_t R, int32_t N, int64_t ldx, int32_t 
     const size_t red = (size_t)BL_GW * 2 * BL_EB * S * 8;
     if (shmem < red) shmem = red;
     // EPG_S3_SCORE_DBG (measurements only, results are wrong): 1 = every phase loads the same chunk, 2 = no table loads, 4 = no gathers
-    static const int dbg = [] { const char* e = getenv("EPG_S3_SCORE_DBG"); return e ? atoi(e) : 0; }();
-    static const int ahead = [] { const char* e = getenv("EPG_S3_AHEAD"); return e ? atoi(e) : 6; }();   // phases between touch and use
+    static const int dbg = [] { const char* e = exp_env("EPG_S3_SCORE_DBG"); return e ? atoi(e) : 0; }();
+    static const int ahead = [] { const char* e = exp_env("EPG_S3_AHEAD"); return e ? atoi(e) : 6; }();   // phases between touch and use
     const int npieces = chb >> 10;                                        // 1 .. 53 for S <= 20; 32 at S = 15, 43 at S = 18
 #define BL_LAUNCH(NP)                                                                                                            \
     do {                                                                                                                         \

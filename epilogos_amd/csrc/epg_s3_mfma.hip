@@ -482,7 +482,7 @@ int transpose_states(const char* X, int64_t R, int32_t N, int64_t ldx, int32_t S
 int hist_s3_mfma(const char* X, int64_t R, int32_t N, int64_t ldx, int32_t S, int32_t* counts, void* ws, hipStream_t st) {
     // EPG_S3_MFMA selects a kernel for A/B measurements: f (default) = fp4 MX with workgroup-shared A operands, e = fp4 MX
     // per wave, b = int8 with per-lane loads.  E / F need the 96 rows of a block to span at most 8 biosamples (S >= 14).
-    static const char choice = [] { const char* e = getenv("EPG_S3_MFMA"); return e && e[0] != 'g' ? e[0] : 'f'; }();
+    static const char choice = [] { const char* e = exp_env("EPG_S3_MFMA"); return e && e[0] != 'g' ? e[0] : 'f'; }();
     const char variant = S >= 14 ? choice : 'b';
     const long Rp = align_up(R, 512);             // whole macro-steps; padded bins hold 31, which matches no row
     char* XT = reinterpret_cast<char*>(ws);

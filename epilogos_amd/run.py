@@ -74,6 +74,9 @@ def _init_device_and_group(world, under_launcher):
     dist_backend = os.environ.get("EPILOGOS_DIST_BACKEND", "")
     if torch.cuda.is_available():
         local = int(os.environ.get("LOCAL_RANK", "0"))
+        if not dist_backend and local >= torch.cuda.device_count():
+            raise SystemExit("ERROR: rank %d of this node has no GPU: %d rank(s) were started for %d usable device(s) "
+                             "(--gpus / *_VISIBLE_DEVICES)" % (local, int(os.environ.get("LOCAL_WORLD_SIZE", "0") or 0), torch.cuda.device_count()))
         torch.cuda.set_device(local % torch.cuda.device_count() if dist_backend else local)
         device = torch.device("cuda", torch.cuda.current_device())
     if world > 1 or under_launcher:
@@ -300,6 +303,14 @@ def _visible_gpus():
                 n += 1
     except (OSError, ValueError):
         n = 0
+    # a container may see the host's whole KFD topology and only some of its render nodes: a GPU without an accessible
+    # /dev/dri/renderD* cannot be opened (a rank on it would die in torch.cuda.set_device)
+    try:
+        usable = len([d for d in Path("/dev/dri").iterdir() if d.name.startswith("renderD") and os.access(d, os.R_OK | os.W_OK)])
+        if n and usable:
+            n = min(n, usable)
+    except OSError:
+        pass
     for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
         v = os.environ.get(var)
         if v is not None:

@@ -127,6 +127,9 @@ int64_t epgio_inflate_mem(const void* in, int64_t n, void* out, int64_t cap, int
  * library's runnable threads right now and their peak since the last reset (callers inside the library + workers they
  * started; a caller waiting for its workers does not count). */
 int32_t epgio_default_threads(void);
+/* Sets that budget (n <= 0: none given).  The environment variable is read once, at the library's first use; the binding
+ * passes later values through here so that no native thread ever reads the environment while Python changes it. */
+void epgio_set_host_threads(int32_t n);
 /* How many files the caller is reading, or is about to read, side by side (worker threads that still have a file to do): the
  * "share" of threads == 0 divides by the larger of this and the readers inside the library at that moment -- a worker between
  * two files must not make the others believe its cores are free.  0 = no plan. */

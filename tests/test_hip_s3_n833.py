@@ -70,7 +70,7 @@ def test_s3_reduced_contraction(eng, case, oracle_counts, monkeypatch):
     """The contraction without each biosample's state S - 1 (its cells follow from the marginals, epg_s3_gemm.hip) against the
     full one: on the matrix WITH bytes that are not states the device-side flag must send the call down the full path, on the
     cleaned matrix the reduced path runs -- the same integers as the oracle either way, and accumulating into non-zero counts."""
-    monkeypatch.setenv("EPG_S3_REDUCED", "1")
+    eng._abi.call("epg_test_force", 2, 2)                        # the reduced contraction whatever the call's size
     dirty = eng.hist_s3(case["X"], N, S)
     assert torch.equal(dirty, case["mfma"])
     x = case["x"].copy()
@@ -81,9 +81,9 @@ def test_s3_reduced_contraction(eng, case, oracle_counts, monkeypatch):
     Xc = eng.states_to_device(x)
     red = eng.hist_s3(Xc, N, S)                                  # reduced contraction + reconstruction
     red2 = eng.hist_s3(Xc, N, S, counts=case["mfma"].clone())    # += into non-zero counts
-    monkeypatch.setenv("EPG_S3_REDUCED", "0")
+    eng._abi.call("epg_test_force", 2, 1)                        # the contraction over all S states
     full = eng.hist_s3(Xc, N, S)
-    monkeypatch.delenv("EPG_S3_REDUCED")
+    eng._abi.call("epg_test_force", 2, 0)
     assert torch.equal(red, full)
     assert torch.equal(red2, full + case["mfma"])
     assert int(red.sum(dtype=torch.int64)) == R * N * (N - 1)
@@ -145,18 +145,19 @@ def test_s3_scores_n833(eng, case, oracle_counts):
 
 def test_s3_score_two_kernels_agree(eng, case, oracle_counts, monkeypatch):
     """The biosample-lane kernel (default, 32-bit fixed-point table, epg_s3_lanes.hip) against the bin-lane kernel (float32
-    table, float64 folds, EPG_S3_SCORE=bins) on the same 4400 bins -- three workgroup slices of 1440 with a ragged tail,
+    table, float64 folds, epg_test_force(1, 1)) on the same 4400 bins -- three workgroup slices of 1440 with a ragged tail,
     27 chunks of 32 biosamples with a ragged last one (833 = 26 * 32 + 1), bins holding bytes that are not states."""
     q = torch.from_numpy(onp.normalise(oracle_counts).reshape(-1)).cuda()
     lo = 70001 - 2000
     X = case["X"][lo:lo + 4400]
-    monkeypatch.delenv("EPG_S3_SCORE", raising=False)
     a32, a64 = eng.score_s3(X, N, S, q, want32=True, want64=True)
     a32b, _ = eng.score_s3(X, N, S, q, want32=True, want64=False)
     assert torch.equal(a32, a32b)                                   # integer accumulation: run-to-run identical
-    monkeypatch.setenv("EPG_S3_SCORE", "bins")
-    b32, b64 = eng.score_s3(X, N, S, q, want32=True, want64=True)
-    monkeypatch.delenv("EPG_S3_SCORE")
+    eng._abi.call("epg_test_force", 1, 1)
+    try:
+        b32, b64 = eng.score_s3(X, N, S, q, want32=True, want64=True)
+    finally:
+        eng._abi.call("epg_test_force", 1, 0)
     np.testing.assert_allclose(a64.cpu().numpy(), b64.cpu().numpy(), rtol=1e-6, atol=1e-9)
     assert not torch.equal(a64, b64)                                # two different kernels did run
     # a partition of the bins gives the same bits (the cells are integers until the last step)

@@ -514,3 +514,41 @@ def test_bgzf_blocks_are_read_in_parallel_and_written_on_request(tmp_path, monke
         assert pos == len(b)
     s, _l = _io.read_table(tmp_path / "w_chr1.txt.gz")
     assert np.array_equal(s, st)
+
+
+def test_bgzf_member_with_an_empty_payload_is_declined():
+    """a BGZF member whose deflate payload is EMPTY (BSIZE says 26 bytes in all, CRC 0, ISIZE 0) is not a deflate
+    stream -- zlib rejects it -- and must not pass the block reader's checks as "0 bytes used of 0" (a truncated or corrupt
+    block would be read as empty text).  The regular end-of-file block (two payload bytes) still passes."""
+    import zlib
+    from tools.fuzz_inflate import BGZF_EOF, bgzf
+    good = bgzf(b"chr1\t0\t200\t1\t2\n" * 50, 6, 300)
+    assert _io.inflate_mem(good, own=2) == b"chr1\t0\t200\t1\t2\n" * 50
+    empty = bytes([0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 66, 67, 2, 0, 25, 0]) + (0).to_bytes(4, "little") + (0).to_bytes(4, "little")
+    for blob in (good[:-len(BGZF_EOF)] + empty + BGZF_EOF, empty + good, good[:-len(BGZF_EOF)] + empty):
+        with pytest.raises((zlib.error, EOFError, gzip.BadGzipFile)):
+            gzip.decompress(blob)                              # (every member is read: the one without a deflate stream fails)
+        assert _io.inflate_mem(blob, own=2) is None, "the block reader accepted a member without a deflate stream"
+        assert _io.inflate_mem(blob, own=False) is None
+
+
+def test_host_budget_reaches_the_library_through_the_setter(monkeypatch):
+    """the native library must not read the environment from its reader threads while Python rewrites it.  The
+    variable is read once; _io.host_budget() hands later values over with epgio_set_host_threads."""
+    lib = _io.load()
+    before = lib.epgio_default_threads()
+    try:
+        monkeypatch.setenv("EPILOGOS_NUM_CORES", "3")
+        monkeypatch.setenv("LOCAL_WORLD_SIZE", "1")
+        assert _io.host_budget() == min(3, _io.node_cores()) == lib.epgio_default_threads()
+        monkeypatch.setenv("EPILOGOS_HOST_THREADS", "57")      # changing the variable behind the library's back does nothing
+        assert lib.epgio_default_threads() == min(3, _io.node_cores())
+        lib.epgio_set_host_threads(5)
+        assert lib.epgio_default_threads() == 5
+    finally:
+        monkeypatch.delenv("EPILOGOS_NUM_CORES", raising=False)
+        monkeypatch.delenv("EPILOGOS_HOST_THREADS", raising=False)
+        _io._budget_told = None
+        lib.epgio_set_host_threads(0)
+        assert lib.epgio_default_threads() >= 1
+        _io.host_budget()

@@ -74,6 +74,11 @@ def main():
         seeds += [bgzf(t, 6, 700), bgzf(t, 1, 2000, eof=False), bgzf(t, 0, 512)]
     for k, s in enumerate(seeds[n_plain:]):
         assert _io.inflate_mem(s, own=2) == _io.inflate_mem(s, own=False) is not None, "BGZF seed %d" % k
+    # a BGZF member WITHOUT a deflate stream (empty payload, CRC 0, ISIZE 0): declined by every reader, before and
+    # after a good member -- it is not a seed (the unmutated seeds must be accepted), its neighbours are
+    empty = bytes([0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 66, 67, 2, 0, 25, 0]) + bytes(8)
+    for blob in (empty + seeds[n_plain], seeds[n_plain][:-len(BGZF_EOF)] + empty + BGZF_EOF):
+        assert _io.inflate_mem(blob, own=2) is None and _io.inflate_mem(blob, own=False) is None, "empty BGZF member accepted"
     for k, s in enumerate(seeds):                      # the unmutated seeds must be accepted by both, identically
         a, b = _io.inflate_mem(s, own=True), _io.inflate_mem(s, own=False)
         assert a is not None and a == b, "seed %d: own %s zlib %s" % (k, a is None, b is None)
