@@ -12,10 +12,11 @@ from . import _io
 
 def getNumStates(stateFile):
     """Number of states = data rows of the state-metadata TSV (reference helpers.py:9-17: pandas' read_table with a header
-    row, which skips EMPTY lines only: a line of blanks or tabs is a row there -- counted here without importing pandas, a
-    third of a second the command line spends before it has read a byte otherwise)."""
+    row, whose tokenizer skips a line that is empty or holds nothing but SPACES -- a line of tabs, the separator, is a row of
+    empty fields -- counted here without importing pandas, a third of a second the command line spends before it has read a
+    byte otherwise)."""
     with open(Path(stateFile), "r", newline=None) as fh:
-        rows = [l for l in fh.read().splitlines() if l != ""]
+        rows = [l for l in fh.read().splitlines() if l.strip(" ") != ""]
     if not rows:
         import pandas as pd
         return pd.read_table(Path(stateFile), header=0, sep="\t").shape[0]      # (raises pandas' EmptyDataError like the reference)

@@ -556,10 +556,12 @@ def test_early_readers_do_not_outlive_a_failed_start(tmp_path, golden_real, stat
 
 
 def test_get_num_states_counts_whitespace_only_lines_like_pandas(tmp_path):
-    """pandas' read_table (reference helpers.py:9-17) skips EMPTY lines only; a line of blanks or tabs is a row."""
+    """pandas' read_table (reference helpers.py:9-17) skips empty lines and lines of spaces; a line of tabs (the
+    separator) is a row."""
     import pandas as pd
     from epilogos_amd import helpers
-    for k, text in enumerate(("a\tb\n1\t2\n\n3\t4\n", "a\tb\n1\t2\n\t\n3\t4\n", "a\tb\n1\t2\n \n3\t4\n\n\n", "a\tb\r\n1\t2\r\n\r\n3\t4\r\n")):
+    for k, text in enumerate(("a\tb\n1\t2\n\n3\t4\n", "a\tb\n1\t2\n\t\n3\t4\n", "a\tb\n1\t2\n \n3\t4\n\n\n", "a\tb\r\n1\t2\r\n\r\n3\t4\r\n",
+                              "a\tb\n1\t2\n \t \n3\t4\n", "a\tb\n1\t2\n   \n\t\n")):
         f = tmp_path / ("m%d.tsv" % k)
         f.write_text(text)
         assert helpers.getNumStates(f) == pd.read_table(f, header=0, sep="\t").shape[0], repr(text)
