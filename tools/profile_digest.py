@@ -38,6 +38,11 @@ if trace.exists() and bench:
     tr = list(csv.DictReader(open(trace)))
     k1 = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) for r in tr
                 if "k_bin_hist<18, 7" in r["Kernel_Name"])
+    # round 5: the first job's add_device probes the histogram placement with launches over 1 M-bin slices (engine.alloc_hist);
+    # the whole-matrix launches are the long ones
+    if k1:
+        top = max(d for _t, d in k1)
+        k1 = [x for x in k1 if x[1] >= 0.6 * top]
     steps, warm = bench["steps"], bench["warmup"]
     if len(k1) >= 1 + warm + steps:
         d = [x[1] for x in k1[1 + warm:1 + warm + steps]]
@@ -114,8 +119,11 @@ for cname in ("fetch", "write"):
     for key in list(agg):
         # k_bin_hist: the placement experiment and the S2 config launch it too (some without the histogram store); the bench's
         # own warm-up + steps are dispatches 1..4 of a PMC pass (`--steps 3 --warmup 1`)
+        # (round 5: and the placement probe launches it over 1 M-bin slices first -- the whole-matrix launches with the store are
+        # the ones with the largest counter values)
         if "k_bin_hist<18, 7" in key[0]:
-            agg[key] = agg[key][1:5]
+            top = max(agg[key])
+            agg[key] = [v for v in agg[key] if v >= 0.9 * top][:4]
     lines += ["## PMC pass `%s`" % cname, "", "| kernel | counter | mean per launch | bytes (KB x1024%s) |" % (", x2 gfx950 read correction" if cname == "fetch" else ""), "|---|---|---|---|"]
     for (k, c), v in sorted(agg.items()):
         m = sum(v) / len(v)
