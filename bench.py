@@ -497,7 +497,7 @@ def main():
     ap.add_argument("--dist-variants", type=int, default=1, help="one GPU: K1 / job time on the uniform and the row-correlated matrix (SURVEY 8d); 0 = skip")
     ap.add_argument("--graph-leg", type=int, default=1, help="after the headline: the step as one hipGraph replay (graph_ms_per_step); 0 = skip")
     ap.add_argument("--config-reps", type=int, default=3)
-    ap.add_argument("--extras-deadline", type=int, default=900,
+    ap.add_argument("--extras-deadline", type=int, default=300,
                     help="seconds the measurements after the timed region (placement experiment, --configs) may take before rank 0 "
                          "prints the line without the rest and every rank exits; 0 = no limit")
     ap.add_argument("--graph", action="store_true", help="capture the step (K1, all-reduce, combine, score) in a hipGraph and replay it "
@@ -890,41 +890,6 @@ def main():
         if os.environ.get("EPG_BENCH_HANG_LEG") == name:               # tests: a secondary measurement that never returns
             time.sleep(10 ** 6)
 
-    # ---- the same step as ONE hipGraph replay (K1, all-reduce, combine, score captured together): what is left of the step when
-    # the host side of three launches and a collective is taken out -- on an eighth of the genome that is 10 % of the step
-    if args.graph_leg and not args.graph and use_pg and args.backend != "nccl":
-        if line is not None:                                             # (a host-side backend syncs inside the collective)
-            line["graph_ms_per_step"], line["graph_error"] = None, "not captured: the %s backend's all-reduce cannot be part of a hipGraph" % args.backend
-    elif args.graph_leg and not args.graph:
-        hang_hook("graph")
-        try:
-            Hg = engine.alloc_hist(X, N, S)
-            og = torch.empty((R, S), dtype=torch.float32, device=dev)
-            dtg, _, _, _ = timed_steps(X, Hg, og, args.steps, args.warmup, graph=True)
-            dtg = _max_over_ranks(torch, d, dtg, dev)
-            if line is not None:
-                line["graph_ms_per_step"] = round(dtg / args.steps * 1e3, 4)
-                line["graph_value"] = round(R_global * args.steps / dtg / 1e6, 3)
-            del Hg, og
-        except Exception as e:
-            if line is not None:
-                line["graph_ms_per_step"] = None
-                line["graph_error"] = repr(e)[:300]
-
-    # ---- RCCL self-test: every collective of the multi-rank command line against numbers (reported, never fatal)
-    if use_pg:
-        hang_hook("rccl_selftest")
-        st = rccl_selftest(torch, dist, dev, rank, world, N, S)
-        oks = torch.tensor([1 if st["ok"] else 0], dtype=torch.int32, device=dev)
-        try:
-            dist.all_reduce(oks, op=dist.ReduceOp.MIN)
-            st["ok_on_every_rank"] = bool(int(oks.item()))
-        except Exception as e:
-            st["ok_on_every_rank"] = False
-            st["error"] = repr(e)[:200]
-        if line is not None:
-            line["rccl_selftest"] = st
-
     # ---- secondary: the same jobs with the histogram cache where a plain allocation puts it (add_device(place=False))
     placement["report"] = engine.placement_report(dev)
     if args.placement_experiment and world == 1 and R * X.stride(0) >= (1 << 30) and not args.packed and use_session:
@@ -984,6 +949,42 @@ def main():
             line["dist_variants"] = dv
         except Exception as e:
             line["dist_variants"] = {"error": repr(e)[:300]}
+
+    # ---- RCCL self-test: every collective of the multi-rank command line against numbers (reported, never fatal)
+    if use_pg:
+        hang_hook("rccl_selftest")
+        st = rccl_selftest(torch, dist, dev, rank, world, N, S)
+        oks = torch.tensor([1 if st["ok"] else 0], dtype=torch.int32, device=dev)
+        try:
+            dist.all_reduce(oks, op=dist.ReduceOp.MIN)
+            st["ok_on_every_rank"] = bool(int(oks.item()))
+        except Exception as e:
+            st["ok_on_every_rank"] = False
+            st["error"] = repr(e)[:200]
+        if line is not None:
+            line["rccl_selftest"] = st
+
+    # ---- LAST (a captured collective is the one leg no box of this pool could try with more than one rank): the same step as ONE
+    # hipGraph replay (K1, all-reduce, combine, score captured together): what is left of the step when
+    # the host side of three launches and a collective is taken out -- on an eighth of the genome that is 10 % of the step
+    if args.graph_leg and not args.graph and use_pg and args.backend != "nccl":
+        if line is not None:                                             # (a host-side backend syncs inside the collective)
+            line["graph_ms_per_step"], line["graph_error"] = None, "not captured: the %s backend's all-reduce cannot be part of a hipGraph" % args.backend
+    elif args.graph_leg and not args.graph:
+        hang_hook("graph")
+        try:
+            Hg = engine.alloc_hist(X, N, S)
+            og = torch.empty((R, S), dtype=torch.float32, device=dev)
+            dtg, _, _, _ = timed_steps(X, Hg, og, args.steps, args.warmup, graph=True)
+            dtg = _max_over_ranks(torch, d, dtg, dev)
+            if line is not None:
+                line["graph_ms_per_step"] = round(dtg / args.steps * 1e3, 4)
+                line["graph_value"] = round(R_global * args.steps / dtg / 1e6, 3)
+            del Hg, og
+        except Exception as e:
+            if line is not None:
+                line["graph_ms_per_step"] = None
+                line["graph_error"] = repr(e)[:300]
 
     if watchdog is not None:
         watchdog.cancel()
