@@ -599,3 +599,54 @@ def test_bench_extras_timeout_exits_nonzero_after_the_line(tmp_path):
                           timeout=600, cwd=str(tmp_path))
     assert res1.returncode == 3, res1.stdout[-2000:] + res1.stderr[-2000:]
     assert "exit code 3" in json.loads([l for l in res1.stdout.splitlines() if l.startswith("{")][-1])["configs"]["deadline"]
+
+
+@pytest.mark.parametrize("mode", ["single", "paired"])
+def test_launch_then_finish_rescores_when_a_device_table_differs(mode):
+    """The one sequence of the command line and of bench.py: launch() (STEP 2 on the device + every part's score pass enqueued, no
+    host sync), then finish() (count check, device-built S1 tables against numpy's).  The branch nobody has ever seen taken -- a
+    device table that differs from the reference's -- is forced here by corrupting the table between the two calls: finish() must
+    replace it AND score the early parts again, so that what scores() / results() hand out are the reference's numbers."""
+    import torch
+    from epilogos_amd import backend
+    from epilogos_amd.driver import shuffle_key
+    from oracle import oracle_np as onp
+    from tests.conftest import synth_states
+    be = backend.HipBackend()
+    S_, NA, NB, R_ = 18, 61, 47, 500
+    xa, xb = synth_states(R_, NA, seed=5), synth_states(R_, NB, seed=6)
+
+    def run(corrupt):
+        if mode == "single":
+            sess = be.open_single(S_, 1)
+            pids = [sess.add_device(be.to_device(xa[:300]), NA), sess.add_device(be.to_device(xa[300:]), NA)]
+            sess.ensure_acc(NA)
+            sess.launch(R_, NA, pids)
+            early = [sess.early_scores(p).clone() for p in pids]
+        else:
+            sess = be.open_paired(S_, 1, S_ - 1, -1, 99)
+            pids = [sess.add_staged(be.to_device(xa[:300]), NA, be.to_device(xb[:300]), NB, shuffle_key(0, 0)),
+                    sess.add_staged(be.to_device(xa[300:]), NA, be.to_device(xb[300:]), NB, shuffle_key(1, 0))]
+            sess.ensure_acc(NA + NB)
+            sess.launch(R_, NA + NB, pids)
+            early = [sess._early[p]["delta"].clone() for p in pids]
+        if corrupt:
+            for T in sess._t1.values():
+                T.view(-1)[T.numel() // 2] += 1.0                  # one float32 entry of every device-built table
+        q = sess.finish(R_, NA if mode == "single" else NA + NB)
+        out = [sess.scores(p) if mode == "single" else sess.results(p)["delta"] for p in pids]
+        return q, np.concatenate(out), torch.cat(early).cpu().numpy(), sess.tables_patched
+
+    q0, clean, early0, patched0 = run(False)
+    q1, fixed, early1, patched1 = run(True)
+    assert patched0 == 0 and patched1 >= 1
+    assert np.array_equal(q0, q1) and np.array_equal(clean, early0)      # nothing patched: the early results ARE the results
+    assert np.array_equal(fixed, clean)                                   # patched: re-scored from the reference's table
+    if mode == "single":
+        ref = onp.score_s1(xa, q0, S_).astype(np.float32)
+        np.testing.assert_allclose(clean, ref, rtol=2e-7, atol=0)
+    else:
+        both = np.concatenate([xa, xb], axis=1)
+        assert np.array_equal(q0, onp.normalise(onp.expected_s1(both, S_)))
+        ref = onp.score_s1(xa, q0, S_).astype(np.float32) - onp.score_s1(xb, q0, S_).astype(np.float32)
+        np.testing.assert_allclose(clean, ref, rtol=1e-6, atol=1e-7)
