@@ -53,6 +53,7 @@ PROTOTYPES = {
     "epg_quiescent_from_binhist": (C.c_int, [_p, _p, _i64, _i32, _i32, _i32, _i32, _p, _p]),
     "epg_null_hist_from_binhist": (C.c_int, [_p, _p, _i64, _i32, _i32, _i32, _i32, _u64, _i64, _p, _p, _p]),
     "epg_null_hist_from_binhist_parts": (C.c_int, [_i32, _p, _p, _p, _i32, _i32, _i32, _i32, _u64, _p, _p, _p, _p]),
+    "epg_pair_count_null_parts": (C.c_int, [_i32, _p, _p, _p, _i32, _i32, _p, _p, _i32, _p, _p, _p, _u64, _p, _p, _p, _p]),
     "epg_test_force": (C.c_int, [_i32, _i32]),
 }
 

@@ -492,15 +492,17 @@ class _HipPairedSession(_HipSession):
     # groups are drawn in ONE launch on the second stream, under the count pass of the next batch (the sampler is VALU-bound,
     # the count pass HBM-bound: tools/overlap_probe.py).  Round 4 launched per part: 2 x 24 count passes of ~80 us and 24 samplers
     # for a genome, each with its ramp and tail -- the count phase of BASELINE config 5 ran at 0.36 of its bytes.
-    BATCH_ROWS = int(os.environ.get("EPILOGOS_PAIR_BATCH_ROWS", 2_000_000))
+    # rows per batch: the default group sizes take the fused kernel (nothing to overlap: two launches per genome, 4.62 ms per
+    # 15 M bins against 4.71 with seven); the two-kernel path overlaps batch k's sampler with batch k + 1's count pass
+    # (1 / 2 / 3 / 4 M rows: 5.04 / 5.05 / 5.12 / 5.10 ms before the score pass prefetched, one batch 6.1)
+    BATCH_ROWS = os.environ.get("EPILOGOS_PAIR_BATCH_ROWS")
 
     def add_staged(self, XA, NA, XB, NB, row0):
         """One part's two groups, resident.  row0 keys the null shuffle of the part's first row: the driver passes
         (file ordinal << 40) + row in the file -- known the moment a file is parsed, whatever the partition.  The part joins
-        the pending batch; the batch is launched when it holds BATCH_ROWS rows (an eighth of a genome: a streaming run still
-        counts while it parses, a resident genome takes seven count launches and seven sampler launches instead of 48 + 24;
-        1 / 2 / 3 / 4 M rows measured 5.04 / 5.05 / 5.12 / 5.10 ms per 15 M-bin job, one batch 6.1) or when anything needs
-        its histograms."""
+        the pending batch; the batch is launched when it holds BATCH_ROWS rows (half a genome with the fused kernel, an eighth
+        with the two-kernel path: a streaming run still counts while it parses) or 32 parts, or when anything needs its
+        histograms."""
         S = self.S
         # widths of the widest part seen: an empty file pair (no columns) must not be the one that is remembered
         self.NA, self.NB = max(getattr(self, "NA", 0) or 0, NA or 0), max(getattr(self, "NB", 0) or 0, NB or 0)
@@ -512,30 +514,51 @@ class _HipPairedSession(_HipSession):
         pid = len(self.parts) - 1
         self._pending.append((pid, NA, NB))
         self._pending_rows += XA.shape[0]
-        if self._pending_rows >= self.BATCH_ROWS:
+        limit = int(self.BATCH_ROWS) if self.BATCH_ROWS else (8_000_000 if self.groupSize == -1 else 2_000_000)
+        if self._pending_rows >= limit or len(self._pending) >= 32:
             self._flush()
         return pid
 
     def _flush(self):
-        """Count pass of the pending batch (one launch), then its null groups (one launch on the second stream)."""
+        """Count pass of the pending batch and its null groups.  The default group sizes, a state model and widths the fused
+        kernel takes: ONE launch does both (epg_pair_count_null_parts: a wave counts a tile of both groups, then draws its null
+        groups -- the memory pipe and the VALU of a CU are busy at the same time without a second kernel).  Otherwise one launch
+        for the count pass (epg_bin_hist_parts), then one for the null groups on the second stream (_start_null)."""
         if not self._pending:
             return
         eng, S = self.eng, self.S
         batch, self._pending, self._pending_rows = self._pending, [], 0
         XAs = [self.parts[pid][0] for pid, _na, _nb in batch]
         XBs = [self.parts[pid][1] for pid, _na, _nb in batch]
-        widths = [na for _p, na, _nb in batch] + [nb for _p, _na, nb in batch]
         k = len(batch)
-        if self.sal == 1:                                # counts over [A|B] = counts of A + counts of B (helpers.py:173)
-            Hs, _ = eng.bin_hist_parts(XAs + XBs, widths, S, counts=self._acc(S))
+        counts = self._acc(S) if self.sal == 1 else None  # counts over [A|B] = counts of A + counts of B (helpers.py:173)
+        fused = None
+        uniform = all(na == self.NA and nb == self.NB for _p, na, nb in batch)
+        if (self.groupSize == -1 and uniform and all(self.parts[pid][4] is not None for pid, _na, _nb in batch)
+                and os.environ.get("EPILOGOS_PAIR_FUSED", "1") != "0"):
+            try:
+                fused = eng.pair_count_null_parts(XAs, XBs, self.NA, self.NB, S, self.seed, [self.parts[pid][4] for pid, _na, _nb in batch],
+                                                  counts=counts)
+            except eng.EpilogosHipError as e:
+                if e.code != -2:
+                    raise
+        if fused is not None:
+            HAs, HBs, OAs, OBs = fused
+            for i, (pid, _na, _nb) in enumerate(batch):
+                XA, XB, _ha, _hb, row0, _null = self.parts[pid]
+                self.parts[pid] = (XA, XB, HAs[i], HBs[i], row0, (OAs[i], OBs[i], None))
         else:
-            Hs, _ = eng.bin_hist_parts(XAs + XBs, widths, S, counts=None)
+            widths = [na for _p, na, _nb in batch] + [nb for _p, _na, nb in batch]
+            Hs, _ = eng.bin_hist_parts(XAs + XBs, widths, S, counts=counts)
+            HAs, HBs = Hs[:k], Hs[k:]
+            for i, (pid, _na, _nb) in enumerate(batch):
+                XA, XB, _ha, _hb, row0, null = self.parts[pid]
+                self.parts[pid] = (XA, XB, HAs[i], HBs[i], row0, null)
+        if self.sal != 1:
             for i in range(k):
-                eng.hist_s2_from_binhist_pair(Hs[i], Hs[k + i], S, counts=self._acc(S * S))
-        for i, (pid, _na, _nb) in enumerate(batch):
-            XA, XB, _ha, _hb, row0, null = self.parts[pid]
-            self.parts[pid] = (XA, XB, Hs[i], Hs[k + i], row0, null)
-        self._start_null([pid for pid, _na, _nb in batch if self.parts[pid][4] is not None])
+                eng.hist_s2_from_binhist_pair(HAs[i], HBs[i], S, counts=self._acc(S * S))
+        if fused is None:
+            self._start_null([pid for pid, _na, _nb in batch if self.parts[pid][4] is not None])
 
     def _start_null(self, pids):
         """The null groups' histograms of the parts `pids` (multivariate hypergeometric, from the real groups' histograms; they

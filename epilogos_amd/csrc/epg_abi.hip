@@ -61,6 +61,10 @@ int bin_hist_parts_impl(int32_t, const int8_t* const*, const int64_t*, const int
 int null_hist_parts_impl(int32_t, const uint16_t* const*, const uint16_t* const*, const int64_t*, int32_t, int32_t, int32_t, int32_t, uint64_t,
                          const int64_t*, uint16_t* const*, uint16_t* const*, hipStream_t);
 
+int pair_count_null_parts_impl(int32_t, const int8_t* const*, const int8_t* const*, const int64_t*, int32_t, int32_t, const int64_t*, const int64_t*,
+                               int32_t, uint16_t* const*, uint16_t* const*, int64_t*, uint64_t, const int64_t*, uint16_t* const*, uint16_t* const*,
+                               hipStream_t);
+
 int g_force[FORCE_COUNT] = {0};
 
 }  // namespace epg
@@ -106,6 +110,12 @@ int epg_null_hist_from_binhist_parts(int32_t nparts, const uint16_t* const* HA, 
                                      int32_t n_cols, int32_t ga, int32_t gb, uint64_t seed, const int64_t* row0, uint16_t* const* OA,
                                      uint16_t* const* OB, void* stream) {
     return null_hist_parts_impl(nparts, HA, HB, R, S, n_cols, ga, gb, seed, row0, OA, OB, (hipStream_t)stream);
+}
+
+int epg_pair_count_null_parts(int32_t nparts, const int8_t* const* XA, const int8_t* const* XB, const int64_t* R, int32_t NA, int32_t NB,
+                              const int64_t* ldxa, const int64_t* ldxb, int32_t S, uint16_t* const* HA, uint16_t* const* HB, int64_t* counts,
+                              uint64_t seed, const int64_t* row0, uint16_t* const* OA, uint16_t* const* OB, void* stream) {
+    return pair_count_null_parts_impl(nparts, XA, XB, R, NA, NB, ldxa, ldxb, S, HA, HB, counts, seed, row0, OA, OB, (hipStream_t)stream);
 }
 
 int epg_hist_s1(const int8_t* X, int64_t R, int32_t N, int64_t ldx, int32_t S, int64_t* counts, void* stream) {

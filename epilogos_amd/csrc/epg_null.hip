@@ -5,7 +5,7 @@
 // need_A / remaining, group B with need_B / remaining) is exactly the law of (first ga, next gb) of a uniform
 // permutation.  Randomness: Philox4x32-10 keyed by the seed, counter = (global row, group, column block) -- the result
 // depends only on (seed, row0 + row), never on the launch geometry or on which GPU owns the row.  gfx950 only.
-#include "epg_common.h"
+#include "epg_count.h"
 
 #include <string.h>
 
@@ -298,6 +298,119 @@ __device__ __forceinline__ u32 nh_range_pop(const u32* __restrict__ bits, u32 o,
     return cnt;
 }
 
+// One row of the bit-string sampler (ga + gb == n_cols): pa / pb = the row's histograms of the two real groups in LDS on entry,
+// the two null groups' on return; bitsA = the lane's outcome-bit words [word * 64]; grow = the row's shuffle key.  Shared by
+// k_null_hist_h and the fused count + sample kernel of paired mode (k_pair_count_null).
+__device__ __forceinline__ void nh_sample_row_full(u16* __restrict__ pa, u16* __restrict__ pb, u32* __restrict__ bitsA, int S, int n_cols,
+                                                   int ga, u64 seed, u64 grow) {
+    u32 best = 0;
+    int modal = 0;
+    for (int s = 0; s < S; ++s) {
+        const u32 h = (u32)pa[s] + pb[s];
+        pa[s] = (u16)h;
+        if (h > best) { best = h; modal = s; }
+    }
+    int Am1 = (int)(((u32)ga << 16) - 1u);                                        // (need_A << 16) - 1
+    const u32 m = (u32)n_cols - best;
+    
+    u32 calls = 0;
+    u32 a0w = 0, a1w = 0, a2w = 0, a3w = 0, ahave = 0, acalls = 0;
+    u32 wA = 0;
+    // the careful draw at position d: certain unless the 16-bit interval straddles need_A / rem, then 32 more bits decide
+    auto draw = [&](u32 v, u32 d) {
+        const int rem = n_cols - (int)d;
+        const int x = Am1 - (int)__umul24(v, (u32)rem);                           // (need_A << 16) - 1 - v rem
+        bool a = x >= rem - 1;                                                    // (v + 1) rem <= need_A << 16
+        if (!a && x >= 0) {                                                       // v rem < need_A << 16 < (v + 1) rem
+            if (ahave == 0) {
+                u32 c[4] = {(u32)grow, (u32)(grow >> 32), acalls++, 0x74696573u};
+                philox4x32_10(c, (u32)seed, (u32)(seed >> 32));
+                a0w = c[0]; a1w = c[1]; a2w = c[2]; a3w = c[3];
+                ahave = 4;
+            }
+            const u64 u48 = ((u64)v << 32) | a0w;
+            a0w = a1w; a1w = a2w; a2w = a3w;
+            --ahave;
+            const u32 pick = (u32)((u48 * (u32)rem) >> 48);                       // uniform in [0, rem)
+            a = pick < (((u32)Am1 + 1u) >> 16);
+        }
+        wA |= a ? 1u << (d & 31u) : 0u;
+        Am1 -= a ? 65536 : 0;
+    };
+    u32 d = 0;
+    for (; d + 8 <= m; d += 8) {
+        u32 c[4] = {(u32)grow, (u32)(grow >> 32), calls++, 0x6e756c6cu};
+        philox4x32_10(c, (u32)seed, (u32)(seed >> 32));
+        const int Am1_0 = Am1;
+        const u32 wA_0 = wA;
+        const int rem0 = __builtin_amdgcn_readfirstlane(n_cols - (int)d);         // every lane of the wave is at the same d
+        const int bit0 = __builtin_amdgcn_readfirstlane((int)(d & 31u));
+        u32 low = 0xffffffffu;
+        // two draws per word of Philox output, 13 instructions: v_and / v_lshrrev (the two halves), then per draw
+        // v_mad_i32_i24 (x), v_cmp_le_i32 (a), v_cndmask (a as 0 / 1), v_lshl_or (the outcome bit), v_mad_i32_i24 (need_A),
+        // and one v_min3_u32 for the tie test
+#define NH_PAIR(W, K)                                                                                                             \
+        {                                                                                                                 \
+            u32 v0_, v1_, x0_, x1_, a_;                                                                                   \
+            asm volatile(                                                                                                 \
+                "v_and_b32_e32 %[v0], 0xffff, %[w]\n\t"                                                                   \
+                "v_lshrrev_b32_e32 %[v1], 16, %[w]\n\t"                                                                   \
+                "v_mad_i32_i24 %[x0], %[v0], %[nr0], %[am]\n\t"                                                           \
+                "v_cmp_le_i32_e32 vcc, %[rm0], %[x0]\n\t"                                                                 \
+                "v_cndmask_b32_e64 %[a], 0, 1, vcc\n\t"                                                                   \
+                "v_lshl_or_b32 %[wa], %[a], %[b0], %[wa]\n\t"                                                             \
+                "v_mad_i32_i24 %[am], %[a], %[m64k], %[am]\n\t"                                                           \
+                "v_mad_i32_i24 %[x1], %[v1], %[nr1], %[am]\n\t"                                                           \
+                "v_cmp_le_i32_e32 vcc, %[rm1], %[x1]\n\t"                                                                 \
+                "v_cndmask_b32_e64 %[a], 0, 1, vcc\n\t"                                                                   \
+                "v_lshl_or_b32 %[wa], %[a], %[b1], %[wa]\n\t"                                                             \
+                "v_mad_i32_i24 %[am], %[a], %[m64k], %[am]\n\t"                                                           \
+                "v_min3_u32 %[lo], %[x0], %[x1], %[lo]"                                                                   \
+                : [v0] "=&v"(v0_), [v1] "=&v"(v1_), [x0] "=&v"(x0_), [x1] "=&v"(x1_), [a] "=&v"(a_), [wa] "+v"(wA),       \
+                  [am] "+v"(Am1), [lo] "+v"(low)                                                                          \
+                : [w] "v"(W), [nr0] "s"((K) - rem0), [nr1] "s"((K) + 1 - rem0), [rm0] "s"(rem0 - (K) - 1),                \
+                  [rm1] "s"(rem0 - (K) - 2), [b0] "s"(bit0 + (K)), [b1] "s"(bit0 + (K) + 1), [m64k] "s"(-65536)           \
+                : "vcc");                                                                                                 \
+        }
+        NH_PAIR(c[0], 0)
+        NH_PAIR(c[1], 2)
+        NH_PAIR(c[2], 4)
+        NH_PAIR(c[3], 6)
+#undef NH_PAIR
+        if (low < (u32)rem0) {                                                    // a tie is possible in this call: repeat it carefully
+            Am1 = Am1_0;
+            wA = wA_0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) draw((k & 1) ? c[k >> 1] >> 16 : c[k >> 1] & 0xffffu, d + k);
+        }
+        if ((d & 31u) == 24u) {
+            bitsA[(d >> 5) * 64] = wA;
+            wA = 0;
+        }
+    }
+    if (d < m) {                                                                  // the last one to seven draws
+        u32 c[4] = {(u32)grow, (u32)(grow >> 32), calls++, 0x6e756c6cu};
+        philox4x32_10(c, (u32)seed, (u32)(seed >> 32));
+#pragma unroll
+        for (int k = 0; k < 7; ++k)
+            if (d + k < m) draw((k & 1) ? c[k >> 1] >> 16 : c[k >> 1] & 0xffffu, d + k);
+    }
+    if (m & 31u) bitsA[(m >> 5) * 64] = wA;
+    // counts per state: range popcounts between the prefix sums of the histogram; the modal state takes what is missing
+    u32 o = 0;
+    for (int s = 0; s < S; ++s) {
+        const u32 h = s == modal ? 0u : (u32)pa[s];
+        const u32 ca = nh_range_pop(bitsA, o, h);
+        pa[s] = (u16)ca;
+        pb[s] = (u16)(h - ca);
+        o += h;
+    }
+    // positions o .. m - 1 are the columns without a state: drawn (they take places in the groups), not reported
+    const u32 needA = ((u32)Am1 + 1u) >> 16;                                      // = ga - (A members among the m drawn)
+    pa[modal] = (u16)needA;
+    pb[modal] = (u16)(best - needA);
+}
+
 // Round 4: the draw loop again.  Where round 3's 3.15 ms went: ~14 instructions per draw on the main path, Philox 4 (64 per
 // call -- the 32 x 32 multiplies are full rate on gfx950, tools/ubench/rng_rate.hip --, 16 byte-sized draws per call) and ~7 for
 // the tie path, which a wave walked whenever ONE of its 64 lanes' bytes straddled need_A / remaining: 22 % of the draws.  Now
@@ -334,112 +447,7 @@ __global__ __launch_bounds__(256) void k_null_hist_h(const NhParts pt, int S, in
         if (lane < rows) {
             u16* pa = reinterpret_cast<u16*>(sa + lane * rowb);
             u16* pb = reinterpret_cast<u16*>(sb + lane * rowb);
-            u32 best = 0;
-            int modal = 0;
-            for (int s = 0; s < S; ++s) {
-                const u32 h = (u32)pa[s] + pb[s];
-                pa[s] = (u16)h;
-                if (h > best) { best = h; modal = s; }
-            }
-            int Am1 = (int)(((u32)ga << 16) - 1u);                                        // (need_A << 16) - 1
-            const u32 m = (u32)n_cols - best;
-            const u64 grow = (u64)(row0 + r0 + lane);
-            u32 calls = 0;
-            u32 a0w = 0, a1w = 0, a2w = 0, a3w = 0, ahave = 0, acalls = 0;
-            u32 wA = 0;
-            // the careful draw at position d: certain unless the 16-bit interval straddles need_A / rem, then 32 more bits decide
-            auto draw = [&](u32 v, u32 d) {
-                const int rem = n_cols - (int)d;
-                const int x = Am1 - (int)__umul24(v, (u32)rem);                           // (need_A << 16) - 1 - v rem
-                bool a = x >= rem - 1;                                                    // (v + 1) rem <= need_A << 16
-                if (!a && x >= 0) {                                                       // v rem < need_A << 16 < (v + 1) rem
-                    if (ahave == 0) {
-                        u32 c[4] = {(u32)grow, (u32)(grow >> 32), acalls++, 0x74696573u};
-                        philox4x32_10(c, (u32)seed, (u32)(seed >> 32));
-                        a0w = c[0]; a1w = c[1]; a2w = c[2]; a3w = c[3];
-                        ahave = 4;
-                    }
-                    const u64 u48 = ((u64)v << 32) | a0w;
-                    a0w = a1w; a1w = a2w; a2w = a3w;
-                    --ahave;
-                    const u32 pick = (u32)((u48 * (u32)rem) >> 48);                       // uniform in [0, rem)
-                    a = pick < (((u32)Am1 + 1u) >> 16);
-                }
-                wA |= a ? 1u << (d & 31u) : 0u;
-                Am1 -= a ? 65536 : 0;
-            };
-            u32 d = 0;
-            for (; d + 8 <= m; d += 8) {
-                u32 c[4] = {(u32)grow, (u32)(grow >> 32), calls++, 0x6e756c6cu};
-                philox4x32_10(c, (u32)seed, (u32)(seed >> 32));
-                const int Am1_0 = Am1;
-                const u32 wA_0 = wA;
-                const int rem0 = __builtin_amdgcn_readfirstlane(n_cols - (int)d);         // every lane of the wave is at the same d
-                const int bit0 = __builtin_amdgcn_readfirstlane((int)(d & 31u));
-                u32 low = 0xffffffffu;
-                // two draws per word of Philox output, 13 instructions: v_and / v_lshrrev (the two halves), then per draw
-                // v_mad_i32_i24 (x), v_cmp_le_i32 (a), v_cndmask (a as 0 / 1), v_lshl_or (the outcome bit), v_mad_i32_i24 (need_A),
-                // and one v_min3_u32 for the tie test
-#define NH_PAIR(W, K)                                                                                                             \
-                {                                                                                                                 \
-                    u32 v0_, v1_, x0_, x1_, a_;                                                                                   \
-                    asm volatile(                                                                                                 \
-                        "v_and_b32_e32 %[v0], 0xffff, %[w]\n\t"                                                                   \
-                        "v_lshrrev_b32_e32 %[v1], 16, %[w]\n\t"                                                                   \
-                        "v_mad_i32_i24 %[x0], %[v0], %[nr0], %[am]\n\t"                                                           \
-                        "v_cmp_le_i32_e32 vcc, %[rm0], %[x0]\n\t"                                                                 \
-                        "v_cndmask_b32_e64 %[a], 0, 1, vcc\n\t"                                                                   \
-                        "v_lshl_or_b32 %[wa], %[a], %[b0], %[wa]\n\t"                                                             \
-                        "v_mad_i32_i24 %[am], %[a], %[m64k], %[am]\n\t"                                                           \
-                        "v_mad_i32_i24 %[x1], %[v1], %[nr1], %[am]\n\t"                                                           \
-                        "v_cmp_le_i32_e32 vcc, %[rm1], %[x1]\n\t"                                                                 \
-                        "v_cndmask_b32_e64 %[a], 0, 1, vcc\n\t"                                                                   \
-                        "v_lshl_or_b32 %[wa], %[a], %[b1], %[wa]\n\t"                                                             \
-                        "v_mad_i32_i24 %[am], %[a], %[m64k], %[am]\n\t"                                                           \
-                        "v_min3_u32 %[lo], %[x0], %[x1], %[lo]"                                                                   \
-                        : [v0] "=&v"(v0_), [v1] "=&v"(v1_), [x0] "=&v"(x0_), [x1] "=&v"(x1_), [a] "=&v"(a_), [wa] "+v"(wA),       \
-                          [am] "+v"(Am1), [lo] "+v"(low)                                                                          \
-                        : [w] "v"(W), [nr0] "s"((K) - rem0), [nr1] "s"((K) + 1 - rem0), [rm0] "s"(rem0 - (K) - 1),                \
-                          [rm1] "s"(rem0 - (K) - 2), [b0] "s"(bit0 + (K)), [b1] "s"(bit0 + (K) + 1), [m64k] "s"(-65536)           \
-                        : "vcc");                                                                                                 \
-                }
-                NH_PAIR(c[0], 0)
-                NH_PAIR(c[1], 2)
-                NH_PAIR(c[2], 4)
-                NH_PAIR(c[3], 6)
-#undef NH_PAIR
-                if (low < (u32)rem0) {                                                    // a tie is possible in this call: repeat it carefully
-                    Am1 = Am1_0;
-                    wA = wA_0;
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) draw((k & 1) ? c[k >> 1] >> 16 : c[k >> 1] & 0xffffu, d + k);
-                }
-                if ((d & 31u) == 24u) {
-                    bitsA[(d >> 5) * 64] = wA;
-                    wA = 0;
-                }
-            }
-            if (d < m) {                                                                  // the last one to seven draws
-                u32 c[4] = {(u32)grow, (u32)(grow >> 32), calls++, 0x6e756c6cu};
-                philox4x32_10(c, (u32)seed, (u32)(seed >> 32));
-#pragma unroll
-                for (int k = 0; k < 7; ++k)
-                    if (d + k < m) draw((k & 1) ? c[k >> 1] >> 16 : c[k >> 1] & 0xffffu, d + k);
-            }
-            if (m & 31u) bitsA[(m >> 5) * 64] = wA;
-            // counts per state: range popcounts between the prefix sums of the histogram; the modal state takes what is missing
-            u32 o = 0;
-            for (int s = 0; s < S; ++s) {
-                const u32 h = s == modal ? 0u : (u32)pa[s];
-                const u32 ca = nh_range_pop(bitsA, o, h);
-                pa[s] = (u16)ca;
-                pb[s] = (u16)(h - ca);
-                o += h;
-            }
-            // positions o .. m - 1 are the columns without a state: drawn (they take places in the groups), not reported
-            const u32 needA = ((u32)Am1 + 1u) >> 16;                                      // = ga - (A members among the m drawn)
-            pa[modal] = (u16)needA;
-            pb[modal] = (u16)(best - needA);
+            nh_sample_row_full(pa, pb, bitsA, S, n_cols, ga, seed, (u64)(row0 + r0 + lane));
         }
         __builtin_amdgcn_wave_barrier();
         store_staged(sa, reinterpret_cast<char*>(OA + r0 * S), rows * rowb, lane);
@@ -662,6 +670,248 @@ int null_hist_from_binhist_impl(const uint16_t* HA, const uint16_t* HB, int64_t 
                                 uint64_t seed, int64_t row0, uint16_t* OA, uint16_t* OB, hipStream_t st) {
     if (R > 0 && (!HA || !HB || !OA || !OB)) return fail(EPG_ERR_INVALID_ARG, "null_hist_from_binhist: NULL argument");
     return null_hist_parts_impl(1, &HA, &HB, &R, S, n_cols, ga, gb, seed, &row0, &OA, &OB, st);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Paired mode, count pass AND null draw in one kernel (round 5).  Two kernels on two streams share every SIMD and lose ~30 % of
+// the issue slots to each other (count pass 2.44 ms + sampler 2.06 ms alone, 3.3-3.4 ms together: profiles/r05g_*).  Here a
+// wave owns tiles of 64 bins of a part: it counts the tile's rows of group A and of group B with k_bin_hist's core (four
+// 16-row sub-tiles, quad per row; at raised priority: whatever feeds the memory pipe goes first), leaves the two real groups'
+// histograms in its LDS slot, writes them out, then every lane draws its row's null groups from them (nh_sample_row_full) and the
+// wave writes those out too.  The waves of a CU are in different phases, so its memory pipe and its VALU are busy at the same
+// time without a second kernel.  Same integers and the same draws as epg_bin_hist_parts + epg_null_hist_from_binhist_parts
+// (tests/test_hip_abi_calls.py).  Compile-time S (15 / 18 / 25) and groups of 128 bytes per row (both widths the same number, <= 4);
+// the default group sizes only (ga = NA, gb = NB: one bit string); everything else takes the two kernels.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int PC_MAXP = 32;
+struct PcParts {
+    const char* xa[PC_MAXP];
+    const char* xb[PC_MAXP];
+    u16* ha[PC_MAXP];
+    u16* hb[PC_MAXP];
+    u16* oa[PC_MAXP];
+    u16* ob[PC_MAXP];
+    long rows[PC_MAXP];
+    long ldxa[PC_MAXP];
+    long ldxb[PC_MAXP];
+    long key[PC_MAXP];
+    long t0[PC_MAXP + 1];                  // first tile (64 rows) of every part, and their total
+    int n;
+};
+
+template <int S>
+__device__ __forceinline__ void pc_stage_row(char* srow, const u32 (&d)[(S + 1) / 2], int j) {
+    constexpr int ND = (S + 1) / 2;
+    if constexpr ((S & 1) == 0) {                        // even S: whole dwords
+#pragma unroll
+        for (int k = 0; k < (ND + 3) / 4; ++k) {
+            const u32 v = sel4(d[4 * k], 4 * k + 1 < ND ? d[4 * k + 1] : 0u, 4 * k + 2 < ND ? d[4 * k + 2] : 0u, 4 * k + 3 < ND ? d[4 * k + 3] : 0u, j);
+            if (4 * k + j < ND) *reinterpret_cast<u32*>(srow + 4 * (4 * k + j)) = v;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < (S + 3) / 4; ++k) {
+            const u32 v = (j & 2) ? (2 * k + 1 < ND ? d[2 * k + 1] : 0u) : d[2 * k];
+            const u32 c = (j & 1) ? v >> 16 : v & 0xffffu;
+            if (4 * k + j < S) *reinterpret_cast<u16*>(srow + 2 * (4 * k + j)) = (u16)c;
+        }
+    }
+}
+
+template <int S, int NG>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_pair_count_null(const PcParts pt, int NA, int NB, u64* __restrict__ counts, u64 seed, int NW) {
+    constexpr int ND = (S + 1) / 2;
+    constexpr int ROWB = 2 * S;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ u64 s_cnt[S + 1];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int j = lane & 3, b = lane >> 2;
+    const size_t per_wave = (size_t)2 * 64 * ROWB + (size_t)NW * 256;
+    char* sa = smem + (size_t)wave * per_wave;
+    char* sb = sa + 64 * ROWB;
+    u32* bitsA = reinterpret_cast<u32*>(sb + 64 * ROWB) + lane;
+    if (threadIdx.x <= S) s_cnt[threadIdx.x] = 0;
+    __syncthreads();
+    u32 accp[ND];
+#pragma unroll
+    for (int m = 0; m < ND; ++m) accp[m] = 0;
+    const int nmax = NA > NB ? NA : NB;
+    const int flush_every = 65535 / nmax > 1 ? 65535 / nmax - 1 : 1;
+    int since = 0;
+    auto flush = [&]() {
+        if (j == 0) {
+#pragma unroll
+            for (int m = 0; m < ND; ++m) {
+                const u32 lo = accp[m] & 0xffffu, hi = accp[m] >> 16;
+                if (lo) atomicAdd(&s_cnt[2 * m], (u64)lo);
+                if (hi) atomicAdd(&s_cnt[2 * m + 1], (u64)hi);
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < ND; ++m) accp[m] = 0;
+        since = 0;
+    };
+    const RowGeom gA = make_geom(NA), gB = make_geom(NB);
+    const int n_cols = NA + NB;
+    const long ntiles = pt.t0[pt.n];
+    const long tstride = (long)gridDim.x * 4;
+    // a tile's descriptor; `nx` is the tile after this one (its first sub-tile is loaded before this tile's draws start)
+    struct Tile { const char* xa; const char* xb; u16* ha; u16* hb; u16* oa; u16* ob; long R, ldxa, ldxb, key, r0; };
+    int part = 0;
+    auto describe = [&](long tile, Tile& t) {
+        while (tile >= pt.t0[part + 1]) ++part;                   // (a wave's tiles ascend: the part only moves forward)
+        t.xa = pt.xa[part]; t.xb = pt.xb[part]; t.ha = pt.ha[part]; t.hb = pt.hb[part]; t.oa = pt.oa[part]; t.ob = pt.ob[part];
+        t.R = pt.rows[part]; t.ldxa = pt.ldxa[part]; t.ldxb = pt.ldxb[part]; t.key = pt.key[part];
+        t.r0 = (tile - pt.t0[part]) * 64;
+    };
+    // the loads of ONE 16-row sub-tile of one group (2 NG dwordx4 per lane), kept in flight while the previous sub-tile is counted
+    u32 wa[NG][8], wb[NG][8];
+    auto issue = [&](const char* X, long ldx, long R_, long r0, int sub, const RowGeom& g, u32 (&w)[NG][8]) {
+        const long row = r0 + 16 * sub + b;
+        const char* rowp = X + (row < R_ ? row : R_ - 1) * ldx;
+#pragma unroll
+        for (int t = 0; t < NG; ++t) {
+            if (t < NG - 1) {
+                load_slot<false>(rowp, 2 * t, j, g, &w[t][0]);
+                load_slot<false>(rowp, 2 * t + 1, j, g, &w[t][4]);
+            } else {
+                load_slot<true>(rowp, 2 * t, j, g, &w[t][0]);
+                load_slot<true>(rowp, 2 * t + 1, j, g, &w[t][4]);
+            }
+        }
+    };
+    auto count_into = [&](u32 (&w)[NG][8], char* srow, bool valid) {
+        u32 cnt[S];
+#pragma unroll
+        for (int s = 0; s < S; ++s) cnt[s] = 0;
+#pragma unroll
+        for (int t = 0; t < NG; ++t) count_group<S>(w[t], cnt);
+        u32 d[ND];
+        pack_reduce<S>(cnt, d);
+        pc_stage_row<S>(srow, d, j);
+        if (counts) {
+#pragma unroll
+            for (int m = 0; m < ND; ++m) accp[m] += valid ? d[m] : 0u;
+            if (++since >= flush_every) flush();
+        }
+    };
+    long tile = (long)blockIdx.x * 4 + wave;
+    Tile cur, nx;
+    if (tile < ntiles) {
+        describe(tile, cur);
+        issue(cur.xa, cur.ldxa, cur.R, cur.r0, 0, gA, wa);
+        issue(cur.xb, cur.ldxb, cur.R, cur.r0, 0, gB, wb);
+    }
+    for (; tile < ntiles; tile += tstride) {
+        const bool more = tile + tstride < ntiles;
+        if (more) describe(tile + tstride, nx);
+        const int rows = (int)(cur.R - cur.r0 < 64 ? cur.R - cur.r0 : 64);
+        __builtin_amdgcn_s_setprio(3);                           // the phase that feeds the memory pipe goes first
+#pragma unroll
+        for (int sub = 0; sub < 4; ++sub) {
+            const bool valid = cur.r0 + 16 * sub + b < cur.R;
+            count_into(wa, sa + (16 * sub + b) * ROWB, valid);
+            if (sub < 3) issue(cur.xa, cur.ldxa, cur.R, cur.r0, sub + 1, gA, wa);
+            else if (more) issue(nx.xa, nx.ldxa, nx.R, nx.r0, 0, gA, wa);      // in flight during this tile's draws
+            count_into(wb, sb + (16 * sub + b) * ROWB, valid);
+            if (sub < 3) issue(cur.xb, cur.ldxb, cur.R, cur.r0, sub + 1, gB, wb);
+            else if (more) issue(nx.xb, nx.ldxb, nx.R, nx.r0, 0, gB, wb);
+        }
+        __builtin_amdgcn_wave_barrier();
+        store_staged(sa, reinterpret_cast<char*>(cur.ha + cur.r0 * S), rows * ROWB, lane);
+        store_staged(sb, reinterpret_cast<char*>(cur.hb + cur.r0 * S), rows * ROWB, lane);
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_s_setprio(0);
+        if (lane < rows)
+            nh_sample_row_full(reinterpret_cast<u16*>(sa + lane * ROWB), reinterpret_cast<u16*>(sb + lane * ROWB), bitsA, S, n_cols, NA, seed,
+                               (u64)(cur.key + cur.r0 + lane));
+        __builtin_amdgcn_wave_barrier();
+        store_staged(sa, reinterpret_cast<char*>(cur.oa + cur.r0 * S), rows * ROWB, lane);
+        store_staged(sb, reinterpret_cast<char*>(cur.ob + cur.r0 * S), rows * ROWB, lane);
+        __builtin_amdgcn_wave_barrier();
+        cur = nx;
+    }
+    if (counts) {
+        flush();
+        __syncthreads();
+        if ((int)threadIdx.x < S && s_cnt[threadIdx.x]) atomicAdd(&counts[threadIdx.x], s_cnt[threadIdx.x]);
+    }
+}
+
+template <int S, int NG>
+static int launch_pair_count_null(const PcParts& pt, int NA, int NB, u64* counts, u64 seed, hipStream_t st) {
+    const int NW = (NA + NB + 31) / 32;
+    const size_t shmem = 4 * ((size_t)2 * 64 * 2 * S + (size_t)NW * 256);
+    static bool attr_set = false;
+    if (!attr_set) {
+        EPG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pair_count_null<S, NG>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    160 * 1024 - 1024));     // (the kernel also holds a small static array)
+        attr_set = true;
+    }
+    long blocks = (pt.t0[pt.n] + 3) / 4;
+    const long per_cu = (long)((160 * 1024 - 1024) / shmem);
+    const long cap = num_cus() * (per_cu < 1 ? 1 : per_cu);
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL((k_pair_count_null<S, NG>), dim3((unsigned)blocks), dim3(256), shmem, st, pt, NA, NB, counts, seed, NW);
+    EPG_LAUNCH_CHECK("k_pair_count_null");
+    return EPG_OK;
+}
+
+template <int S>
+static int dispatch_pair_count_null(int ng, const PcParts& pt, int NA, int NB, u64* counts, u64 seed, hipStream_t st) {
+    switch (ng) {
+        case 1: return launch_pair_count_null<S, 1>(pt, NA, NB, counts, seed, st);
+        case 2: return launch_pair_count_null<S, 2>(pt, NA, NB, counts, seed, st);
+        case 3: return launch_pair_count_null<S, 3>(pt, NA, NB, counts, seed, st);
+        default: return launch_pair_count_null<S, 4>(pt, NA, NB, counts, seed, st);
+    }
+}
+
+// -> EPG_ERR_UNSUPPORTED when the shape is not the fused kernel's (the caller then takes epg_bin_hist_parts +
+// epg_null_hist_from_binhist_parts: the same results)
+int pair_count_null_parts_impl(int32_t nparts, const int8_t* const* XA, const int8_t* const* XB, const int64_t* R, int32_t NA, int32_t NB,
+                               const int64_t* ldxa, const int64_t* ldxb, int32_t S, uint16_t* const* HA, uint16_t* const* HB, int64_t* counts,
+                               uint64_t seed, const int64_t* row0, uint16_t* const* OA, uint16_t* const* OB, hipStream_t st) {
+    if (nparts < 0 || NA < 1 || NB < 1 || S < 1) return fail(EPG_ERR_INVALID_ARG, "pair_count_null: bad shape");
+    if (nparts && (!XA || !XB || !R || !ldxa || !ldxb || !HA || !HB || !row0 || !OA || !OB)) return fail(EPG_ERR_INVALID_ARG, "pair_count_null: NULL argument array");
+    const int ng = (NA + 127) / 128;
+    if (!(S == 15 || S == 18 || S == 25) || ng != (NB + 127) / 128 || ng > 4 || NA + NB > 3072)
+        return fail(EPG_ERR_UNSUPPORTED, "pair_count_null: S=%d, widths %d + %d are not the fused kernel's", S, NA, NB);
+    for (int p = 0; p < nparts; ++p) {
+        if (R[p] < 0) return fail(EPG_ERR_INVALID_ARG, "pair_count_null: bad shape of part %d", p);
+        if (R[p] == 0) continue;
+        if (!XA[p] || !XB[p] || !HA[p] || !HB[p] || !OA[p] || !OB[p]) return fail(EPG_ERR_INVALID_ARG, "pair_count_null: NULL argument of part %d", p);
+        if ((reinterpret_cast<uintptr_t>(HA[p]) | reinterpret_cast<uintptr_t>(HB[p]) | reinterpret_cast<uintptr_t>(OA[p]) | reinterpret_cast<uintptr_t>(OB[p])) & 15)
+            return fail(EPG_ERR_INVALID_ARG, "pair_count_null: histogram arrays must be 16-byte aligned");
+        // the 16-byte loads of a row's last chunk must stay inside the row pitch (engine.alloc_states pads to 16)
+        if (ldxa[p] < 16L * ((NA + 15) / 16) || ldxb[p] < 16L * ((NB + 15) / 16))
+            return fail(EPG_ERR_UNSUPPORTED, "pair_count_null: row pitch of part %d is not padded to 16 bytes", p);
+    }
+    u64* cnt = reinterpret_cast<u64*>(counts);
+    for (int p0 = 0; p0 < nparts;) {
+        PcParts pt;
+        memset(&pt, 0, sizeof(pt));
+        long tiles = 0;
+        int p = p0;
+        for (; p < nparts && pt.n < PC_MAXP; ++p) {
+            if (R[p] == 0) continue;
+            const int k = pt.n++;
+            pt.xa[k] = reinterpret_cast<const char*>(XA[p]); pt.xb[k] = reinterpret_cast<const char*>(XB[p]);
+            pt.ha[k] = HA[p]; pt.hb[k] = HB[p]; pt.oa[k] = OA[p]; pt.ob[k] = OB[p];
+            pt.rows[k] = R[p]; pt.ldxa[k] = ldxa[p]; pt.ldxb[k] = ldxb[p]; pt.key[k] = row0[p];
+            pt.t0[k] = tiles;
+            tiles += (R[p] + 63) / 64;
+        }
+        pt.t0[pt.n] = tiles;
+        p0 = p;
+        if (pt.n == 0) break;
+        int rc;
+        if (S == 18) rc = dispatch_pair_count_null<18>(ng, pt, NA, NB, cnt, (u64)seed, st);
+        else if (S == 15) rc = dispatch_pair_count_null<15>(ng, pt, NA, NB, cnt, (u64)seed, st);
+        else rc = dispatch_pair_count_null<25>(ng, pt, NA, NB, cnt, (u64)seed, st);
+        if (rc) return rc;
+    }
+    return EPG_OK;
 }
 
 // quiescent from cached histograms of the two real groups (scores.py:294-303): every column of A and of B holds the

@@ -250,6 +250,25 @@ def null_hist_from_binhist_parts(HAs, HBs, n_cols, S, ga, gb, seed, row0s, strea
     return OAs, OBs
 
 
+def pair_count_null_parts(XAs, XBs, NA, NB, S, seed, row0s, counts=None):
+    """Paired mode, default group sizes: count pass of both groups and the null draw of several resident parts in ONE launch
+    (epg_pair_count_null_parts).  -> (HAs, HBs, OAs, OBs) lists of [R_p, S] histograms (real groups, null groups).  Raises
+    EpilogosHipError(-2) for shapes outside the fused kernel's: bin_hist_parts + null_hist_from_binhist_parts give the same."""
+    n = len(XAs)
+    sa = [_check_states(X, NA) if X.shape[0] else (0, padded_width(NA)) for X in XAs]
+    sb = [_check_states(X, NB) if X.shape[0] else (0, padded_width(NB)) for X in XBs]
+    rows = [r for r, _l in sa]
+    if rows != [r for r, _l in sb]:
+        raise ValueError("paired inputs must have the same number of bins")
+    dev = XAs[0].device
+    H = hist_rows_alloc(rows + rows, S, dev)
+    O = hist_rows_alloc(rows + rows, S, dev)
+    _abi.call("epg_pair_count_null_parts", n, _ptr_array(XAs), _ptr_array(XBs), (C.c_int64 * n)(*rows), NA, NB,
+              (C.c_int64 * n)(*[l for _r, l in sa]), (C.c_int64 * n)(*[l for _r, l in sb]), S, _ptr_array(H[:n]), _ptr_array(H[n:]),
+              _ptr(counts), seed, (C.c_int64 * n)(*[int(r) for r in row0s]), _ptr_array(O[:n]), _ptr_array(O[n:]), _stream())
+    return H[:n], H[n:], O[:n], O[n:]
+
+
 def hist_s2_from_binhist(H, S, counts=None):
     if counts is None:
         counts = zeros_counts(S * S, device=H.device)

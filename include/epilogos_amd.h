@@ -199,6 +199,17 @@ int epg_null_hist_from_binhist_parts(int32_t nparts, const uint16_t* const* HA, 
                                      int32_t S, int32_t n_cols, int32_t ga, int32_t gb, uint64_t seed, const int64_t* row0,
                                      uint16_t* const* OA, uint16_t* const* OB, void* stream);
 
+/* Paired mode, the default group sizes (ga = NA, gb = NB): count pass of both groups AND the null draw of several resident parts in
+ * ONE kernel -- HA / HB as epg_bin_hist_parts leaves them (their state counts into counts[S], which may be NULL), OA / OB as
+ * epg_null_hist_from_binhist_parts draws them from HA / HB with the keys row0; the same integers, the same draws.  Every part has NA
+ * columns in XA and NB in XB.  Returns EPG_ERR_UNSUPPORTED for shapes outside the fused kernel's (S other than 15 / 18 / 25, widths
+ * that differ in their number of 128-byte groups per row or exceed four, a row pitch not padded to 16 bytes): the caller then makes
+ * the two calls.  Replaces helpers.py:173,183-194 + expected.py:100-113 for resident files of a paired run. */
+int epg_pair_count_null_parts(int32_t nparts, const int8_t* const* XA, const int8_t* const* XB, const int64_t* R, int32_t NA,
+                              int32_t NB, const int64_t* ldxa, const int64_t* ldxb, int32_t S, uint16_t* const* HA,
+                              uint16_t* const* HB, int64_t* counts, uint64_t seed, const int64_t* row0, uint16_t* const* OA,
+                              uint16_t* const* OB, void* stream);
+
 /* ---- test hook (tests/ only; nothing in the package calls it) ----------------------------------------------
  * Several entry points have a fallback kernel that other shapes take; epg_test_force(which, value) makes the next calls take it
  * on any shape so that the tests can compare it with the default on theirs.  which: 0 = the column-by-column null sampler

@@ -285,3 +285,44 @@ def test_null_hist_parts_equals_a_call_per_part(abi, ga_gb):
             abi.call("epg_test_force", 0, 0)
     with pytest.raises(abi.EpilogosHipError):
         abi.call("epg_test_force", 99, 1)
+
+
+@pytest.mark.parametrize("S_,NA,NB", [(18, 379, 342), (18, 70, 53), (15, 130, 200), (25, 300, 257), (18, 512, 400)])
+def test_pair_count_null_parts_equals_the_two_kernels(abi, S_, NA, NB):
+    """epg_pair_count_null_parts (count pass of both groups + null draw in one kernel) against epg_bin_hist_parts +
+    epg_null_hist_from_binhist_parts: the same histograms, the same state counts, the same null groups bit for bit -- parts of
+    0, 1, 63, 64, 65 and a few hundred rows, with and without the count accumulator; shapes outside the fused kernel's are
+    declined with EPG_ERR_UNSUPPORTED."""
+    from epilogos_amd import engine
+    rng = np.random.default_rng(S_ * 1000 + NA)
+    rows = [0, 1, 63, 64, 65, 300, 129, 1000]
+    xs_a = [synth_states(r, NA, S=S_, seed=int(rng.integers(1 << 30)), uniform=S_ > 18) for r in rows]
+    xs_b = [synth_states(r, NB, S=S_, seed=int(rng.integers(1 << 30)), uniform=S_ > 18) for r in rows]
+    xs_a[5][7, 3] = -1                                          # a column without a state
+    xs_b[5][9, :] = 1
+    xs_a[5][9, :] = 1                                           # a bin in which every column holds one state: nothing to draw
+    XAs = [engine.states_to_device(x) if x.shape[0] else torch.empty((0, engine.padded_width(NA)), dtype=torch.int8, device="cuda") for x in xs_a]
+    XBs = [engine.states_to_device(x) if x.shape[0] else torch.empty((0, engine.padded_width(NB)), dtype=torch.int8, device="cuda") for x in xs_b]
+    keys = [(k << 40) + 17 * k for k in range(len(rows))]
+    c_ref = torch.zeros(S_, dtype=torch.int64, device="cuda")
+    H, _ = engine.bin_hist_parts(XAs + XBs, [NA] * len(rows) + [NB] * len(rows), S_, counts=c_ref)
+    HA_ref, HB_ref = H[:len(rows)], H[len(rows):]
+    OA_ref, OB_ref = engine.null_hist_from_binhist_parts(HA_ref, HB_ref, NA + NB, S_, NA, NB, 4242, keys)
+    for with_counts in (True, False):
+        c = torch.zeros(S_, dtype=torch.int64, device="cuda") if with_counts else None
+        HA, HB, OA, OB = engine.pair_count_null_parts(XAs, XBs, NA, NB, S_, 4242, keys, counts=c)
+        for k in range(len(rows)):
+            assert torch.equal(HA[k], HA_ref[k]) and torch.equal(HB[k], HB_ref[k]), (k, rows[k])
+            assert torch.equal(OA[k], OA_ref[k]) and torch.equal(OB[k], OB_ref[k]), (k, rows[k])
+        if with_counts:
+            assert torch.equal(c, c_ref)
+            want = sum(np.bincount(x[x >= 0].ravel().astype(np.int64), minlength=S_)[:S_] for x in xs_a + xs_b if x.shape[0])
+            assert np.array_equal(c.cpu().numpy(), want)
+    with pytest.raises(abi.EpilogosHipError) as e:              # widths in different load-schedule classes: the two kernels' job
+        engine.pair_count_null_parts([engine.states_to_device(synth_states(5, 100))], [engine.states_to_device(synth_states(5, 300))],
+                                     100, 300, 18, 1, [0])
+    assert e.value.code == -2
+    with pytest.raises(abi.EpilogosHipError) as e:
+        engine.pair_count_null_parts([engine.states_to_device(synth_states(5, 40, S=20, uniform=True))],
+                                     [engine.states_to_device(synth_states(5, 40, S=20, uniform=True))], 40, 40, 20, 1, [0])
+    assert e.value.code == -2
