@@ -218,25 +218,29 @@ def bench_single(torch, be, d, sal, X, N, S, R, R_global, world, reps, fence):
            "phases_ms": {"expected": round(exp_ms, 3), "allreduce+normalise": round(comb_ms, 3), "scores": round(score_ms, 3)},
            "path": "backend._HipSingleSession (the command line's session), device-resident"}
     if sal == 2:
-        # bytes the job has to move per bin: X read, H written, H read by the pair counts, H read + float32 scores written
-        bpb = N + 2 * S + 2 * S + 2 * S + 4 * S
+        # bytes the job has to move per bin: X read, H written (the pair counts come out of the count pass's own launch since
+        # round 5: no pass of their own over H), H read + float32 scores written
+        bpb = N + 2 * S + 2 * S + 4 * S
         eng = be.engine
-        H, _ = eng.bin_hist(X, N, S, want_counts=False, H=eng.alloc_hist(X, N, S))    # (where the session's jobs had it)
-        c2 = eng.hist_s2_from_binhist(H, S)
+        H = eng.alloc_hist(X, N, S)                                         # (where the session's jobs had it)
+        c2 = torch.zeros(S * S, dtype=torch.int64, device=dev)
+        eng.bin_hist_s2(X, N, S, counts2=c2, H=H)
         q2 = eng.normalise(c2)
         o = torch.empty((R, S), dtype=torch.float32, device=dev)
         ws = eng.workspace(2, 0, N, S, device=dev)
-        k1 = _event_ms(torch, lambda: eng.bin_hist(X, N, S, want_counts=False, H=H))
+        k1 = _event_ms(torch, lambda: eng.bin_hist_s2(X, N, S, counts2=c2, H=H))
+        k0 = _event_ms(torch, lambda: eng.bin_hist(X, N, S, want_counts=False, H=H))
         kc = _event_ms(torch, lambda: eng.hist_s2_from_binhist(H, S, counts=c2))
         ks = _event_ms(torch, lambda: eng.score_s2_from_binhist(H, N, S, q2, out32=o, ws=ws))
-        out["kernels_ms"] = {"k_bin_hist": round(k1, 4), "k_s2_hist_wave": round(kc, 4), "k_score_s2_bin(+tables)": round(ks, 4)}
+        out["kernels_ms"] = {"k_bin_hist_s2 (count pass + pair counts, one launch)": round(k1, 4), "k_score_s2_bin(+tables)": round(ks, 4),
+                             "for comparison: k_bin_hist alone": round(k0, 4), "for comparison: k_s2_hist_wave (the separate pair-count pass of rounds 2-4)": round(kc, 4)}
         gb = R * bpb / (exp_ms + comb_ms + score_ms) / 1e6
         out["roofline"] = {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBPS, "algorithmic_bytes_per_bin": bpb,
                            "achieved": round(gb, 1), "frac": round(gb / HBM_PEAK_GBPS, 4),
                            "what": "whole job (device time of the three phases) against the bytes it has to move",
-                           "kernel_fracs": {"k_bin_hist (N + 2S B/bin)": round(R * (N + 2 * S) / k1 / 1e6 / HBM_PEAK_GBPS, 4),
-                                            "k_s2_hist_wave (2S B/bin)": round(R * 2 * S / kc / 1e6 / HBM_PEAK_GBPS, 4),
+                           "kernel_fracs": {"k_bin_hist_s2 (N + 2S B/bin)": round(R * (N + 2 * S) / k1 / 1e6 / HBM_PEAK_GBPS, 4),
                                             "k_score_s2_bin (6S B/bin)": round(R * 6 * S / ks / 1e6 / HBM_PEAK_GBPS, 4)}}
+        del H
     else:
         pairs = float(R) * N * (N - 1)
         M = N * (S - 1) if R >= 262144 else N * S                 # the reduced contraction leaves one state per biosample out

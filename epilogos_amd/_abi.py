@@ -28,6 +28,7 @@ PROTOTYPES = {
     "epg_last_error": (C.c_char_p, []),
     "epg_device_cus": (C.c_int, []),
     "epg_bin_hist": (C.c_int, [_p, _i64, _i32, _i64, _i32, _p, _p, _p]),
+    "epg_bin_hist_s2": (C.c_int, [_p, _i64, _i32, _i64, _i32, _p, _p, _p, _p]),
     "epg_bin_hist_parts": (C.c_int, [_i32, _p, _p, _p, _p, _i32, _p, _p, _p]),
     "epg_hist_s1": (C.c_int, [_p, _i64, _i32, _i64, _i32, _p, _p]),
     "epg_hist_s2": (C.c_int, [_p, _i64, _i32, _i64, _i32, _p, _p, _i64, _p]),

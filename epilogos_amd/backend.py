@@ -371,9 +371,8 @@ class _HipSingleSession(_HipSession):
         if self.sal == 1:
             H, _ = eng.bin_hist(X, N, S, counts=self._acc(S), H=eng.alloc_hist(X, N, S) if place else None)
             self.parts.append(H)
-        elif self.sal == 2:
-            H, _ = eng.bin_hist(X, N, S, want_counts=False, H=eng.alloc_hist(X, N, S) if place else None)
-            eng.hist_s2_from_binhist(H, S, counts=self._acc(S * S))
+        elif self.sal == 2:                              # the count pass with the pair counts folded in: one launch
+            H, _ = eng.bin_hist_s2(X, N, S, counts2=self._acc(S * S), H=eng.alloc_hist(X, N, S) if place else None)
             self.parts.append(H)
         elif self.sal == 3:
             # the ~8 GB workspace of the matrix-core contraction is allocated once per session and grows to the largest

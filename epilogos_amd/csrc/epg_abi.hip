@@ -65,6 +65,8 @@ int pair_count_null_parts_impl(int32_t, const int8_t* const*, const int8_t* cons
                                int32_t, uint16_t* const*, uint16_t* const*, int64_t*, uint64_t, const int64_t*, uint16_t* const*, uint16_t* const*,
                                hipStream_t);
 
+int bin_hist_s2_impl(const int8_t*, int64_t, int32_t, int64_t, int32_t, uint16_t*, int64_t*, int64_t*, hipStream_t);
+
 int g_force[FORCE_COUNT] = {0};
 
 }  // namespace epg
@@ -99,6 +101,11 @@ int epg_device_cus(void) {
 
 int epg_bin_hist(const int8_t* X, int64_t R, int32_t N, int64_t ldx, int32_t S, uint16_t* H, int64_t* counts, void* stream) {
     return bin_hist_impl(X, R, N, ldx, S, H, counts, (hipStream_t)stream);
+}
+
+int epg_bin_hist_s2(const int8_t* X, int64_t R, int32_t N, int64_t ldx, int32_t S, uint16_t* H, int64_t* counts, int64_t* counts2,
+                    void* stream) {
+    return bin_hist_s2_impl(X, R, N, ldx, S, H, counts, counts2, (hipStream_t)stream);
 }
 
 int epg_bin_hist_parts(int32_t nparts, const int8_t* const* X, const int64_t* R, const int32_t* N, const int64_t* ldx, int32_t S,

@@ -204,6 +204,18 @@ def bin_hist(X, N, S, want_hist=True, counts=None, want_counts=True, H=None):
     return H, counts
 
 
+def bin_hist_s2(X, N, S, counts2=None, H=None, counts=None):
+    """K1 with the S2 pair counts of the same bins folded into the launch (epg_bin_hist_s2): -> (H, counts2 int64 [S*S]);
+    counts (int64 [S], optional) also gets the state counts."""
+    R, ldx = _check_states(X, N)
+    if H is None:
+        H = torch.empty((R, S), dtype=torch.int16, device=X.device)
+    if counts2 is None:
+        counts2 = zeros_counts(S * S, device=X.device)
+    _abi.call("epg_bin_hist_s2", _ptr(X), R, N, ldx, S, _ptr(H), _ptr(counts), _ptr(counts2), _stream())
+    return H, counts2
+
+
 def _ptr_array(ts):
     return (C.c_void_p * len(ts))(*[t.data_ptr() if t is not None and t.numel() else None for t in ts])
 

@@ -60,6 +60,13 @@ int epg_device_cus(void);
 int epg_bin_hist(const int8_t* X, int64_t R, int32_t N, int64_t ldx, int32_t S,
                  uint16_t* H, int64_t* counts, void* stream);
 
+/* epg_bin_hist with the S2 pair counts of the same bins folded into the launch: H as above (required), counts2[S*S] +=
+ * sum_b h_i*h_j (i != j), h_i*(h_i-1) (i == j) -- what epg_hist_s2_from_binhist(H) adds, expected.py:146-158 -- and, when
+ * counts is not NULL, counts[S] += the state counts.  One launch for 15-, 18- and 25-state models on rows of up to 1024 columns
+ * (the pair products come from the rows the kernel stages in LDS for the H store); the two passes otherwise.  Same integers. */
+int epg_bin_hist_s2(const int8_t* X, int64_t R, int32_t N, int64_t ldx, int32_t S, uint16_t* H, int64_t* counts,
+                    int64_t* counts2, void* stream);
+
 /* epg_bin_hist over `nparts` resident matrices (the chromosome files of a genome; both groups of a paired run) in as few
  * launches as their widths allow (one when every N[p] has the same number of 128-byte groups per row), all parts' state
  * counts into the same counts[S].  X, R, N, ldx, H are HOST arrays of nparts entries (H, or single entries of it, may be NULL).

@@ -326,3 +326,33 @@ def test_pair_count_null_parts_equals_the_two_kernels(abi, S_, NA, NB):
         engine.pair_count_null_parts([engine.states_to_device(synth_states(5, 40, S=20, uniform=True))],
                                      [engine.states_to_device(synth_states(5, 40, S=20, uniform=True))], 40, 40, 20, 1, [0])
     assert e.value.code == -2
+
+
+@pytest.mark.parametrize("S_,N,R", [(18, 833, 3000), (18, 41, 1), (18, 379, 33), (15, 127, 2049), (25, 1024, 700), (18, 1030, 300),
+                                     (20, 64, 500), (18, 200, 31)])
+def test_bin_hist_s2_equals_count_pass_then_pair_count_pass(abi, S_, N, R):
+    """epg_bin_hist_s2 (the S2 pair counts folded into the count pass: one launch) against epg_bin_hist + epg_hist_s2_from_binhist and
+    the oracle (expected.py:146-158): histograms, pair counts and -- when asked for -- state counts, bit for bit; row counts that
+    are not a multiple of 32 (a super-tile's unused rows must not be multiplied), accumulation into non-zero counts, shapes that
+    take the two-pass fallback (a 20-state model, 1030 columns), bytes that are not states."""
+    from epilogos_amd import engine
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    x = synth_states(R, N, S=S_, seed=R + N, uniform=S_ > 18)
+    if R > 3:
+        x[R // 2, N // 2] = -1
+    X = engine.states_to_device(x)
+    H_ref, c1_ref = engine.bin_hist(X, N, S_)
+    c2_ref = engine.hist_s2_from_binhist(H_ref, S_)
+    H = torch.empty((R, S_), dtype=torch.int16, device="cuda")
+    c1 = torch.zeros(S_, dtype=torch.int64, device="cuda")
+    c2 = torch.zeros(S_ * S_, dtype=torch.int64, device="cuda")
+    abi.call("epg_bin_hist_s2", _p(X), R, N, X.stride(0), S_, _p(H), _p(c1), _p(c2), st)
+    assert torch.equal(H, H_ref) and torch.equal(c1, c1_ref) and torch.equal(c2, c2_ref), (S_, N, R)
+    h = engine.hist_to_numpy(H).astype(np.int64)
+    want = h.T @ h
+    want[np.arange(S_), np.arange(S_)] -= h.sum(axis=0)
+    assert np.array_equal(c2.cpu().numpy().reshape(S_, S_), want)
+    H2, c2b = engine.bin_hist_s2(X, N, S_, counts2=c2.clone())                      # += into non-zero counts, no state counts
+    assert torch.equal(H2, H_ref) and torch.equal(c2b, 2 * c2_ref)
+    with pytest.raises(abi.EpilogosHipError):
+        abi.call("epg_bin_hist_s2", _p(X), R, N, X.stride(0), S_, None, None, _p(c2), st)      # H is required

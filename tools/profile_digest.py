@@ -75,10 +75,10 @@ if trace.exists() and bench:
                       % (cfg["s3"]["bins_total"], sum(sy) / len(sy) / 1e6, sum(sc) / len(sc) / 1e6, reps, cfg["s3"]["phases_ms"]["expected"],
                          cfg["s3"]["phases_ms"]["scores"]), ""]
     if "s2" in cfg and "kernels_ms" in cfg["s2"]:
-        a = [d for _, d in tsum(lambda n: "k_s2_hist_wave" in n, 3)]
+        a = [d for _, d in tsum(lambda n: "k_bin_hist_s2" in n, 3)]
         b = [d for _, d in tsum(lambda n: "k_score_s2_bin" in n, 3)]
         if a and b:
-            lines += ["config s2: `k_s2_hist_wave` %.4f ms, `k_score_s2_bin` %.4f ms in the trace (last 3 calls); bench line kernels_ms: %s"
+            lines += ["config s2: `k_bin_hist_s2` %.4f ms, `k_score_s2_bin` %.4f ms in the trace (last 3 calls); bench line kernels_ms: %s"
                       % (sum(a) / len(a) / 1e6, sum(b) / len(b) / 1e6, json.dumps(cfg["s2"]["kernels_ms"])), ""]
     if "paired" in cfg and "phases_ms" in cfg["paired"]:
         names = ("k_null_hist_h", "k_pair_fused_s1", "k_score_s1_from_hist", "k_pair_finish", "k_pair_metrics", "k_quiescent_h")
