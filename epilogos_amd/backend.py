@@ -37,8 +37,8 @@ class HipBackend:
             _, c = eng.bin_hist(X, N, S, want_hist=False)
             return c.cpu().numpy()
         if saliency == 2:
-            H, _ = eng.bin_hist(X, N, S, want_counts=False)
-            return eng.hist_s2_from_binhist(H, S).cpu().numpy().reshape(S, S)
+            _H, c2 = eng.bin_hist_s2(X, N, S)
+            return c2.cpu().numpy().reshape(S, S)
         if saliency == 3:
             return eng.hist_s3(X, N, S).cpu().numpy().reshape(N, N, S, S)
         raise ValueError("Please ensure that saliency metric is either 1, 2, or 3")
@@ -56,8 +56,7 @@ class HipBackend:
         if saliency == 1:
             eng.bin_hist(X, N, S, want_hist=False, counts=acc)
         elif saliency == 2:
-            H, _ = eng.bin_hist(X, N, S, want_counts=False)
-            eng.hist_s2_from_binhist(H, S, counts=acc)
+            eng.bin_hist_s2(X, N, S, counts2=acc)
         elif saliency == 3:
             eng.hist_s3(X, N, S, counts=acc)
         else:
