@@ -285,8 +285,8 @@ def bench_paired(torch, be, d, R, R_global, bin0, S, world, reps, fence, dev, di
     count passes, the all-reduce of the [A|B] counts, normalise, the hypergeometric null groups, four score passes, deltas, null
     distances, STEP 4's per-bin reduction and the quiescence mask -- everything the command line computes before it writes.
     The session is fed the way the command line feeds it: one part per chromosome file (24 in hg19's proportions, natural
-    order), each keyed by (file, row) -- so the null groups of a part are drawn on the session's second stream while the next
-    part is counted."""
+    order), each keyed by (file, row); the session counts the parts in batches (one kernel per batch counts both groups and
+    draws the null groups)."""
     from epilogos_amd.driver import shuffle_key
     eng = be.engine
     XA, XB = eng.alloc_states(R, NA, device=dev), eng.alloc_states(R, NB, device=dev)
@@ -332,14 +332,15 @@ def bench_paired(torch, be, d, R, R_global, bin0, S, world, reps, fence, dev, di
             "job_ms": round(wall_ms, 3), "value": round(R_global / wall_ms / 1e3, 3), "unit": "Mbins/s",
             "outputs_finite": ok, "quiescent_bins": nq, "s1_tables_equal_numpy_reference": patched == 0,
             "host_enqueue_ms_of_the_count_phase": round(host_count_ms, 3),
-            "phases_ms": {"count passes of the 2 x %d parts (main stream; the null groups of part k run on the second stream under "
-                          "the count pass of part k + 1)" % len(parts): round(exp_ms, 3),
-                          "allreduce+normalise+tables": round(comb_ms, 3),
-                          "rest of the null groups + scores/deltas/null distances/metrics/quiescence of all parts (one launch)": round(res_ms, 3)},
+            "phases_ms": {"count pass + null draw of the batches that filled up while the %d parts were added (default group sizes: one "
+                          "kernel per batch, k_pair_count_null; otherwise count launch + sampler launch on the second stream)" % len(parts): round(exp_ms, 3),
+                          "count pass + null draw of the last batch, all-reduce, normalise, tables": round(comb_ms, 3),
+                          "scores/deltas/null distances/metrics/quiescence of all parts (one launch)": round(res_ms, 3)},
             "roofline": {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBPS, "algorithmic_bytes_per_bin": bpb,
                          "achieved": round(gb, 1), "frac": round(gb / HBM_PEAK_GBPS, 4),
                          "what": "whole job (device time of the three phases on the main stream) against the bytes it has to move; the "
-                                 "null groups are compute-bound (Philox + selection sampling), see DESIGN.md 3"},
+                                 "count + null-draw kernel is bound by its VALU instruction count (Philox + selection sampling on top of the "
+                                 "counting core: 110 wave instructions per bin), see DESIGN.md 3"},
             "path": "backend._HipPairedSession (the command line's session), device-resident"}
 
 

@@ -81,7 +81,7 @@ if trace.exists() and bench:
             lines += ["config s2: `k_bin_hist_s2` %.4f ms, `k_score_s2_bin` %.4f ms in the trace (last 3 calls); bench line kernels_ms: %s"
                       % (sum(a) / len(a) / 1e6, sum(b) / len(b) / 1e6, json.dumps(cfg["s2"]["kernels_ms"])), ""]
     if "paired" in cfg and "phases_ms" in cfg["paired"]:
-        names = ("k_null_hist_h", "k_pair_fused_s1", "k_score_s1_from_hist", "k_pair_finish", "k_pair_metrics", "k_quiescent_h")
+        names = ("k_pair_count_null", "k_bin_hist_parts", "k_null_hist_h", "k_pair_fused_s1", "k_pair_finish", "k_pair_metrics", "k_quiescent_h")
         parts = []
         for nm in names:
             v = [d for _, d in tsum(lambda n, nm=nm: nm in n, 0)]
