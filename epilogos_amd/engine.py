@@ -43,7 +43,7 @@ def alloc_states(R, N, device="cuda"):
 PLACE_MIN_BYTES = 1 << 30           # a matrix under 1 GiB is counted in < 0.2 ms: not worth a probe
 PLACE_GOOD = 1.12                   # K1 with the H store / K1 counts only: <= this = "H is in another memory class than X"
 PLACE_BLOCK = 4 << 30               # candidates are the heads of blocks of this size (see alloc_hist)
-PLACE_TRIES = 16
+PLACE_TRIES = 24                    # runs of one class are up to 16 blocks long (profiles/r02ae_*): 24 walks out of any of them
 _placement = {}                     # device index -> {"key", "home", "report"}
 
 
@@ -99,7 +99,7 @@ def alloc_hist(X, N, S):
     buffers are carved: nothing is returned to the driver (freed device memory is scrubbed in the background at every
     HBM-bound kernel's expense), nothing is withheld from the process but the home block.
     While a view of the home is alive (another session still holds its parts) the next request gets a plain allocation.
-    EPILOGOS_PLACEMENT=0 switches the search off; EPILOGOS_PLACEMENT_TRIES bounds it (default 16 blocks)."""
+    EPILOGOS_PLACEMENT=0 switches the search off; EPILOGOS_PLACEMENT_TRIES bounds it (default 24 blocks)."""
     import os
     R = X.shape[0]
     dev = X.device
