@@ -60,6 +60,8 @@ def test_single_group_s1_s2_random_shapes(eng, S, N, R, seed):
         c2 = eng.hist_s2_from_binhist(Hv, S)
         w2 = onp.expected_s2(xv, S)
         assert np.array_equal(c2.cpu().numpy().reshape(S, S), w2)
+        Hf, c2f = eng.bin_hist_s2(Xv, N, S)                      # the count pass with the pair counts folded in (or its fallback)
+        assert torch.equal(Hf, Hv) and torch.equal(c2f, c2)
         q2 = eng.normalise(c2)
         s32, s64 = eng.score_s2_from_binhist(Hv, N, S, q2, want32=True, want64=True)
         r2 = onp.score_s2(xv, q2.cpu().numpy().reshape(S, S), S)
@@ -81,6 +83,12 @@ def test_paired_s1_random_shapes(eng, S, N, R, seed):
     HB, _ = eng.bin_hist(eng.states_to_device(xb), NB, S, counts=cA)
     q = eng.normalise(cA).cpu().numpy()
     OA, OB = eng.null_hist_from_binhist(HA, HB, NA + NB, S, NA, NB, seed=seed, row0=(3 << 40) + 17)
+    try:                                                         # count pass + null draw in one kernel: the same bits where it applies
+        cF = torch.zeros(S, dtype=torch.int64, device="cuda")
+        fa, fb, foa, fob = eng.pair_count_null_parts([eng.states_to_device(xa)], [eng.states_to_device(xb)], NA, NB, S, seed, [(3 << 40) + 17], counts=cF)
+        assert torch.equal(fa[0], HA) and torch.equal(fb[0], HB) and torch.equal(foa[0], OA) and torch.equal(fob[0], OB) and torch.equal(cF, cA)
+    except eng.EpilogosHipError as e:
+        assert e.code == -2 and (S not in (15, 18, 25) or (NA + 127) // 128 != (NB + 127) // 128)
     tot = eng.hist_to_numpy(HA).astype(np.int64) + eng.hist_to_numpy(HB).astype(np.int64)
     oa, ob = eng.hist_to_numpy(OA).astype(np.int64), eng.hist_to_numpy(OB).astype(np.int64)
     assert np.array_equal(oa + ob, tot) and (oa.sum(axis=1) == NA).all() and (ob.sum(axis=1) == NB).all()
