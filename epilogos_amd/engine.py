@@ -41,7 +41,8 @@ def alloc_states(R, N, device="cuda"):
 
 # ---- where the histogram cache of a RESIDENT matrix goes
 PLACE_MIN_BYTES = 1 << 30           # a matrix under 1 GiB is counted in < 0.2 ms: not worth a probe
-PLACE_GOOD = 1.12                   # K1 with the H store / K1 counts only: <= this = "H is in another memory class than X"
+PLACE_GOOD = 1.11                   # K1 with the H store / K1 counts only: <= this = "H is in another memory class than X" (measured:
+                                    # 1.05-1.105 in another class, 1.14-1.19 in the same, 1.118 with X straddling two classes)
 PLACE_BLOCK = 4 << 30               # candidates are the heads of blocks of this size (see alloc_hist)
 PLACE_TRIES = 24                    # runs of one class are up to 16 blocks long (profiles/r02ae_*): 24 walks out of any of them
 _placement = {}                     # device index -> {"key", "home", "report"}
@@ -87,7 +88,7 @@ def alloc_hist(X, N, S):
     allocation order (profiles/r02ae_k1_memory_class_map.txt).  k_bin_hist reads X and writes H: with both in one class the
     launch is 13-17 % slower (2.6 against 2.3 ms for 15 M x 833) whatever the offsets, the data or the other buffers are.  HIP
     does not tell the class of an allocation, so the classifier is the kernel itself, on three 1 M-bin slices of X (head,
-    middle, tail: 0.5 ms per pass): a candidate is good when the launches with the H store cost < 12 % over the counts-only
+    middle, tail: 0.5 ms per pass): a candidate is good when the launches with the H store cost < 11 % over the counts-only
     launches (measured: 1.06-1.10 in another class, 1.14-1.18 in the same, profiles/r05a_placement_spread.txt).
     Candidates are the HEADS OF 4 GiB BLOCKS allocated one after the other and held during the search: the driver serves a
     small allocation from the smallest free fragment that fits -- the crumbs the matrix's own allocation left behind, i.e.
