@@ -503,7 +503,7 @@ def main():
     ap.add_argument("--graph-leg", type=int, default=1, help="after the headline: the step as one hipGraph replay (graph_ms_per_step); 0 = skip")
     ap.add_argument("--config-reps", type=int, default=3)
     ap.add_argument("--extras-deadline", type=int, default=300,
-                    help="seconds the measurements after the timed region (placement experiment, --configs) may take before rank 0 "
+                    help="seconds the measurements after the timed region (--configs, the unplaced jobs, the self-test, the graph leg) may take before rank 0 "
                          "prints the line without the rest and every rank exits; 0 = no limit")
     ap.add_argument("--graph", action="store_true", help="capture the step (K1, all-reduce, combine, score) in a hipGraph and replay it "
                                                          "(kernels_ms then comes from an un-captured probe after the timed region)")
@@ -798,7 +798,7 @@ def main():
         allreduce_probe = {"tensor": "int64[%d]" % S, "calls": n_ar, "device_us_per_call_back_to_back": round(e0.elapsed_time(e1) / n_ar * 1e3, 2),
                            "host_us_per_call": round(host_us, 2), "backend": args.backend, "world": world}
 
-    # ---- the line: everything the timed region produced is in it from here on; what follows (placement experiment, BASELINE
+    # ---- the line: everything the timed region produced is in it from here on; what follows (the unplaced jobs, BASELINE
     # configs 3-5) fills `placement` and `configs` in.  A watchdog on every rank bounds those extras: past --extras-deadline
     # seconds rank 0 prints the line with what it has and every rank leaves, so that a collective that never completes in a
     # secondary measurement cannot take the headline of a multi-GPU run with it.

@@ -465,10 +465,8 @@ class _HipPairedSession(_HipSession):
         self.qstate, self.groupSize, self.seed = quiescentState, groupSize, seed
         self._ready = None                               # results of all parts, computed at the first results() call
         self._pending, self._pending_rows = [], 0        # parts whose count pass has not been launched yet (see add_staged)
-        if getattr(be, "_null_stream", None) is None:    # one second stream per backend, not per session
-            prio = os.environ.get("EPILOGOS_NULL_PRIORITY")
-            be._null_stream = (self.torch.cuda.Stream(device=self.device) if prio is None else
-                               self.torch.cuda.Stream(device=self.device, priority=int(prio)))
+        if getattr(be, "_null_stream", None) is None:    # one second stream per backend, not per session (used by the two-kernel path)
+            be._null_stream = self.torch.cuda.Stream(device=self.device)
         self.null_stream = be._null_stream
 
     def stage(self, arr, N, ticket):

@@ -82,9 +82,9 @@ __global__ __launch_bounds__(256) void k_s3_tq_max(const float* __restrict__ q, 
     if ((threadIdx.x & 63) == 0 && m) atomicMax(maxbits, m);
 }
 
-// scal[0] = unit (score per fixed-point step), scal[1] = 1 / unit.  max|T| N / 2^30 -- the unit of the modal-state kernel
-// (epg_s3_sparse.hip), whose table holds DIFFERENCES of two entries: with one unit the two kernels add up the same
-// integers and return the same bits
+// scal[0] = unit (score per fixed-point step), scal[1] = 1 / unit.  max|T| N / 2^30 (round 3 halved the range for the modal-state
+// kernel, whose table held DIFFERENCES of two entries; that kernel was deleted in round 5, the unit stays: scores are bit-identical
+// to every earlier run)
 __global__ void k_s3_tq_unit(const u32* __restrict__ maxbits, int N, double* __restrict__ scal) {
     const double mx = (double)__uint_as_float(*maxbits);
     const double unit = mx * (double)N / 1073741824.0;

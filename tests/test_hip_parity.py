@@ -296,7 +296,7 @@ def test_quiescent_wide_rows(eng, packed):
 
 @pytest.mark.parametrize("S_,R,hi", [(18, 1000, 834), (5, 129, 4096), (25, 300, 900), (31, 257, 4095), (18, 700, 65536), (30, 1, 70)])
 def test_s2_counts_from_arbitrary_histograms(eng, S_, R, hi):
-    """k_s2_hist_from_binhist on histograms it is handed directly: every S up to 31 (one to three pair roles per
+    """epg_hist_s2_from_binhist (k_s2_hist_wave) on histograms it is handed directly: every S up to 31 (one to three pair roles per
     thread), batches that end mid-way, and counts >= 4096, which leave the 32-bit dot-product path."""
     rng = np.random.default_rng(S_ * 1000 + R)
     h = rng.integers(0, hi, size=(R, S_)).astype(np.uint16)

@@ -56,7 +56,7 @@ if trace.exists() and bench:
                 if ln.startswith("{") and '"kernels_ms"' in ln:
                     own = json.loads(ln)
         lines += ["k_bin_hist over the %d timed dispatches of the trace (dispatches %d..%d of the kernel; later ones belong to the "
-                  "placement experiment and the S2 config): avg %.0f ns, min %d, max %d -- HIP events of the SAME (profiled) process: %s ns; "
+                  "secondary measurements): avg %.0f ns, min %d, max %d -- HIP events of the SAME (profiled) process: %s ns; "
                   "un-profiled run above (another process, its own placement of X and H): %.0f ns"
                   % (steps, 1 + warm, warm + steps, sum(d) / len(d), min(d), max(d),
                      ("%.0f" % (own["kernels_ms"]["k_bin_hist"] * 1e6)) if own else "n/a", bench["kernels_ms"]["k_bin_hist"] * 1e6), ""]
@@ -117,7 +117,7 @@ for cname in ("fetch", "write"):
     for r in rows_c:
         agg[(r["Kernel_Name"].split("(")[0], r["Counter_Name"])].append(float(r["Counter_Value"]))
     for key in list(agg):
-        # k_bin_hist: the placement experiment and the S2 config launch it too (some without the histogram store); the bench's
+        # k_bin_hist: the secondary measurements launch it too (some without the histogram store); the bench's
         # own warm-up + steps are dispatches 1..4 of a PMC pass (`--steps 3 --warmup 1`)
         # (round 5: and the placement probe launches it over 1 M-bin slices first -- the whole-matrix launches with the store are
         # the ones with the largest counter values)
