@@ -88,6 +88,22 @@ __device__ __forceinline__ void store_staged(const char* lds, char* dst, int nby
     if ((nbytes & 2) && lane == 0) *reinterpret_cast<u16*>(dst + nbytes - 2) = *reinterpret_cast<const u16*>(lds + nbytes - 2);
 }
 
+// The same with NON-TEMPORAL stores, for score outputs (nobody on the device reads them again).  A float32 score array written
+// with ordinary stores lingers dirty in L2 and the 256 MB memory-side cache and is written back under whatever streams next --
+// the next job's count pass: measured in bench.py's loop of S1 jobs, k_bin_hist inside the step 2.30 -> 2.25 ms on the genome
+// and 0.323 -> 0.296 ms on the 1.9 M-bin shard of an 8-GPU split (whose 135 MB of scores fit that cache entirely), the score pass
+// itself no slower (0.343 -> 0.337 ms).  Histograms keep ordinary stores: the score pass reads them back at once.
+typedef u32 epg_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store_staged_nt(const char* lds, char* dst, int nbytes, int lane) {
+    const int nchunks = nbytes >> 4;
+    for (int c = lane; c < nchunks; c += 64)
+        __builtin_nontemporal_store(*reinterpret_cast<const epg_u32x4*>(lds + 16 * c), reinterpret_cast<epg_u32x4*>(dst + 16 * c));
+    const int tail0 = nchunks << 4;
+    for (int o = tail0 + 4 * lane; o + 4 <= nbytes; o += 256)
+        __builtin_nontemporal_store(*reinterpret_cast<const u32*>(lds + o), reinterpret_cast<u32*>(dst + o));
+    if ((nbytes & 2) && lane == 0) *reinterpret_cast<u16*>(dst + nbytes - 2) = *reinterpret_cast<const u16*>(lds + nbytes - 2);
+}
+
 // kl(p, q) = p * log2(p / q) with the reference's masked-zero semantics (scores.py:550):
 // 0 where q == 0, 0 where p/q <= 0.
 __device__ __forceinline__ double kl_term(double p, double q) {

@@ -276,7 +276,7 @@ __global__ __launch_bounds__(256) void k_score_s1(const char* __restrict__ X, lo
         }
     };
     auto finish = [&](long st, long row0, int rows) {
-        store_staged(s_stage[wave], reinterpret_cast<char*>(out) + row0 * ROWB, rows * ROWB, lane);
+        store_staged_nt(s_stage[wave], reinterpret_cast<char*>(out) + row0 * ROWB, rows * ROWB, lane);
     };
     tile_loop<S, NG>(X, R, N, ldx, epilogue, finish);
 }
@@ -323,11 +323,16 @@ __global__ __launch_bounds__(LDS_T ? 1024 : 256) void k_score_s1_from_hist(const
                 v[k] = c[k] ? T[(long)c[k] * S + s] : (OT)0;
                 s = s + 1 == S ? 0 : s + 1;
             }
+            // non-temporal: nobody on the device reads the scores again (store_staged_nt, epg_common.h)
             if constexpr (sizeof(OT) == 4) {
-                *reinterpret_cast<float4*>(out + e0) = make_float4(v[0], v[1], v[2], v[3]);
+                typedef float v4f_nt __attribute__((ext_vector_type(4)));
+                const v4f_nt vv = {(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+                __builtin_nontemporal_store(vv, reinterpret_cast<v4f_nt*>(out + e0));
             } else {
-                *reinterpret_cast<double2*>(out + e0) = make_double2(v[0], v[1]);
-                *reinterpret_cast<double2*>(out + e0 + 2) = make_double2(v[2], v[3]);
+                typedef double v2d_nt __attribute__((ext_vector_type(2)));
+                const v2d_nt lo = {(double)v[0], (double)v[1]}, hi = {(double)v[2], (double)v[3]};
+                __builtin_nontemporal_store(lo, reinterpret_cast<v2d_nt*>(out + e0));
+                __builtin_nontemporal_store(hi, reinterpret_cast<v2d_nt*>(out + e0 + 2));
             }
         }
     }

@@ -358,7 +358,7 @@ __global__ __launch_bounds__(256) void k_score_s2_bin(const u16* __restrict__ H,
         __builtin_amdgcn_wave_barrier();
         const long row0 = tile * 64;
         const int rows = (int)(R - row0 < 64 ? R - row0 : 64);
-        store_staged(s_stage[wave], reinterpret_cast<char*>(out) + row0 * ROWB, rows * ROWB, lane);
+        store_staged_nt(s_stage[wave], reinterpret_cast<char*>(out) + row0 * ROWB, rows * ROWB, lane);
         __builtin_amdgcn_wave_barrier();
     }
 }
@@ -477,7 +477,7 @@ __global__ __launch_bounds__(256) void k_pair_finish(const float* __restrict__ a
             }
         }
         __builtin_amdgcn_wave_barrier();
-        store_staged(sa, reinterpret_cast<char*>(delta + row0 * S), rows * rowb, lane);
+        store_staged_nt(sa, reinterpret_cast<char*>(delta + row0 * S), rows * rowb, lane);
         __builtin_amdgcn_wave_barrier();
     }
 }
@@ -723,7 +723,7 @@ __global__ __launch_bounds__(64 * PF_WAVES_MAX) __attribute__((amdgpu_waves_per_
             ndist[row0 + lane] = nsq * nsg;
         }
         __builtin_amdgcn_wave_barrier();
-        store_staged(sD, reinterpret_cast<char*>(delta + row0 * S), rows * rowb, lane);
+        store_staged_nt(sD, reinterpret_cast<char*>(delta + row0 * S), rows * rowb, lane);
         __builtin_amdgcn_wave_barrier();
     }
 }

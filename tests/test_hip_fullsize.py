@@ -103,8 +103,10 @@ def test_placed_histogram_cache(world):
     eng.bin_hist(X, N, S, counts=acc, H=Hp)
     assert torch.equal(Hp, H) and torch.equal(acc, counts)
     assert 1 <= rep["blocks_tried"] <= eng.PLACE_TRIES and 0 <= rep["picked"] < rep["blocks_tried"]
-    assert rep["ratio"] == min(r for r in rep["ratios"] if r != "...")
-    assert rep["good"] == (rep["ratio"] <= eng.PLACE_GOOD)
+    if rep["good"]:                                                  # passed on the slices AND over the whole matrix
+        assert rep["ratio"] <= eng.PLACE_GOOD and rep["picked"] == rep["blocks_tried"] - 1
+        assert rep["whole_matrix_ratios"][str(rep["picked"])] <= eng.PLACE_GOOD_WHOLE
+    assert all(v > 1.0 for v in rep["whole_matrix_ratios"].values())
     home = Hp.data_ptr()
     other = eng.alloc_hist(X, N, S)                                   # the home is in use: a plain allocation
     assert other.data_ptr() != home and eng.placement_report()["plain_while_home_in_use"] == 1
