@@ -68,7 +68,10 @@ def header_symbols():
 
 
 def lib_path():
-    return _build.LIB_PATH
+    """The in-tree library; EPILOGOS_HIP_LIB=<path> loads another build of it (A/B measurements of kernel variants)."""
+    import os
+    p = os.environ.get("EPILOGOS_HIP_LIB")
+    return Path(p) if p else _build.LIB_PATH
 
 
 def load():

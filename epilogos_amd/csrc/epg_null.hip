@@ -676,7 +676,7 @@ int null_hist_from_binhist_impl(const uint16_t* HA, const uint16_t* HB, int64_t 
 // Paired mode, count pass AND null draw in one kernel (round 5).  Two kernels on two streams share every SIMD and lose ~30 % of
 // the issue slots to each other (count pass 2.44 ms + sampler 2.06 ms alone, 3.3-3.4 ms together: profiles/r05g_*).  Here a
 // wave owns tiles of 64 bins of a part: it counts the tile's rows of group A and of group B with k_bin_hist's core (four
-// 16-row sub-tiles, quad per row; at raised priority: whatever feeds the memory pipe goes first), leaves the two real groups'
+// 16-row sub-tiles, quad per row), leaves the two real groups'
 // histograms in its LDS slot, writes them out, then every lane draws its row's null groups from them (nh_sample_row_full) and the
 // wave writes those out too.  The waves of a CU are in different phases, so its memory pipe and its VALU are busy at the same
 // time without a second kernel.  Same integers and the same draws as epg_bin_hist_parts + epg_null_hist_from_binhist_parts
@@ -806,7 +806,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         const bool more = tile + tstride < ntiles;
         if (more) describe(tile + tstride, nx);
         const int rows = (int)(cur.R - cur.r0 < 64 ? cur.R - cur.r0 : 64);
-        __builtin_amdgcn_s_setprio(3);                           // the phase that feeds the memory pipe goes first
+        // Priorities: the DRAW phase runs at wave priority 3, the count phase at 0 -- like the two-kernel form, where the sampler
+        // (the longer chain of VALU work) had to go first.  Measured, job ms on one box: draws first 4.27 / 4.27, count phase first
+        // 4.45 / 4.56, no priorities 4.58 / 4.65; (count 1, draws 3) and (count 0, draws 1) are within noise of draws first.
+        __builtin_amdgcn_s_setprio(0);
 #pragma unroll
         for (int sub = 0; sub < 4; ++sub) {
             const bool valid = cur.r0 + 16 * sub + b < cur.R;
@@ -821,7 +824,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         store_staged(sa, reinterpret_cast<char*>(cur.ha + cur.r0 * S), rows * ROWB, lane);
         store_staged(sb, reinterpret_cast<char*>(cur.hb + cur.r0 * S), rows * ROWB, lane);
         __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_s_setprio(3);
         if (lane < rows)
             nh_sample_row_full(reinterpret_cast<u16*>(sa + lane * ROWB), reinterpret_cast<u16*>(sb + lane * ROWB), bitsA, S, n_cols, NA, seed,
                                (u64)(cur.key + cur.r0 + lane));
