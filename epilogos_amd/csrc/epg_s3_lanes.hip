@@ -245,7 +245,11 @@ __global__ __launch_bounds__(BL_THREADS) void k_s3_score_bl(const char* __restri
     if ((u32)(size_t)(__attribute__((address_space(3))) char*)tab != 0u) __builtin_trap();
 
     if (wv == BL_GW) {
-        // ---- loader wave
+        // ---- loader wave, at wave priority 3 (round 5): it shares its SIMD with four gather waves whose instruction streams never
+        // pause, and every one of its few instructions -- the LDS-DMA requests of chunk a + 1, the wait, the barrier all sixteen
+        // waves meet at -- queued behind theirs: 77.4 -> 62.8 ms per 1 M bins at N = 833 (the "gathers alone" figure above is 58),
+        // one line.  The same bits (tests/test_hip_s3_n833.py, test_hip_s3_stress.py).
+        __builtin_amdgcn_s_setprio(3);
         constexpr int NPF = (NP + 7) / 8;
         const char* tq = TQ + (long)c * N * chb;
         const long tstride = (dbg & 1) ? 0 : chb;                        // measurement: every phase loads the chunk of a = 0
