@@ -71,8 +71,11 @@ __global__ __launch_bounds__(256) void k_transpose_states16(const char* __restri
     constexpr int LD = 68;                            // tile row pitch in bytes: 17 dwords, the four 16-bin groups fall on different banks
     __shared__ __attribute__((aligned(16))) unsigned char tile[64 * LD];
     const int t = threadIdx.x;
-    const long b0 = (long)blockIdx.x * 64;
-    const int s0 = blockIdx.y * 64;
+    // one-dimensional grid, the biosample tile fastest: the ceil(N / 64) blocks that share 64 bins run side by side, so the second
+    // half of every 128-byte line of the state matrix they read is still in L2 (bin tile fastest: each line was fetched twice)
+    const int nst = (N + 63) / 64;
+    const long b0 = (long)(blockIdx.x / nst) * 64;
+    const int s0 = (int)(blockIdx.x % nst) * 64;
     bool seen_bad = false;
     {
         const int row = t >> 2, c = t & 3;
@@ -532,7 +535,7 @@ int transpose_states_flag(const char* X, int64_t R, int32_t N, int64_t ldx, int3
     // 16-byte stores need XT rows that start 16-byte aligned (Rp a multiple of 16, an aligned base): always so for the workspaces
     // this library lays out; anything else takes the byte-per-thread kernel
     if (Rp % 16 == 0 && (reinterpret_cast<uintptr_t>(XT) & 15) == 0)
-        hipLaunchKernelGGL(k_transpose_states16, dim3((unsigned)((Rp + 63) / 64), (unsigned)((N + 63) / 64)), dim3(256), 0, st, X, (long)R, N,
+        hipLaunchKernelGGL(k_transpose_states16, dim3((unsigned)(((Rp + 63) / 64) * ((N + 63) / 64))), dim3(256), 0, st, X, (long)R, N,
                            (long)ldx, S, XT, (long)Rp, shift, bad, dirty);
     else
         hipLaunchKernelGGL(k_transpose_states, dim3((unsigned)((Rp + 63) / 64), (unsigned)((N + 63) / 64)), dim3(256), 0, st, X, (long)R, N,
