@@ -164,6 +164,9 @@ def alloc_hist(X, N, S):
         if r <= PLACE_GOOD and (rw is None or rw <= PLACE_GOOD_WHOLE):
             good = True
             break
+        rs = [t[1] for t in tried]
+        if len(rs) >= 6 and max(rs) <= 1.04 * min(rs):       # six blocks within 4 %: at this shape the store does not tell the
+            break                                            # classes apart (narrow matrices: 127 columns 1.13-1.16 everywhere)
     if not tried:
         raise RuntimeError("out of device memory for the histogram cache")
     # the first good block; else the best whole-matrix figure; else the best slice figure
