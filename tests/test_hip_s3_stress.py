@@ -84,3 +84,29 @@ def test_s3_expected_kernels_random_shapes(monkeypatch):
         assert torch.equal(red2, 2 * full), (N, S, R, dirty)
         if not dirty and N * N * S * S * R < 4e8:                  # oracle-sized and clean: the reference's own counts
             assert np.array_equal(full.cpu().numpy().reshape(N, N, S, S), onp.expected_s3(x, S)), (N, S, R)
+
+
+@pytest.mark.parametrize("N,R,pitch_extra,off", [(33, 130, 0, 0), (33, 130, 0, 5), (70, 257, 3, 1), (129, 64, 0, 0), (17, 1000, 15, 7), (64, 65, 0, 3)])
+def test_s3_on_packed_and_misaligned_matrices(N, R, pitch_extra, off):
+    """The S3 passes start from a transposed copy of the state matrix (k_transpose_states16: 16-byte loads of a bin's states): row
+    pitches that are not a multiple of 16 (a packed matrix: pitch = N), bases that are not 16-byte aligned and rows whose last
+    16-byte piece would reach past the pitch must give the counts and scores of the padded layout."""
+    from epilogos_amd import engine
+    engine.require_gpu()
+    S = 18
+    rng = np.random.default_rng(N * 1000 + R)
+    x = rng.choice(S, size=(R, N), p=rng.dirichlet(np.full(S, 0.5))).astype(np.int8)
+    pitch = N + pitch_extra
+    flat = torch.full((R * pitch + off + 64,), -1, dtype=torch.int8, device="cuda")
+    view = flat[off:off + R * pitch].view(R, pitch)
+    view[:, :N] = torch.from_numpy(x).cuda()
+    Xpad = engine.states_to_device(x)
+    c_ref = engine.hist_s3(Xpad, N, S)
+    c = engine.hist_s3(view, N, S)
+    assert torch.equal(c, c_ref)
+    if N * N * S * S * R < 4e8:
+        assert np.array_equal(c.cpu().numpy().reshape(N, N, S, S), onp.expected_s3(x, S))
+    q = engine.normalise(c)
+    a32, a64 = engine.score_s3(view, N, S, q, want32=True, want64=True)
+    b32, b64 = engine.score_s3(Xpad, N, S, q, want32=True, want64=True)
+    assert torch.equal(a64, b64) and torch.equal(a32, b32)
