@@ -465,6 +465,53 @@ def launch_command(gpus, argv, port):
             "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve())] + list(argv)
 
 
+_KEEPER_SRC = r"""
+import signal, sys
+for sig in (signal.SIGTERM, signal.SIGINT, signal.SIGHUP):
+    signal.signal(sig, signal.SIG_IGN)
+last = None
+for l in sys.stdin.buffer:
+    if l.endswith(b"\n"):
+        last = l
+if last is not None:
+    sys.stdout.buffer.write(last)
+    sys.stdout.flush()
+"""
+
+
+class LineKeeper:
+    """Rank 0 of a run with more than one rank: the ONE JSON line is printed by a small child process (started before the first GPU
+    call, GPU-free, a session of its own) that holds the latest version rank 0 has handed it and prints it when rank 0's end of the
+    pipe closes -- because rank 0 finished, or because it died in a secondary measurement (an abort inside a collective, a SIGTERM
+    from the launcher after another rank failed): no box of this pool has more than one GPU, so every multi-rank leg after the timed
+    region runs for the first time on the driver's node, and none of them may take the headline with it."""
+
+    def __init__(self):
+        import subprocess
+        self.p = subprocess.Popen([sys.executable, "-c", _KEEPER_SRC], stdin=subprocess.PIPE, start_new_session=True)
+
+    def keep(self, text):
+        try:
+            self.p.stdin.write(text.encode() + b"\n")
+            self.p.stdin.flush()
+            return True
+        except (OSError, ValueError):
+            return False
+
+    def final(self, text):
+        """Hand the final line over and wait until it is out; False = the keeper is gone (the caller prints)."""
+        ok = self.keep(text)
+        try:
+            self.p.stdin.close()
+        except OSError:
+            ok = False
+        try:
+            ok = self.p.wait(timeout=20) == 0 and ok
+        except Exception:
+            ok = False
+        return ok
+
+
 def launch_ranks(gpus, argv):
     """One process per GPU under torch.distributed.run, as a child of this (GPU-free) process; -> its exit code."""
     import socket
@@ -540,6 +587,7 @@ def main():
         R_global = args.bins * world
     R = bin1 - bin0
 
+    keeper = LineKeeper() if rank == 0 and world > 1 else None      # (before the first GPU call)
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
@@ -859,18 +907,26 @@ def main():
         }
     emitted = threading.Lock()
 
+    def serialise(**more):
+        for attempt in range(50):                          # the watchdog may serialise while the main thread adds a config
+            try:
+                return json.dumps(dict(line, **more))
+            except RuntimeError:
+                time.sleep(0.01)
+        # never leave without the headline: drop what is still being filled in
+        return json.dumps(dict(line, configs={"deadline": "extras dropped"}, placement=None, **more))
+
     def emit():
         if rank == 0 and emitted.acquire(blocking=False):
-            text = None
-            for attempt in range(50):                      # the watchdog may serialise while the main thread adds a config
-                try:
-                    text = json.dumps(line)
-                    break
-                except RuntimeError:
-                    time.sleep(0.01)
-            if text is None:                               # never leave without the headline: drop what is still being filled in
-                text = json.dumps(dict(line, configs={"deadline": "extras dropped"}, placement=None))
-            print(text, flush=True)
+            text = serialise()
+            if keeper is None or not keeper.final(text):
+                print(text, flush=True)
+
+    def checkpoint(leg):
+        """More than one rank: the line as it stands goes to the keeper before every secondary measurement; it is what comes
+        out if this process does not live to print the complete one."""
+        if keeper is not None and rank == 0:
+            keeper.keep(serialise(ended_early="rank 0 ended in the secondary measurement %r: the line is the state before it" % leg))
 
     def bail():
         # the headline is printed, then the process says what happened: exit code 3 (a hung collective in a secondary
@@ -890,10 +946,15 @@ def main():
         watchdog.daemon = True
         watchdog.start()
 
+    checkpoint("(none started)")
+
     def hang_hook(name):
         progress["leg"] = name
+        checkpoint(name)
         if os.environ.get("EPG_BENCH_HANG_LEG") == name:               # tests: a secondary measurement that never returns
             time.sleep(10 ** 6)
+        if os.environ.get("EPG_BENCH_ABORT_LEG") == name and rank == 0:  # tests: rank 0 dies in a secondary measurement
+            os.abort()
 
     # ---- secondary: the same jobs with the histogram cache where a plain allocation puts it (add_device(place=False))
     placement["report"] = engine.placement_report(dev)

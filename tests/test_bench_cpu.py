@@ -122,3 +122,36 @@ def test_collective_selftest_two_gloo_ranks(tmp_path):
         assert st["ok"] and st["world"] == 2 and st["backend"] == "gloo"
         legs = [k for k, v in st.items() if isinstance(v, dict)]
         assert len(legs) == 6 and all(st[k]["ok"] for k in legs)
+
+
+def test_line_keeper_prints_the_last_whole_line_however_its_parent_ends(tmp_path):
+    """bench.LineKeeper (rank 0 of a multi-rank run): the child prints the latest line it was handed when the parent's end of the
+    pipe closes -- after final(), after an abort, after a SIGTERM from the launcher -- and never a torn one."""
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parents[1]
+    prog = """
+import os, signal, sys, time
+sys.path.insert(0, %r)
+import bench
+k = bench.LineKeeper()
+k.keep('{"v": 1}')
+k.keep('{"v": 2}')
+how = sys.argv[1]
+if how == "final":
+    assert k.final('{"v": 3}')
+elif how == "abort":
+    os.abort()
+elif how == "term":
+    os.kill(os.getpid(), signal.SIGTERM)
+    time.sleep(5)
+elif how == "torn":
+    k.p.stdin.write(b'{"v": 9')
+    k.p.stdin.flush()
+    os._exit(7)
+""" % str(root)
+    for how, want in (("final", '{"v": 3}'), ("abort", '{"v": 2}'), ("term", '{"v": 2}'), ("torn", '{"v": 2}')):
+        res = subprocess.run([sys.executable, "-c", prog, how], capture_output=True, text=True, timeout=120, cwd=str(tmp_path))
+        assert (res.returncode == 0) == (how == "final"), (how, res.returncode, res.stderr[-500:])
+        assert res.stdout.strip().splitlines() == [want], (how, res.stdout, res.stderr[-500:])

@@ -601,6 +601,40 @@ def test_bench_extras_timeout_exits_nonzero_after_the_line(tmp_path):
     assert "exit code 3" in json.loads([l for l in res1.stdout.splitlines() if l.startswith("{")][-1])["configs"]["deadline"]
 
 
+def test_bench_line_survives_rank0_dying_in_a_secondary_measurement(tmp_path):
+    """More than one rank: the line is printed by bench.LineKeeper, a child of rank 0 that holds its latest version.  Rank 0 is
+    aborted (SIGABRT, what a failed assertion inside a collective library does) in the paired leg of two gloo ranks: the launcher
+    reports failure and the ONE line on stdout is the state before that leg -- headline and the S2 config in it, an
+    `ended_early` note, no paired config."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parents[1]
+    env = dict(os.environ, PYTHONPATH=str(root), EPG_BENCH_ABORT_LEG="paired")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR"):
+        env.pop(k, None)
+    cmd = [sys.executable, str(root / "bench.py"), "--gpus", "2", "--backend", "gloo", "--bins", "200000", "--steps", "2",
+           "--warmup", "1", "--config-reps", "1", "--configs", "s2,paired", "--extras-deadline", "120", "--graph-leg", "0"]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=str(tmp_path))
+    assert res.returncode != 0, res.stdout[-2000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, res.stdout[-3000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["value"] > 0 and line["roofline"]["frac"] > 0
+    assert "'paired'" in line["ended_early"]
+    assert "s2" in line["configs"] and "paired" not in line["configs"]
+    # and the undisturbed run of the same command prints one complete line through the same keeper
+    env.pop("EPG_BENCH_ABORT_LEG")
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=str(tmp_path))
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert "ended_early" not in line and "paired" in line["configs"] and "s2" in line["configs"]
+
+
 @pytest.mark.parametrize("mode", ["single", "paired"])
 def test_launch_then_finish_rescores_when_a_device_table_differs(mode):
     """The one sequence of the command line and of bench.py: launch() (STEP 2 on the device + every part's score pass enqueued, no
