@@ -74,6 +74,9 @@ def lib_path():
     return Path(p) if p else _build.LIB_PATH
 
 
+ABI_VERSION = 1
+
+
 def load():
     """Load libepilogos_hip.so (must have been built: __graft_entry__.build() or python -m epilogos_amd.build)."""
     global _lib
@@ -91,6 +94,9 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing: fail loudly
         fn.restype = res
         fn.argtypes = args
+    if lib.epg_version() != ABI_VERSION:                    # (EPG_ABI_VERSION of include/epilogos_amd.h the library was built from)
+        raise EpilogosHipError(-3, "%s has ABI version %d, this package speaks %d: rebuild it with `python -m epilogos_amd.build`"
+                               % (path, lib.epg_version(), ABI_VERSION))
     _lib = lib
     return lib
 

@@ -167,8 +167,8 @@ def alloc_hist(X, N, S):
         rs = [t[1] for t in tried]
         if len(rs) >= 6 and max(rs) <= 1.04 * min(rs):       # six blocks within 4 %: at this shape the store does not tell the
             break                                            # classes apart (narrow matrices: 127 columns 1.13-1.16 everywhere)
-    if not tried:
-        raise RuntimeError("out of device memory for the histogram cache")
+    if not tried:                                            # not even one block fits: no search, a plain allocation (or torch's OOM)
+        return plain()
     # the first good block; else the best whole-matrix figure; else the best slice figure
     rank = lambda t: (0, t[2]) if t[2] is not None else (1, t[1])
     pick = len(tried) - 1 if good else min(range(len(tried)), key=lambda i: rank(tried[i]))

@@ -133,6 +133,13 @@ def test_placed_histogram_cache(world):
     del Hy, Y
     eng.release_placement()
     assert eng.placement_report() is None
+    import os                                                         # no block to be had (here: none allowed): a plain allocation
+    os.environ["EPILOGOS_PLACEMENT_TRIES"] = "0"
+    try:
+        Hn = eng.alloc_hist(X, N, S)
+    finally:
+        del os.environ["EPILOGOS_PLACEMENT_TRIES"]
+    assert Hn.shape == (R, S) and eng.placement_report() is None
 
 
 def test_paired_job_full_size_properties(world):
