@@ -43,8 +43,9 @@ def alloc_states(R, N, device="cuda"):
 PLACE_MIN_BYTES = 1 << 30           # a matrix under 1 GiB is counted in < 0.2 ms: not worth a probe
 PLACE_GOOD = 1.11                   # K1 with the H store / K1 counts only: <= this = "H is in another memory class than X" (measured:
                                     # 1.05-1.105 in another class, 1.14-1.19 in the same, 1.118 with X straddling two classes)
-PLACE_GOOD_WHOLE = 1.14             # the same ratio over the WHOLE matrix (2.25-2.31 / 2.03-2.05 ms = 1.10-1.13 in another class; 1.15-1.20
-                                    # with the matrix straddling classes the slices missed; 1.27-1.3 in the same class)
+PLACE_GOOD_WHOLE = 1.125            # the same ratio over the WHOLE matrix (2.24-2.27 / 2.02-2.03 ms = 1.10-1.12 in another class; 1.14-1.20
+                                    # with the matrix straddling classes the slices missed -- one accepted at 1.136 ran K1 at 2.37 ms --;
+                                    # 1.27-1.3 in the same class)
 PLACE_BLOCK = 4 << 30               # candidates are the heads of blocks of this size (see alloc_hist)
 PLACE_TRIES = 24                    # runs of one class are up to 16 blocks long (profiles/r02ae_*): 24 walks out of any of them
 _placement = {}                     # device index -> {"key", "home", "report"}
@@ -102,7 +103,8 @@ def alloc_hist(X, N, S):
     buffers are carved: nothing is returned to the driver (freed device memory is scrubbed in the background at every
     HBM-bound kernel's expense), nothing is withheld from the process but the home block.
     While a view of the home is alive (another session still holds its parts) the next request gets a plain allocation.
-    EPILOGOS_PLACEMENT=0 switches the search off; EPILOGOS_PLACEMENT_TRIES bounds it (default 24 blocks)."""
+    EPILOGOS_PLACEMENT=0 switches the search off; EPILOGOS_PLACEMENT_TRIES bounds it (default 24 blocks: a run of one class is at
+    most 16 blocks long)."""
     import os
     R = X.shape[0]
     dev = X.device
@@ -134,8 +136,8 @@ def alloc_hist(X, N, S):
         if slices == whole:
             return None
         if not base_whole:
-            base_whole.append(_probe_ms(X, N, S, None, counts, whole, reps=2))
-        return _probe_ms(X, N, S, cand, counts, whole, reps=2) / base_whole[0]
+            base_whole.append(_probe_ms(X, N, S, None, counts, whole, reps=3))
+        return _probe_ms(X, N, S, cand, counts, whole, reps=3) / base_whole[0]
 
     tried = []                                               # (block, slice ratio, whole-matrix ratio or None)
     if st is not None and st["home"].numel() >= hbytes:      # another matrix: is the home good for it too?
@@ -164,18 +166,24 @@ def alloc_hist(X, N, S):
         if r <= PLACE_GOOD and (rw is None or rw <= PLACE_GOOD_WHOLE):
             good = True
             break
+        # blocks that all measure the same: either the store does not tell the classes apart at this shape (narrow matrices,
+        # where the store is a large share of the traffic: 127 columns 1.13-1.16 everywhere) -- six are enough to see that --
+        # or every block so far lies in the matrix's own class, whose runs are up to 64 GiB long (seen on one box: six
+        # blocks at 1.15-1.18 behind the 15 M x 833 matrix, the search gave up and K1 ran at 2.47 instead of 2.25 ms)
         rs = [t[1] for t in tried]
-        if len(rs) >= 6 and max(rs) <= 1.04 * min(rs):       # six blocks within 4 %: at this shape the store does not tell the
-            break                                            # classes apart (narrow matrices: 127 columns 1.13-1.16 everywhere)
+        narrow = 2 * S > 0.10 * X.stride(0)
+        if len(rs) >= (6 if narrow else 17) and max(rs) <= 1.04 * min(rs):
+            break
     if not tried:                                            # not even one block fits: no search, a plain allocation (or torch's OOM)
         return plain()
-    # the first good block; else the best whole-matrix figure; else the best slice figure
-    rank = lambda t: (0, t[2]) if t[2] is not None else (1, t[1])
+    # the first good block; else the best figure: the whole-matrix one where it was taken, the slices' + 0.03 (how the two differ
+    # on a matrix that lies in one class) where not
+    rank = lambda t: t[2] if t[2] is not None else t[1] + 0.03
     pick = len(tried) - 1 if good else min(range(len(tried)), key=lambda i: rank(tried[i]))
     home = tried[pick][0]
     ratios = [round(t[1], 3) for t in tried]
     report = {"probe": "k_bin_hist over 3 x %d bins of the matrix, with the store into the candidate / counts only; a candidate "
-                       "that passes (<= %.2f) is confirmed over the whole matrix (<= %.2f)" % (slices[0][1] - slices[0][0], PLACE_GOOD, PLACE_GOOD_WHOLE),
+                       "that passes (<= %.2f) is confirmed over the whole matrix (<= %.3f)" % (slices[0][1] - slices[0][0], PLACE_GOOD, PLACE_GOOD_WHOLE),
               "ms_counts_only": round(base * 1.0, 4), "blocks_tried": len(tried), "block_GiB": round(block / 2**30, 2),
               "ratios": ratios if len(ratios) <= 12 else ratios[:4] + ["..."] + ratios[-6:],
               "whole_matrix_ratios": {str(i): round(t[2], 3) for i, t in enumerate(tried) if t[2] is not None}, "picked": pick,
