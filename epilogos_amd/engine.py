@@ -47,7 +47,7 @@ PLACE_GOOD_WHOLE = 1.125            # the same ratio over the WHOLE matrix (2.24
                                     # with the matrix straddling classes the slices missed -- one accepted at 1.136 ran K1 at 2.37 ms --;
                                     # 1.27-1.3 in the same class)
 PLACE_BLOCK = 4 << 30               # candidates are the heads of blocks of this size (see alloc_hist)
-PLACE_TRIES = 24                    # runs of one class are up to 16 blocks long (profiles/r02ae_*): 24 walks out of any of them
+PLACE_TRIES = 24                    # a class is at most a third of the memory in one run (96 GB): 24 blocks and the matrix walk out of it
 _placement = {}                     # device index -> {"key", "home", "report"}
 
 
@@ -166,13 +166,14 @@ def alloc_hist(X, N, S):
         if r <= PLACE_GOOD and (rw is None or rw <= PLACE_GOOD_WHOLE):
             good = True
             break
-        # blocks that all measure the same: either the store does not tell the classes apart at this shape (narrow matrices,
-        # where the store is a large share of the traffic: 127 columns 1.13-1.16 everywhere) -- six are enough to see that --
-        # or every block so far lies in the matrix's own class, whose runs are up to 64 GiB long (seen on one box: six
-        # blocks at 1.15-1.18 behind the 15 M x 833 matrix, the search gave up and K1 ran at 2.47 instead of 2.25 ms)
+        # six blocks that all measure the same: at a NARROW shape (the store a large share of the traffic: 127 columns measure
+        # 1.13-1.16 everywhere) the store does not tell the classes apart, and the search ends.  Behind a wide matrix it goes on:
+        # every block so far lies in the matrix's own class, and on a box whose memory is still in one piece a class is ONE run
+        # of a third of it -- seen: six blocks at 1.15-1.18 (the search of that day gave up: K1 2.47 instead of 2.25 ms), and
+        # seventeen at 1.17-1.18 on another box; PLACE_TRIES blocks (96 GiB) and the matrix are more than a third of the memory
         rs = [t[1] for t in tried]
         narrow = 2 * S > 0.10 * X.stride(0)
-        if len(rs) >= (6 if narrow else 17) and max(rs) <= 1.04 * min(rs):
+        if narrow and len(rs) >= 6 and max(rs) <= 1.04 * min(rs):
             break
     if not tried:                                            # not even one block fits: no search, a plain allocation (or torch's OOM)
         return plain()

@@ -565,3 +565,49 @@ def test_get_num_states_counts_whitespace_only_lines_like_pandas(tmp_path):
         f = tmp_path / ("m%d.tsv" % k)
         f.write_text(text)
         assert helpers.getNumStates(f) == pd.read_table(f, header=0, sep="\t").shape[0], repr(text)
+
+
+def test_placement_search_walks_out_of_a_long_run_of_the_matrix_class(monkeypatch):
+    """engine.alloc_hist's search, on the host with the probe faked: behind a WIDE matrix it walks through twenty blocks that
+    measure like the matrix's own memory class (on a box whose memory is in one piece a class is one run of a third of it) and
+    takes the first block of the next class; behind a NARROW matrix, where the store does not tell classes apart, six equal
+    blocks end it; with no good block at all it takes the best; a candidate that passes on the slices and fails over the whole
+    matrix is passed over."""
+    import torch
+    from epilogos_amd import engine
+    order = {}
+
+    def level_of(t):
+        return order.setdefault(t.untyped_storage().data_ptr(), len(order))
+
+    def run(ldx, levels, whole=None, R=4096, S=18):
+        order.clear()
+        X = torch.zeros((R, ldx), dtype=torch.int8)
+
+        def fake_probe(X_, N_, S_, Hflat, counts, slices, reps=3):
+            if Hflat is None:
+                return 1.0
+            k = level_of(Hflat)
+            over_whole = slices == [(0, R)]
+            return (whole or {}).get(k, levels[min(k, len(levels) - 1)] + 0.02) if over_whole else levels[min(k, len(levels) - 1)]
+
+        monkeypatch.setattr(engine, "_probe_ms", fake_probe)
+        monkeypatch.setattr(engine, "PLACE_MIN_BYTES", 1024)
+        monkeypatch.setattr(engine, "PLACE_BLOCK", 1 << 16)
+        monkeypatch.setattr(engine, "_probe_slices", lambda R_, rows=0: [(0, 1024), (1024, 2048), (3072, 4096)])
+        monkeypatch.setattr(torch.cuda, "mem_get_info", lambda dev=None: (1 << 40, 1 << 40))
+        engine.release_placement()
+        H = engine.alloc_hist(X, ldx - 15, S)
+        rep = engine.placement_report(X.device) if X.device.index is not None else dict(engine._placement[None]["report"])
+        engine.release_placement()
+        assert H.shape == (R, S) and H.dtype == torch.int16
+        return rep
+
+    rep = run(848, [1.175] * 20 + [1.08])
+    assert rep["good"] and rep["blocks_tried"] == 21 and rep["picked"] == 20
+    rep = run(128, [1.15] * 24)                                           # narrow: 36 of 128 row bytes are the store
+    assert not rep["good"] and rep["blocks_tried"] == 6
+    rep = run(848, [1.17] * 9 + [1.13] + [1.17] * 14)
+    assert not rep["good"] and rep["blocks_tried"] == engine.PLACE_TRIES and rep["picked"] == 9
+    rep = run(848, [1.17, 1.09, 1.17, 1.08], whole={1: 1.16})            # block 1 straddles: the slices missed it
+    assert rep["good"] and rep["picked"] == 3 and rep["whole_matrix_ratios"] == {"1": 1.16, "3": 1.1}
