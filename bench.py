@@ -601,6 +601,8 @@ def main():
     engine.require_gpu()
     if args.backend != "nccl":
         local_rank = local_rank % torch.cuda.device_count()
+        if world > torch.cuda.device_count():
+            os.environ["EPILOGOS_PLACEMENT"] = "0"       # ranks share a GPU (tests): no search that holds 4 GiB blocks per process
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     use_pg = world > 1 or args.pg
