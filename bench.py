@@ -587,7 +587,12 @@ def main():
         R_global = args.bins * world
     R = bin1 - bin0
 
-    keeper = LineKeeper() if rank == 0 and world > 1 else None      # (before the first GPU call)
+    keeper = None
+    if rank == 0 and world > 1:                                      # (before the first GPU call)
+        try:
+            keeper = LineKeeper()
+        except OSError:
+            keeper = None                                            # no child to be had: rank 0 prints the line itself
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
