@@ -199,7 +199,9 @@ __global__ void k_s2_tables(const float* __restrict__ q, int S, long perms, int 
         const double qd = (double)q[t];
         const double v = qd == 0.0 ? LPQ_MASKED : log2((double)perms * qd);
         LPQ[t] = v;
-        LPQ[S * S + 1 + (t % S) * S + t / S] = v;   // LPQT[j][i] = LPQ[i][j]: a column of LPQ as 8*S contiguous bytes
+        // LPQT[j][i] = LPQ[i][j] / P: a column of LPQ as 8*S contiguous bytes, already divided by the number of ordered pairs
+        // (k_score_s2_bin works on tables that carry the 1/P of p = num / P: one multiply per score less)
+        LPQ[S * S + 1 + (t % S) * S + t / S] = v * (1.0 / (double)perms);
     }
     if (t == 0) {                                   // LPQ[S*S] = number of masked (q == 0) entries: selects the score kernel
         int nz = 0;
@@ -271,6 +273,10 @@ __global__ __launch_bounds__(256) void k_score_s2_from_hist(const u16* __restric
 // (LPQ = log2(P q)), num = h_i h_j (i != j) or h_j (h_j - 1) (i == j), the sum over i collapses to
 //     score[j] = h_j / P * ( A - G_j + LPQ[j,j] + LH[h_j] (n - h_j - 1) + (h_j - 1) LH[h_j - 1] )
 //     A = sum_i h_i LH[h_i],  n = sum_i h_i,  G_j = sum_i h_i LPQ[i,j]
+// Round 5 (late): the 324 FMAs of G were 42 % of the kernel's 774 VALU instructions per bin, the rest bookkeeping around them.  The
+// tables now carry the 1 / P (LH' = LH / P in the block's LDS copy, LPQ' = LPQ / P in the transposed copy k_s2_tables writes), the
+// last term comes from a second LDS table U'[h] = (h - 1) LH'[h - 1] fetched with LH'[h] in the first loop (no gather, no
+// subtract-multiply in the second), n - 1 is formed once: score[j] = h_j ((A' - G'_j + LPQ'[j,j]) + fma(LH'[h_j], (n - 1) - h_j, U'[h_j])).
 // (h_i = 0 and h_j = 0 give exact zeros like the reference's masked terms).  Everything that depends on (i, j) is the
 // S x S matrix-vector product G = h . LPQ.  LPQ does not depend on the bin, so with a lane per bin its entries are
 // WAVE-UNIFORM: they are read with scalar loads (column j of LPQ = 8*S contiguous bytes of the transposed copy) and enter
@@ -308,12 +314,14 @@ __global__ __launch_bounds__(256) void k_score_s2_bin(const u16* __restrict__ H,
     constexpr int ROWB = S * (int)sizeof(OT);
     __shared__ __attribute__((aligned(16))) char s_stage[4][64 * ROWB];
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    double* s_LH = reinterpret_cast<double*>(smem);
+    double* s_LH = reinterpret_cast<double*>(smem);               // [maxc + 1] pairs (LH'[h], U'[h])
     if (LDS_LH) {
-        for (int e = threadIdx.x; e <= maxc; e += 256) s_LH[e] = gLH[e];
+        for (int e = threadIdx.x; e <= maxc; e += 256) {
+            s_LH[2 * e] = gLH[e] * inv_perms;
+            s_LH[2 * e + 1] = e > 0 ? (double)(e - 1) * (gLH[e - 1] * inv_perms) : 0.0;
+        }
         __syncthreads();
     }
-    const double* LH = LDS_LH ? s_LH : gLH;
     const double* __restrict__ LPQT = gLPQ + S * S + 1;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long ntiles = (R + 63) >> 6;
@@ -326,17 +334,26 @@ __global__ __launch_bounds__(256) void k_score_s2_bin(const u16* __restrict__ H,
 #pragma unroll
         for (int m = 0; m < ND; ++m) w[m] = wnext[m];
         load_hrow<S>(H, (tile + stride) * 64 + lane, tile + stride < ntiles ? R : 0, wnext);   // travels while this tile is scored
-        double hd[S], lh[S];
-        double A = 0.0, n = 0.0;
+        double hd[S], lh[S], um[S];
+        double A = 0.0;
+        u32 ni = 0;
 #pragma unroll
         for (int i = 0; i < S; ++i) {
             u32 h = (i & 1) ? w[i >> 1] >> 16 : w[i >> 1] & 0xffffu;
             h = h > (u32)maxc ? (u32)maxc : h;       // cannot happen for consistent inputs; keeps the gather in bounds
             hd[i] = (double)h;
-            lh[i] = LH[h];
+            if (LDS_LH) {
+                const double2 t = *reinterpret_cast<const double2*>(&s_LH[2 * h]);
+                lh[i] = t.x;
+                um[i] = t.y;
+            } else {
+                lh[i] = gLH[h] * inv_perms;
+                um[i] = h ? (hd[i] - 1.0) * (gLH[h - 1] * inv_perms) : 0.0;
+            }
             A = fma(hd[i], lh[i], A);
-            n += hd[i];
+            ni += h;
         }
+        const double n1 = (double)ni - 1.0;
         OT* srow = reinterpret_cast<OT*>(&s_stage[wave][lane * ROWB]);
         // LPQ is re-read through the scalar cache for every tile: as a loop invariant its 2*S*S dwords would be hoisted,
         // would not fit the 102 SGPRs and would be spilled to VGPR lanes (618 v_readlane per tile in the first build)
@@ -350,10 +367,9 @@ __global__ __launch_bounds__(256) void k_score_s2_bin(const u16* __restrict__ H,
             double G = 0.0;
 #pragma unroll
             for (int i = 0; i < S; ++i) G = fma(hd[i], lpq[j * S + i], G);        // scalar operand: LPQ is wave-uniform
-            const u32 hj = (j & 1) ? w[j >> 1] >> 16 : w[j >> 1] & 0xffffu;
-            const double lhm1 = LH[hj ? (hj > (u32)maxc ? (u32)maxc : hj) - 1 : 0];
-            const double br = ((A - G) + lpq[j * S + j]) + fma(lh[j], n - hd[j] - 1.0, (hd[j] - 1.0) * lhm1);
-            srow[j] = (OT)(hj ? hd[j] * inv_perms * br : 0.0);
+            const double br = ((A - G) + lpq[j * S + j]) + fma(lh[j], n1 - hd[j], um[j]);
+            // h_j = 0: hd = 0 and br is finite (every table entry is); the + 0.0 of the fma makes it the reference's +0.0, not -0.0
+            srow[j] = (OT)__builtin_fma(hd[j], br, 0.0);
         }
         __builtin_amdgcn_wave_barrier();
         const long row0 = tile * 64;
@@ -860,7 +876,7 @@ int score_s2_from_hist_impl(const uint16_t* H, int64_t R, int32_t N, int32_t S, 
     if (out64) hipLaunchKernelGGL((k_score_s2_from_hist<double>), dim3((int)blocks), dim3(256), shmem, st, H, (long)R, S, inv, N, LH, LPQ, out64, fast);
     EPG_LAUNCH_CHECK("k_score_s2_from_hist");
     const bool lds_lh = N < 4096;
-    const size_t lh_bytes = lds_lh ? (size_t)(N + 1) * 8 : 0;
+    const size_t lh_bytes = lds_lh ? (size_t)(N + 1) * 16 : 0;                    // pairs (LH'[h], U'[h])
     const long ntiles = (R + 63) / 64;
     long bblocks = (ntiles + 3) / 4;
     if (bblocks > num_cus() * 4L) bblocks = num_cus() * 4L;
