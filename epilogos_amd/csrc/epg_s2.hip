@@ -276,7 +276,8 @@ __global__ __launch_bounds__(256) void k_score_s2_from_hist(const u16* __restric
 // Round 5 (late): the 324 FMAs of G were 42 % of the kernel's 774 VALU instructions per bin, the rest bookkeeping around them.  The
 // tables now carry the 1 / P (LH' = LH / P in the block's LDS copy, LPQ' = LPQ / P in the transposed copy k_s2_tables writes), the
 // last term comes from a second LDS table U'[h] = (h - 1) LH'[h - 1] fetched with LH'[h] in the first loop (no gather, no
-// subtract-multiply in the second), n - 1 is formed once: score[j] = h_j ((A' - G'_j + LPQ'[j,j]) + fma(LH'[h_j], (n - 1) - h_j, U'[h_j])).
+// subtract-multiply in the second), n is summed from the packed words before it: score[j] = h_j ((A' - G'_j + LPQ'[j,j]) + c_j),
+// c_j = fma(LH'[h_j], (n - 1) - h_j, U'[h_j]) formed in the first loop (two arrays of S doubles live, as before: 128 VGPRs).
 // (h_i = 0 and h_j = 0 give exact zeros like the reference's masked terms).  Everything that depends on (i, j) is the
 // S x S matrix-vector product G = h . LPQ.  LPQ does not depend on the bin, so with a lane per bin its entries are
 // WAVE-UNIFORM: they are read with scalar loads (column j of LPQ = 8*S contiguous bytes of the transposed copy) and enter
@@ -334,26 +335,30 @@ __global__ __launch_bounds__(256) void k_score_s2_bin(const u16* __restrict__ H,
 #pragma unroll
         for (int m = 0; m < ND; ++m) w[m] = wnext[m];
         load_hrow<S>(H, (tile + stride) * 64 + lane, tile + stride < ntiles ? R : 0, wnext);   // travels while this tile is scored
-        double hd[S], lh[S], um[S];
+        // n = the row's sum, from the packed words (two 16-bit partial sums: no carry between the halves below 65536 columns)
+        u32 sw = 0;
+#pragma unroll
+        for (int m = 0; m < ND; ++m) sw += w[m];
+        const double n1 = (double)((sw & 0xffffu) + (sw >> 16)) - 1.0;
+        double hd[S], cj[S];                           // cj = LH'[h_j] (n - 1 - h_j) + U'[h_j]: all of the bracket that is per state
         double A = 0.0;
-        u32 ni = 0;
 #pragma unroll
         for (int i = 0; i < S; ++i) {
             u32 h = (i & 1) ? w[i >> 1] >> 16 : w[i >> 1] & 0xffffu;
             h = h > (u32)maxc ? (u32)maxc : h;       // cannot happen for consistent inputs; keeps the gather in bounds
             hd[i] = (double)h;
+            double lh, um;
             if (LDS_LH) {
                 const double2 t = *reinterpret_cast<const double2*>(&s_LH[2 * h]);
-                lh[i] = t.x;
-                um[i] = t.y;
+                lh = t.x;
+                um = t.y;
             } else {
-                lh[i] = gLH[h] * inv_perms;
-                um[i] = h ? (hd[i] - 1.0) * (gLH[h - 1] * inv_perms) : 0.0;
+                lh = gLH[h] * inv_perms;
+                um = h ? (hd[i] - 1.0) * (gLH[h - 1] * inv_perms) : 0.0;
             }
-            A = fma(hd[i], lh[i], A);
-            ni += h;
+            A = fma(hd[i], lh, A);
+            cj[i] = fma(lh, n1 - hd[i], um);
         }
-        const double n1 = (double)ni - 1.0;
         OT* srow = reinterpret_cast<OT*>(&s_stage[wave][lane * ROWB]);
         // LPQ is re-read through the scalar cache for every tile: as a loop invariant its 2*S*S dwords would be hoisted,
         // would not fit the 102 SGPRs and would be spilled to VGPR lanes (618 v_readlane per tile in the first build)
@@ -367,7 +372,7 @@ __global__ __launch_bounds__(256) void k_score_s2_bin(const u16* __restrict__ H,
             double G = 0.0;
 #pragma unroll
             for (int i = 0; i < S; ++i) G = fma(hd[i], lpq[j * S + i], G);        // scalar operand: LPQ is wave-uniform
-            const double br = ((A - G) + lpq[j * S + j]) + fma(lh[j], n1 - hd[j], um[j]);
+            const double br = ((A - G) + lpq[j * S + j]) + cj[j];
             // h_j = 0: hd = 0 and br is finite (every table entry is); the + 0.0 of the fma makes it the reference's +0.0, not -0.0
             srow[j] = (OT)__builtin_fma(hd[j], br, 0.0);
         }
