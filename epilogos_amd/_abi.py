@@ -74,7 +74,14 @@ def lib_path():
     return Path(p) if p else _build.LIB_PATH
 
 
-ABI_VERSION = 1
+def _header_abi_version():
+    m = re.search(r"^#define\s+EPG_ABI_VERSION\s+(\d+)", HEADER.read_text(), flags=re.M)
+    if m is None:
+        raise RuntimeError("EPG_ABI_VERSION not found in %s" % HEADER)
+    return int(m.group(1))
+
+
+ABI_VERSION = _header_abi_version()                         # one source: the header the library is built from
 
 
 def load():

@@ -208,8 +208,12 @@ class _HipSession:
         """-> alloc(R, N) for _io.read_table / helpers.readTable: a pinned, row-padded destination for part `ticket`."""
         def make(R, N):
             ldx = self.eng.padded_width(N)
-            buf = self.pool.acquire(ticket, R * ldx)
-            self.held[ticket] = buf
+            buf = self.held.get(ticket)                  # asked twice for one part (helpers.readTable's pandas re-read of a file
+            if buf is None or buf.numel() < R * ldx:     # the native parser refused): the same buffer when it fits
+                if buf is not None:
+                    self.pool.release(self.held.pop(ticket))
+                buf = self.pool.acquire(ticket, R * ldx)
+                self.held[ticket] = buf
             return buf[:R * ldx].view(R, ldx).numpy()
         return make
 

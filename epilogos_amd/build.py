@@ -9,7 +9,7 @@ ROOT = PKG.parent
 CSRC = PKG / "csrc"
 LIB_DIR = PKG / "_lib"
 LIB_PATH = LIB_DIR / "libepilogos_hip.so"
-SOURCES = ["epg_abi.hip", "epg_s1.hip", "epg_s2.hip", "epg_s3.hip", "epg_s3_mfma.hip", "epg_s3_gemm.hip", "epg_s3_lanes.hip", "epg_null.hip", "epg_wide.hip"]
+SOURCES = ["epg_abi.hip", "epg_s1.hip", "epg_s2.hip", "epg_s3.hip", "epg_s3_transpose.hip", "epg_s3_gemm.hip", "epg_s3_lanes.hip", "epg_null.hip", "epg_wide.hip"]
 HEADERS = [CSRC / "epg_common.h", CSRC / "epg_count.h", ROOT / "include" / "epilogos_amd.h"]
 ARCH = "gfx950"
 

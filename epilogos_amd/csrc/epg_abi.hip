@@ -73,16 +73,7 @@ int g_force[FORCE_COUNT] = {0};
 
 using namespace epg;
 
-namespace epg { extern int g_blocks_per_cu; }
-
 extern "C" {
-
-// tuning hook for A/B experiments (not part of the public header): persistent-grid size in blocks per CU
-int epg_debug_set_variant(int variant, int blocks_per_cu) {
-    (void)variant;
-    if (blocks_per_cu > 0) epg::g_blocks_per_cu = blocks_per_cu;
-    return EPG_OK;
-}
 
 int epg_test_force(int32_t which, int32_t value) {
     if (which < 0 || which >= FORCE_COUNT) return fail(EPG_ERR_INVALID_ARG, "test_force: unknown switch %d", which);

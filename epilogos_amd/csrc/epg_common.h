@@ -29,7 +29,7 @@ static inline const char* exp_env(const char* name) { return getenv(name); }
 static inline const char* exp_env(const char*) { return nullptr; }
 #endif
 
-enum Force { FORCE_NULL_SEQ = 0, FORCE_S3_SCORE_BINS, FORCE_S3_CONTRACTION, FORCE_S3_HIST_LDS, FORCE_COUNT };
+enum Force { FORCE_NULL_SEQ = 0, FORCE_S3_SCORE_BINS, FORCE_S3_CONTRACTION, FORCE_S3_HIST_LDS, FORCE_K1_BLOCKS_PER_CU, FORCE_COUNT };
 extern int g_force[FORCE_COUNT];
 
 #define EPG_HIP(expr)                                                                         \
@@ -111,6 +111,25 @@ __device__ __forceinline__ double kl_term(double p, double q) {
     const double r = p / q;
     if (!(r > 0.0)) return 0.0;
     return p * log2(r);
+}
+
+// One entry of the S3 score table, T = klScoreND(float32(1) / P, q) with both operands float32 (scores.py:479-480; the masked-zero
+// rules of scores.py:550).  Every operation of the reference's float32 expression is CORRECTLY ROUNDED here: the quotient (IEEE
+// division), the logarithm (evaluated in float64 and rounded once to float32) and the product.  Rounds 1-5 called the device's
+// float32 log2f (<= 1 ulp, not the same ulp as numpy's): real tables are made of few distinct values, so a logarithm that is one
+// ulp off does not average out over the 832 terms of a (bin, biosample), and with terms of both signs the scores were only good
+// to 2e-6 of the float64 restatement.  numpy's own float32 log2 is 1-2 ulp off the correctly rounded value in 0.5-23 % of the
+// arguments (SVML on the build container's Xeon, tests/test_oracle_golden.py records it); against ITS table the scores from this
+// one agree to < 1e-7 on every test shape, against a correctly rounded host table to the fixed-point rounding (~1e-9).
+__device__ __forceinline__ float s3_table_entry(float qv, float obs) {
+    if (qv == 0.0f) return 0.0f;
+    const float r = __fdiv_rn(obs, qv);
+    if (!(r > 0.0f)) return 0.0f;
+#ifdef EPG_S3_TABLE_LOG2F                                // (tools/build_ab_lib.py -DEPG_S3_TABLE_LOG2F: rounds 1-5's table, for the record)
+    return obs * log2f(r);
+#else
+    return __fmul_rn(obs, (float)log2((double)r));
+#endif
 }
 
 }  // namespace epg

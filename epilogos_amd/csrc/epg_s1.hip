@@ -395,11 +395,13 @@ __global__ __launch_bounds__(256) void k_normalise_small(const IT* __restrict__ 
 // ---------------------------------------------------------------------------------------------------------------
 // host-side dispatch
 // ---------------------------------------------------------------------------------------------------------------
-extern int g_blocks_per_cu;
+// persistent grid size in blocks per CU.  Round 3: two blocks (2 waves per SIMD) measure 3-4 % faster than four on 1.9-7.5 M-bin
+// shards and 1 % on 15 M bins (profiles/r03i_*); epg_test_force(4, n) sets another for A/B runs (tools/kbench.py)
+static int blocks_per_cu() { return g_force[FORCE_K1_BLOCKS_PER_CU] > 0 ? g_force[FORCE_K1_BLOCKS_PER_CU] : 2; }
 static int grid_for_tiles(long R) {
     const long nsuper = (R + 31) >> 5;
     long blocks = (nsuper + 3) / 4;
-    const long cap = (long)num_cus() * g_blocks_per_cu;
+    const long cap = (long)num_cus() * blocks_per_cu();
     if (blocks > cap) {
         // persistent grid: a wave walks super-tiles st, st + waves, ...; with the full grid the waves of a 1.9 M-bin shard (an
         // eighth of the genome) get 14 or 15 of them -- the launch ends with 5 % of its time spent by the waves that got 15.
@@ -410,9 +412,6 @@ static int grid_for_tiles(long R) {
     if (blocks < 1) blocks = 1;
     return (int)blocks;
 }
-
-int g_blocks_per_cu = 2;  // persistent grid size (epg_debug_set_variant tunes it for A/B runs).  Round 3: two blocks (2 waves per
-                          // SIMD) measure 3-4 % faster than four on 1.9-7.5 M-bin shards and 1 % on 15 M bins (profiles/r03i_*)
 
 template <int S, int NG>
 static void launch_bin_hist(const char* X, long R, int N, long ldx, int Sout, u16* H, u64* counts, hipStream_t st) {

@@ -103,7 +103,8 @@ __global__ __launch_bounds__(S3H_THREADS) void k_s3_hist(const char* __restrict_
     }
 }
 
-// T[a][b][i][j] = float32 kl(float32(1)/P, q[a,b,i,j]); float32 arithmetic like scores.py:479-480.  Same layout as q.
+// T[a][b][i][j] = float32 kl(float32(1)/P, q[a,b,i,j]); float32 operands and results like scores.py:479-480, every operation
+// correctly rounded (s3_table_entry, epg_common.h).  Same layout as q.
 // rows a in [N, Nceil) and the diagonal a == b are zero, so that the score kernel needs no predicates
 __global__ void k_s3_table(const float* __restrict__ q, int N, int Nceil, int S, float* __restrict__ T) {
     const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -113,11 +114,7 @@ __global__ void k_s3_table(const float* __restrict__ q, int N, int Nceil, int S,
     if (e >= total || ab / N == ab % N) { T[e] = 0.0f; return; }
     const float qv = q[e];
     const float obs = 1.0f / (float)((long)N * (N - 1));
-    float v = 0.0f;
-    if (qv != 0.0f) {
-        const float r = obs / qv;
-        if (r > 0.0f) v = obs * log2f(r);
-    }
+    const float v = s3_table_entry(qv, obs);
     T[e] = v;
 }
 
@@ -283,9 +280,8 @@ static int s3_ta(int S) {
     return ta;
 }
 
-int64_t s3_mfma_ws_bytes(int64_t R, int N);
+int64_t s3_xt_bytes(int64_t R, int N);
 int transpose_states(const char* X, int64_t R, int32_t N, int64_t ldx, int32_t S, char* XT, int64_t Rp, int shift, hipStream_t st);
-int hist_s3_mfma(const char* X, int64_t R, int32_t N, int64_t ldx, int32_t S, int32_t* counts, void* ws, hipStream_t st);
 int64_t s3_gemm_ws_bytes(int64_t R, int N, int S);
 int64_t s3_gemm_ws_min_bytes(int64_t R, int N, int S);
 int hist_s3_gemm(const char* X, int64_t R, int32_t N, int64_t ldx, int32_t S, int32_t* counts, void* ws, int64_t ws_bytes, hipStream_t st);
@@ -305,7 +301,7 @@ int64_t s3_ws_bytes(int64_t R, int N, int S) {
     if (S > 31) return align_up(R * S * 8, 256) + 256;       // the wide models (epg_wide.hip): the fixed-point cells, nothing else
     // score: table + transposed state matrix + float64 accumulator; expected: transposed state matrix (+ a chunk of the
     // precomputed fp4 one-hot operand for the default kernel)
-    int64_t score = s3_table_bytes(N, S) + s3_mfma_ws_bytes(R, N) + align_up(R * S * 8, 256);
+    int64_t score = s3_table_bytes(N, S) + s3_xt_bytes(R, N) + align_up(R * S * 8, 256);
     if (s3_lanes_ok(N, S) && s3_lanes_ws_bytes(R, N, S) > score) score = s3_lanes_ws_bytes(R, N, S);
     const int64_t expected = s3_gemm_ws_bytes(R, N, S);
     return score > expected ? score : expected;
@@ -318,15 +314,12 @@ int hist_s3_impl(const int8_t* X8, int64_t R, int32_t N, int64_t ldx, int32_t S,
     if (R == 0) return EPG_OK;
     if (!X8 || !counts) return fail(EPG_ERR_INVALID_ARG, "hist_s3: NULL argument");
     if (S > 31) return wide_hist_s3(X8, R, N, ldx, S, counts, st);                      // the wide models: epg_wide.hip
-    // matrix-core path when the caller gave room for the transposed matrix (S <= 30: padding rows use pattern 30);
-    // the LDS-counter kernel is the fallback for S = 31 / no workspace (epg_test_force(3, 1): on any shape);
-    // default: the precomputed-operand contraction (epg_s3_gemm.hip) when the workspace holds a chunk of the operand, else the
-    // build-in-kernel contraction of epg_s3_mfma.hip (a workspace that holds the transposed matrix only)
+    // matrix-core path (epg_s3_gemm.hip: the precomputed one-hot fp4 contraction) when the caller's workspace holds the transposed
+    // matrix and at least a 16 K-bin chunk of the operand (S <= 30: padding rows use pattern 30); the LDS-counter kernel below is
+    // the path for S = 31, for no / too small a workspace, and -- epg_test_force(3, 1) -- for the tests on any shape
     const bool force_lds = g_force[FORCE_S3_HIST_LDS] != 0;
     if (!force_lds && S <= 30 && ws && ws_bytes >= s3_gemm_ws_min_bytes(R, N, S))
         return hist_s3_gemm(reinterpret_cast<const char*>(X8), R, N, ldx, S, counts, ws, ws_bytes, st);
-    if (!force_lds && S <= 30 && ws && ws_bytes >= s3_mfma_ws_bytes(R, N))
-        return hist_s3_mfma(reinterpret_cast<const char*>(X8), R, N, ldx, S, counts, ws, st);
     const int TA = s3_ta(S);
     if (TA < 1) return fail(EPG_ERR_UNSUPPORTED, "hist_s3: S=%d needs more LDS than a CU has", S);
     const int n_atiles = (N + TA - 1) / TA, n_btiles = (N + S3_TB - 1) / S3_TB;
@@ -354,7 +347,7 @@ int score_s3_impl(const int8_t* X8, int64_t R, int32_t N, int64_t ldx, int32_t S
     const bool force_bins = g_force[FORCE_S3_SCORE_BINS] != 0;
     if (!force_bins && s3_lanes_ok(N, S) && ws_bytes >= s3_lanes_ws_bytes(R, N, S) - (out64 ? align_up(R * S * 8, 256) : 0))
         return score_s3_lanes(X8, R, N, ldx, S, q, out64, out32, ws, ws_bytes, st);
-    const int64_t tb = s3_table_bytes(N, S), xtb = s3_mfma_ws_bytes(R, N);
+    const int64_t tb = s3_table_bytes(N, S), xtb = s3_xt_bytes(R, N);
     const int64_t need = tb + xtb + (out64 ? 0 : align_up(R * S * 8, 256));
     if (ws_bytes < need) return fail(EPG_ERR_WORKSPACE, "score_s3: workspace %lld < %lld bytes", (long long)ws_bytes, (long long)need);
     float* T = reinterpret_cast<float*>(ws);

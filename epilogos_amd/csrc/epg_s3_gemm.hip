@@ -1,8 +1,8 @@
 // S3 expected pass as a pure fp4 matrix-core contraction of a PRECOMPUTED one-hot operand (gfx950).
 //
 // C[a,b,i,j] = #{bins : x[a] == i and x[b] == j} = E^T E for the one-hot expansion E[bin, (sample, state)]
-// (reference expected.py:183-200).  epg_s3_mfma.hip builds the one-hot nibbles inside the contraction kernel, from state
-// bytes, and measured that on a gfx950 SIMD the VALU time of that build and the MFMA time ADD UP (tools/ubench/
+// (reference expected.py:183-200).  Rounds 1-2 built the one-hot nibbles inside the contraction kernel, from state
+// bytes (deleted in round 6), and measured that on a gfx950 SIMD the VALU time of that build and the MFMA time ADD UP (tools/ubench/
 // mfma_valu.hip): 9 MFMAs of 64 bins cost ~400 cycles, the operand build ~350 more, and every operand is rebuilt by each of
 // the ~157 workgroups that need it.  Here every operand is built ONCE per chunk of bins into HBM, already in the register
 // layout of v_mfma_scale_f32_32x32x64_f8f6f4 (fp4 E2M1, 1.0 = 0b0010, unit block scales), and the contraction kernel is
@@ -53,14 +53,17 @@ constexpr int G_RING_DEFAULT = 3;
 static_assert(g_lds_bytes(4) <= 160 * 1024, "the ring of four must fit a CU's LDS");
 constexpr int G_PATCH_P = 8, G_PATCH_Q = G_WN == 2 ? 8 : 4;           // workgroup ordering: patches of the (P, Q) task grid
 static_assert(G_LA == 2 || G_LA == 3, "five or six loads per wave and stage");
-constexpr long G_KC_MAX = 1048576;                      // bins per chunk the workspace size is quoted for (multiple of 512; < 2^24)
+// bins per chunk the workspace size is quoted for (multiple of 512; < 2^24): 2 M bins = 15 GB of operand at N = 833, of 288.  Every
+// chunk ends in the epilogue's ~2 atomics per cell of counts: 8 M bins in chunks of 1 / 2 / 4 M measure 283.0 / 276.2 / 281.2 ms
+// for the expected phase (profiles/r06b_s3_chunk_overlap_ab.txt; 1 M until round 5)
+constexpr long G_KC_MAX = 2097152;
 constexpr long G_KC_MIN = 16384;
 constexpr long G_REDUCED_MIN_BINS = 262144;             // calls shorter than this take the full contraction (see hist_s3_gemm)
 
 __host__ __device__ inline int g_rows_padded(int NS) { return (NS + G_BN - 1) / G_BN * G_BN; }
 
-// SWAR one-hot of 32 state bytes (two uint4) against the lane's state: fp4 nibbles, 0b0010 where equal (see
-// epg_s3_mfma.hip: both operands come from this routine, so which bin lands in which nibble does not matter)
+// SWAR one-hot of 32 state bytes (two uint4) against the lane's state: fp4 nibbles, 0b0010 where equal
+// (both operands come from this routine, so which bin lands in which nibble does not matter)
 __device__ __forceinline__ u32 g_eq_pair_fp4(u32 w0, u32 w1, u32 pat) {
     const u32 d0 = 0x80808080u - (w0 ^ pat);
     const u32 d1 = 0x80808080u - (w1 ^ pat);
@@ -542,7 +545,15 @@ int hist_s3_gemm(const char* X, int64_t R, int32_t N, int64_t ldx, int32_t S, in
     return hist_s3_gemm_run(XT, Rp, N, S, counts, tasks, E4, KC, dbg_env, dirty, 1, nullptr, st);
 }
 
-// the chunk loop of one contraction over the transposed matrix: one-hot operand of a chunk, then the SYRK kernel
+// the chunk loop of one contraction over the transposed matrix: one-hot operand of a chunk, then the SYRK kernel.
+// The two ALTERNATE on the caller's stream (2.3 ms of HBM / VALU work, then 32 ms of matrix work, per 1 M bins).  Round 6 built the
+// obvious overlap -- operand of chunk c + 1 into a second buffer on a library-owned helper stream, events between the two -- and
+// measured it (profiles/r06b_s3_chunk_overlap_ab.txt, 8 M bins): helper stream at the lowest priority 283.8 ms against 283.0 serial
+// (the operand kernel gets no CU before the contraction's last workgroups are out), at normal / high priority +3-4 % (its blocks
+// take CUs the contraction then cannot use), confined to 8 / 16 / 32 CUs by a CU mask 533 / 428 / 351 ms (it needs most of the chip
+// to reach its bandwidth).  The reason is in the resource report: k_s3_syrk_fp4 takes 256 VGPRs x 2 waves per SIMD, the whole
+// register file of every CU it runs on, so no other wave can be resident beside it -- two kernels never share a CU here, and a
+// second stream can only hand whole CUs from one to the other.  The code was taken out again; the serial order stays.
 static int hist_s3_gemm_run(const char* XT, long Rp, int N, int S, int32_t* counts, int* tasks, char* E4, long KC, int dbg_env,
                             const int* gate, int want, int* marg, hipStream_t st) {
     const int NS = N * S, NSP = g_rows_padded(NS), NT = NSP / 32, NQ = NSP / G_BN;

@@ -55,14 +55,7 @@ static inline int bl_si(int S) { return (S + 1) | 1; }                          
 static inline int bl_chb(int S) { return (int)align_up((int64_t)S * 32 * bl_si(S) * 4, 1024); }   // bytes of one (chunk, a): whole wave loads
 static inline int bl_nchunk(int N) { return (N + 31) / 32; }
 
-__device__ __forceinline__ float s3_t(float qv, float obs) {   // k_s3_table's arithmetic (float32 like scores.py:479-480)
-    float v = 0.0f;
-    if (qv != 0.0f) {
-        const float r = obs / qv;
-        if (r > 0.0f) v = obs * log2f(r);
-    }
-    return v;
-}
+__device__ __forceinline__ float s3_t(float qv, float obs) { return s3_table_entry(qv, obs); }   // (epg_common.h)
 
 // max |T| over the off-diagonal table (bits of a non-negative float order like unsigned integers)
 __global__ __launch_bounds__(256) void k_s3_tq_max(const float* __restrict__ q, int N, int S, u32* __restrict__ maxbits) {

@@ -123,14 +123,7 @@ int wide_hist_s3(const int8_t* X, int64_t R, int32_t N, int64_t ldx, int32_t S, 
 // takes a (bin, b), sums its terms in float64 and adds them to the (bin, state) cell as a 2^-50 fixed-point integer -- integer
 // adds commute, so the scores do not depend on the order of the atomics (like every other S3 score kernel of this library).
 // ---------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float w_s3_t(float qv, float obs) {
-    float v = 0.0f;
-    if (qv != 0.0f) {
-        const float r = obs / qv;
-        if (r > 0.0f) v = obs * log2f(r);
-    }
-    return v;
-}
+__device__ __forceinline__ float w_s3_t(float qv, float obs) { return s3_table_entry(qv, obs); }   // (epg_common.h)
 
 __global__ __launch_bounds__(256) void k_w_score_s3(const unsigned char* __restrict__ X, long R, int N, long ldx, int S, const float* __restrict__ q,
                                                    long long* __restrict__ cells) {

@@ -58,9 +58,55 @@ def _cache_paths(path):
     return [Path(str(base) + ext) for ext in (".states.npy", ".locblob.npy", ".locoff.npy", ".range.npy")]
 
 
+def _readTablePandas(path, rowsToCalc, alloc, with_range):
+    """A matrix file as the REFERENCE reads it -- pandas.read_table(header=None, sep="\\t"), helpers.py:152-155 for the states and
+    scores.py:161 for the first three columns -- for a file the native parser refuses.  pandas is more lenient than a strict
+    reading of the format (README.md:127-134): it skips blank lines, ignores blanks around a number, takes "+1" and "1.0" (a
+    float column cast to int).  A drop-in must read what the reference reads, so such a file goes through pandas itself (slow:
+    ~2 us per value) with a warning; what pandas cannot turn into integers raises here as it does there.  Locations come back
+    as the reference would print them ("{}\\t{}\\t{}" of pandas' values, scores.py:526-531)."""
+    import pandas as pd
+    df = pd.read_table(Path(path), header=None, sep="\t")
+    body = df.iloc[:, 3:]
+    if body.isna().to_numpy().any():
+        # a row with fewer fields than the first: pandas pads it with NaN and the reference's to_numpy(dtype=int) turns that into
+        # an arbitrary integer (a numpy RuntimeWarning, no error) -- a wrong result; here it is an error
+        raise ValueError("{}: a row has fewer state columns than the first row".format(path))
+    vals = body.to_numpy(dtype=int)                                        # (the reference subtracts 1 here: helpers.py:155)
+    R = vals.shape[0]
+    lo, hi = (0, R) if rowsToCalc is None else (max(rowsToCalc[0], 0), min(rowsToCalc[1], R))
+    hi = max(hi, lo)
+    limit = _io.state_limit()
+    part = vals[lo:hi]
+    st = np.where((part >= 1) & (part <= limit), part - 1, -1).astype(np.int8)     # outside the model: "not a state", like the native parser
+    if alloc is None:
+        out = st
+    else:
+        out = alloc(hi - lo, st.shape[1])
+        out[:, :st.shape[1]] = st
+        out[:, st.shape[1]:] = -1
+    loc = _io.Locations.from_object_array(df.iloc[lo:hi, :3].to_numpy())
+    if with_range:
+        return out, loc, ((int(vals.min()), int(vals.max())) if vals.size else (0, 0))
+    return out, loc
+
+
+def _readTableNative(path, rowsToCalc, threads, alloc, with_range):
+    """_io.read_table; a file with a line the native parser calls malformed is read again the way the reference reads it."""
+    try:
+        return _io.read_table(Path(path), rowsToCalc, threads=threads, alloc=alloc, with_range=with_range)
+    except _io.EpilogosIOError as e:
+        if "malformed line" not in str(e):
+            raise
+        print("epilogos_amd: {} -- reading this file through pandas like the reference does (slow)".format(e), flush=True)
+        return _readTablePandas(path, rowsToCalc, alloc, with_range)
+
+
 def readTable(path, rowsToCalc=None, alloc=None, with_range=False, threads=0):
     """Rows [lo, hi) of a matrix file through the native multi-threaded parser: int8 0-based states
-    [rows, N] and the rows' first three columns as written (a _io.Locations).  With EPILOGOS_CACHE_DIR set (the command
+    [rows, N] and the rows' first three columns as written (a _io.Locations); a file the strict native parser refuses but pandas
+    reads (blank lines, blanks around numbers, "+1", "1.0") is read through pandas like the reference's (_readTablePandas).
+    With EPILOGOS_CACHE_DIR set (the command
     line's --cache-dir) the parsed file is kept as an int8 [R, N] .npy plus the coordinate side-car and later runs on the
     same input memory-map it instead of inflating and parsing ~1.7 KB of text per bin again.
     alloc(R, N) -> int8 [R, width >= N] supplies the destination (the driver's pinned, row-padded staging; columns >= N
@@ -68,12 +114,12 @@ def readTable(path, rowsToCalc=None, alloc=None, with_range=False, threads=0):
     threads = native threads for this one file (0 = all cores; the driver, which reads many files at once, gives each its share)."""
     cache = _cache_paths(path)
     if cache is None:
-        return _io.read_table(Path(path), rowsToCalc, threads=threads, alloc=alloc, with_range=with_range)
+        return _readTableNative(path, rowsToCalc, threads, alloc, with_range)
     if not all(c.exists() for c in cache):
         # first run on this input: parse, serve the caller from the arrays just parsed, and write the cache files BEHIND the
         # caller's back (a whole genome is 12.9 GB of them; written before the part was handed on they were a third of a cold
         # run).  The writer threads are ordinary (non-daemon) threads: the interpreter waits for them at exit.
-        states, loc, rng = _io.read_table(Path(path), None, threads=threads, with_range=True)
+        states, loc, rng = _readTableNative(path, None, threads, None, True)
         blob, offsets, rng_arr = loc.blob, loc.offsets, np.array(rng, dtype=np.int64)
         _save_cache_async(cache, (states, blob, offsets, rng_arr))
     else:

@@ -28,7 +28,7 @@
  *   - One host thread per device; calls on different devices/streams are independent.
  *
  * Limits of this build: 1 <= S <= 127 (states are int8; the tuned kernels serve 1..31 -- the reference's ChromHMM models have
- * 15, 18 and 25 -- and larger models take a generic, slow path; epg_null_hist and the modal-state S3 kernel stop at 31 / 19),
+ * 15, 18 and 25 -- and larger models take a generic, slow path; epg_null_hist stops at 31),
  * N <= 65535 (per-bin counts are stored as uint16).
  */
 #ifndef EPILOGOS_AMD_H
@@ -46,7 +46,12 @@ extern "C" {
 #define EPG_ERR_HIP (-3)
 #define EPG_ERR_WORKSPACE (-4)
 
-#define EPG_ABI_VERSION 1
+/* Bumped with EVERY change of this file's entry points or of what a workspace / table argument must hold; epilogos_amd/_abi.py
+ * reads the number from this header and refuses a library that reports another (a stale build behind EPILOGOS_HIP_LIB).
+ *   1  rounds 1-5 (entry points were added without a bump: fixed in 2)
+ *   2  round 6: epg_test_force switch 4 replaces the undeclared epg_debug_set_variant; epg_ws_bytes(3, ...) quotes operand chunks
+ *      of 2 M bins (1 M before); S3 score tables are correctly rounded float32 (the device's log2f before) */
+#define EPG_ABI_VERSION 2
 
 int epg_version(void);
 const char* epg_last_error(void);
@@ -159,8 +164,10 @@ int epg_score_s2(const int8_t* X, int64_t R, int32_t N, int64_t ldx, int32_t S, 
 int epg_score_s2_from_binhist(const uint16_t* H, int64_t R, int32_t N, int32_t S, int64_t perms, const float* q,
                               double* out64, float* out32, void* ws, int64_t ws_bytes, void* stream);
 
-/* S3: T = kl(float32(1)/(N*(N-1)), q) in float32; score[b, s] = sum_{c: X[b,c]==s} sum_{a != c} T[a,c,X[b,a],s]
- *     -- scores.py:455-506 s3Score (float64 accumulation here; see DESIGN.md for the tolerance). */
+/* S3: T = kl(float32(1)/(N*(N-1)), q) in float32 -- the quotient, the logarithm and the product each correctly rounded --;
+ *     score[b, s] = sum_{c: X[b,c]==s} sum_{a != c} T[a,c,X[b,a],s]  -- scores.py:455-506 s3Score.  The sum is exact (fixed-point
+ *     integers) where the reference adds 693 056 float32 terms in sequence: within 1e-6 of the float64 sum of numpy's table
+ *     (observed <= 2.1e-7), within 1e-4 / 5e-6 abs of the reference's own float32 rows. */
 int epg_score_s3(const int8_t* X, int64_t R, int32_t N, int64_t ldx, int32_t S, const float* q,
                  double* out64, float* out32, void* ws, int64_t ws_bytes, void* stream);
 
@@ -221,7 +228,8 @@ int epg_pair_count_null_parts(int32_t nparts, const int8_t* const* XA, const int
  * Several entry points have a fallback kernel that other shapes take; epg_test_force(which, value) makes the next calls take it
  * on any shape so that the tests can compare it with the default on theirs.  which: 0 = the column-by-column null sampler
  * (value 1), 1 = the bin-per-lane S3 score kernel (1), 2 = the S3 contraction (1 = over all S states, 2 = the reduced one
- * whatever the call's size), 3 = the LDS-counter S3 count kernel (1).  value 0 = the library decides (the default). */
+ * whatever the call's size), 3 = the LDS-counter S3 count kernel (1), 4 = blocks per CU of the count pass's persistent grid (value =
+ * the number; an A/B measurement switch, same results).  value 0 = the library decides (the default). */
 int epg_test_force(int32_t which, int32_t value);
 
 #ifdef __cplusplus

@@ -134,11 +134,20 @@ def score_s2(x, q, S, perms=None):
     return out
 
 
-def s3_table(q, N):
-    """scores.py:479-480 -- T = klScoreND(ones(float32)/(N*(N-1)), q) in float32."""
+def s3_table(q, N, correctly_rounded=False):
+    """scores.py:479-480 -- T = klScoreND(ones(float32)/(N*(N-1)), q) in float32, by numpy as the reference runs it.
+    correctly_rounded=True: the same float32 expression with every operation correctly rounded (quotient, log2 evaluated in
+    float64 and rounded once, product) -- what the device builds (csrc/epg_common.h s3_table_entry).  numpy's own float32 log2 is
+    a SIMD routine that is 1-2 ulp off that in a share of its arguments which depends on the host's CPU (tests/test_oracle_golden.py
+    puts a number on it); the two tables give scores that agree to < 1e-7."""
     q = np.asarray(q, dtype=np.float32)
     obs = (np.ones(q.shape, dtype=np.float32) / (N * (N - 1))).astype(np.float32)
-    return kl(obs, q).astype(np.float32)
+    if not correctly_rounded:
+        return kl(obs, q).astype(np.float32)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        ratio = np.where(q != 0, np.divide(obs, q), 0).astype(np.float32)
+        lg = np.where(ratio > 0, np.log2(np.where(ratio > 0, ratio, 1).astype(np.float64)), 0).astype(np.float32)
+    return (obs * lg).astype(np.float32)
 
 
 def score_s3_f32_sequential(x, q, S):
@@ -157,12 +166,12 @@ def score_s3_f32_sequential(x, q, S):
     return out
 
 
-def score_s3_f64(x, q, S):
+def score_s3_f64(x, q, S, correctly_rounded=False):
     """Closed form of scores.py:496-498 with a float64 accumulator: score[b, s] = sum_{beta: x_beta == s}
     sum_{alpha != beta} T[alpha, beta, x_alpha, s], T the float32 table promoted to float64."""
     x = np.asarray(x)
     R, N = x.shape
-    T = s3_table(q, N).astype(np.float64)
+    T = s3_table(q, N, correctly_rounded).astype(np.float64)
     a_idx, b_idx = np.nonzero(~np.eye(N, dtype=bool))
     out = np.zeros((R, S), dtype=np.float64)
     for r in range(R):

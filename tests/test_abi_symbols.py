@@ -40,7 +40,7 @@ def test_exports_are_c_abi(lib):
 
 
 def test_version_and_argument_validation_without_gpu(lib):
-    assert lib.epg_version() == 1
+    assert lib.epg_version() == _abi.ABI_VERSION == 2          # (the header's EPG_ABI_VERSION; bumped with every change of the ABI)
     # pure argument validation happens before any HIP call
     rc = lib.epg_bin_hist(None, -1, 10, 10, 18, None, None, None)
     assert rc == -1 and b"bad shape" in lib.epg_last_error()

@@ -234,7 +234,7 @@ from oracle import oracle_np as onp
 qo = onp.normalise(onp.expected_s3(x, S))
 assert np.array_equal(q, qo)
 ref = onp.score_s3_f64(x[:24], qo, S)
-np.testing.assert_allclose(sc[:24], ref, rtol=3e-6, atol=1e-6)
+np.testing.assert_allclose(sc[:24], ref, rtol=1e-6, atol=1e-6)
 print("S3_RCCL_OK", float(sc.sum()))
 dist.destroy_process_group()
 """ % str(root)

@@ -129,8 +129,8 @@ def test_s3_scores_n833(eng, case, oracle_counts):
     rows = np.array(sorted(rows))
     q = qd.cpu().numpy().reshape(N, N, S, S)
     ref = onp.score_s3_f64(x[rows], q, S)
-    np.testing.assert_allclose(o64.cpu().numpy()[rows], ref, rtol=2e-6, atol=1e-9)
-    np.testing.assert_allclose(o32.cpu().numpy()[rows], ref.astype(np.float32), rtol=3e-6, atol=1e-9)
+    np.testing.assert_allclose(o64.cpu().numpy()[rows], ref, rtol=1e-6, atol=1e-9)
+    np.testing.assert_allclose(o32.cpu().numpy()[rows], ref.astype(np.float32), rtol=1e-6, atol=1e-9)
     # a byte that is not a state adds nothing: the bin's total is that of its valid biosamples (checked against the oracle
     # on the matrix with that biosample's column dropped for the bin: same as removing its terms)
     r, cidx, _ = BAD[0]
@@ -140,7 +140,7 @@ def test_s3_scores_n833(eng, case, oracle_counts):
     T = onp.s3_table(q, N).astype(np.float64)
     want = np.zeros(S)
     np.add.at(want, xr[b_idx[keep]], T[a_idx[keep], b_idx[keep], xr[a_idx[keep]], xr[b_idx[keep]]])
-    np.testing.assert_allclose(o64.cpu().numpy()[r], want, rtol=2e-6, atol=1e-9)
+    np.testing.assert_allclose(o64.cpu().numpy()[r], want, rtol=1e-6, atol=1e-9)
 
 
 def test_s3_score_two_kernels_agree(eng, case, oracle_counts, monkeypatch):

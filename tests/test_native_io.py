@@ -552,3 +552,49 @@ def test_host_budget_reaches_the_library_through_the_setter(monkeypatch):
         lib.epgio_set_host_threads(0)
         assert lib.epgio_default_threads() >= 1
         _io.host_budget()
+
+
+def test_lenient_inputs_are_read_like_the_reference_reads_them(tmp_path, capsys):
+    """Inputs pandas reads and the strict native parser refuses -- a blank line inside the file, blanks around a number, "+1",
+    "1.0" -- must give the arrays the REFERENCE's helpers.readStates gives (helpers.py:152-155: pandas.read_table), and the
+    locations it would print (scores.py:161,526-531): helpers.readTable re-reads such a file through pandas and says so.  The
+    expected arrays were produced by the real reference (tests/golden/make_golden_lenient.py)."""
+    from tests.conftest import load_golden
+    g = load_golden("lenient.npz")
+    names = sorted(k[:-5] for k in g if k.endswith("_text"))
+    assert {"blank_line", "blanks_around", "plus_sign", "float_state", "all_together", "crlf"} <= set(names)
+    for name in names:
+        f = tmp_path / (name + ".txt")
+        f.write_bytes(g[name + "_text"].tobytes())
+        want = g[name + "_states"]
+        strict_ok = True
+        try:
+            _io.read_table(f)
+        except _io.EpilogosIOError as e:
+            strict_ok = False
+            assert "malformed line" in str(e)
+        assert strict_ok == (name == "crlf")                       # (CRLF line ends are read natively)
+        st, loc = helpers.readTable(f)
+        assert st.dtype == np.int8 and np.array_equal(st, want), name
+        assert loc.blob.tobytes().decode().splitlines() == list(g[name + "_loc"]), name
+        assert ("through pandas" in capsys.readouterr().out) == (not strict_ok)
+        # a row range, a caller-owned padded destination and the file's value range, as the driver asks for them
+        R = want.shape[0]
+        got = {}
+
+        def alloc(r, n):
+            got["buf"] = np.full((r, 16), 99, dtype=np.int8)
+            return got["buf"]
+        st2, loc2 = helpers.readTable(f, (1, R), alloc=alloc)
+        assert st2 is got["buf"] and np.array_equal(st2[:, :want.shape[1]], want[1:]) and (st2[:, want.shape[1]:] == -1).all()
+        assert len(loc2) == R - 1
+        assert helpers.readTable(f, with_range=True)[2] == (int(want.min()) + 1, int(want.max()) + 1)
+        assert np.array_equal(helpers.readStates(f, rowsToCalc=(0, int(g[name + "_countRows"]))), want)
+        capsys.readouterr()
+    # what pandas cannot turn into integers raises, as it does in the reference
+    (tmp_path / "alpha.txt").write_text("chr1\t0\t200\t1\tx\nchr1\t200\t400\t1\t2\n")
+    with pytest.raises(ValueError):
+        helpers.readTable(tmp_path / "alpha.txt")
+    (tmp_path / "short.txt").write_text("chr1\t0\t200\t1\t2\nchr1\t200\t400\t1\n")
+    with pytest.raises(ValueError):
+        helpers.readTable(tmp_path / "short.txt")

@@ -24,7 +24,7 @@ a = ap.parse_args()
 
 engine.require_gpu()
 lib = _abi.load()
-lib.epg_debug_set_variant.argtypes = [ctypes.c_int, ctypes.c_int]
+lib.epg_test_force.argtypes = [ctypes.c_int32, ctypes.c_int32]
 N, S, R = a.biosamples, 18, a.bins
 if a.packed:
     flat = torch.empty(R * N + 64, dtype=torch.int8, device="cuda")
@@ -49,7 +49,7 @@ res = {}
 for rnd in range(a.rounds + 1):
     for cfg in a.configs:
         v, bpc = [int(t) for t in cfg.split(":")]
-        lib.epg_debug_set_variant(v, bpc)
+        lib.epg_test_force(4, bpc)
         if "hist" in a.what:
             counts.zero_()
             t = timed(lambda: engine.bin_hist(X, N, S, counts=counts, H=H))

@@ -13,7 +13,7 @@ for spec in sys.argv[1:]:
             else:
                 env[k] = v
     r = subprocess.run([sys.executable, R + "/bench.py", "--no-cpu-baseline", "--configs", "s3_small", "--dist-variants", "0", "--graph-leg", "0", "--placement-experiment", "0",
-                        "--shard-bins", "0", "--steps", "2", "--warmup", "1", "--config-reps", "3"], env=env, capture_output=True, text=True)
+                        "--shard-bins", "0", "--steps", "2", "--warmup", "1", "--config-reps", "3", "--s3-small-bins", os.environ.get("S3_AB_BINS", "2000000")], env=env, capture_output=True, text=True)
     try:
         p = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])["configs"]["s3_small"]
         print("%-40s job %.2f ms  phases %s" % (spec, p["job_ms"], p["phases_ms"]), flush=True)
