@@ -29,10 +29,13 @@ of launches), each with its own roofline figure:
     "paired" paired S1 on 379 + 342 biosamples: two count passes, all-reduce, the hypergeometric null groups, then scores of
              the four groups, deltas, null distances and STEP 4's per-bin reduction in one pass, and the quiescence mask.
     "s3" is the whole 15 M-bin genome (one repetition), "s3_small" the 2 M-bin job of earlier rounds.
-`--configs none` skips them.  The headline step is the product's: a fresh backend._HipSingleSession per job, whose add_device puts
-the histogram cache of a resident matrix into another memory class than the matrix (engine.alloc_hist, DESIGN.md 3: a one-off
-probe per process, reported as `placement.report`); the same jobs with a plain allocation (add_device(place=False)) are timed
-after the timed region and reported as `placement.unplaced`.  After the headline: the same step as ONE hipGraph replay
+`--configs none` skips them.  The headline step is the product's: a fresh backend._HipSingleSession per job, add_device(X, N) with
+the default the command line's add_part runs under -- the histogram cache of a resident matrix of a GiB or more goes into another
+memory class than the matrix (engine.alloc_hist, DESIGN.md 3: a bounded one-off walk per process, `placement.report`,
+`placement.search_ms`), smaller matrices (the command line's chromosome parts) get plain allocations; the same jobs with a plain
+allocation (add_device(place=False)) are timed after the timed region and reported as `placement.unplaced` -- the command-line
+equivalent figure for a genome held as 24 parts.  `projected_speedup_8`: genome step / (step of an eighth + a measured one-rank RCCL
+all-reduce), the prediction the first real 8-GPU run is to be held against.  After the headline: the same step as ONE hipGraph replay
 (`graph_ms_per_step`), an RCCL self-test when there is a process group (`rccl_selftest`), the distribution variants of SURVEY.md
 8d (`dist_variants`).  A secondary measurement that hangs ends the run with exit code 3 AFTER the line has been printed.
 """
@@ -560,6 +563,7 @@ def main():
                          "engine = the bare ABI calls on preallocated buffers (always used by --graph)")
     ap.add_argument("--shard-bins", type=int, default=1_875_000, help="one GPU: both paths are also timed on a shard of this "
                                                                         "many bins (an eighth of the genome: the 8-GPU share); 0 = skip")
+    ap.add_argument("--allreduce-leg", type=int, default=1, help="one GPU without --pg: join a one-rank RCCL group AFTER the timed region to time the count vector's all-reduce (for projected_speedup_8); 0 = skip")
     ap.add_argument("--pg", action="store_true", help="one GPU: still join a one-rank RCCL process group, so that the step contains the all-reduce")
     ap.add_argument("--placement-experiment", type=int, default=1, help="0: skip the jobs with an unplaced histogram cache after the timed region")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to test the "
@@ -664,10 +668,12 @@ def main():
         if e is not None:
             e[3].record()
 
-    def step_session(Xs, e=None, place=True, finish=False):
-        """One whole S1 job through the product's session: a fresh session per job, the histogram cache (placed by
-        engine.alloc_hist: the device's home block, found by the first job of the process), the count vector, the tables and the
-        scores allocated by the session (torch's caching allocator hands the previous job's blocks back)."""
+    def step_session(Xs, e=None, place=None, finish=False):
+        """One whole S1 job through the product's session: a fresh session per job; add_device with ITS default (place=None: the
+        rule the command line's add_part runs under -- engine.alloc_hist places the histogram cache of a matrix of a GiB or more in
+        the device's home block, found by the first job of the process; place=False is the comparison with a plain allocation),
+        the count vector, the tables and the scores allocated by the session (torch's caching allocator hands the previous job's
+        blocks back)."""
         last.clear()                                                       # (the previous job's session and scores are released first)
         sess = be.open_single(S, 1)
         if e is not None:
@@ -694,7 +700,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def timed_steps(Xs, Hs, outs, steps, warmup, graph=False, events=True, session=False, place=True, finish=False):
+    def timed_steps(Xs, Hs, outs, steps, warmup, graph=False, events=True, session=False, place=None, finish=False):
         """-> (wall seconds of `steps` steps, per-step event tuples or [], host enqueue times, this rank's own seconds:
         from the common start to the moment ITS last step was over, before the closing barrier)."""
         ev = [tuple(torch.cuda.Event(enable_timing=True) for _ in range(4)) for _ in range(steps)] if (events and not graph) else []
@@ -857,8 +863,9 @@ def main():
     # configs 3-5) fills `placement` and `configs` in.  A watchdog on every rank bounds those extras: past --extras-deadline
     # seconds rank 0 prints the line with what it has and every rank leaves, so that a collective that never completes in a
     # secondary measurement cannot take the headline of a multi-GPU run with it.
-    placement = {"headline": ("a fresh backend._HipSingleSession per step; add_device takes the histogram cache of the resident matrix from "
-                              "engine.alloc_hist (another memory class than the matrix; found once per process, during the warm-up)"
+    placement = {"headline": ("a fresh backend._HipSingleSession per step; add_device's default hands the histogram cache of a resident matrix "
+                              "of >= 1 GiB to engine.alloc_hist (another memory class than the matrix: a bounded walk over <= 8 blocks of 4 GiB, a "
+                              "relative decision, found once per process during the warm-up; `report` is what it did, `search_ms` its wall time)"
                               if use_session else "bare ABI calls on preallocated plain torch allocations (--path engine / --graph)")}
     configs = {}
     line = None
@@ -892,8 +899,12 @@ def main():
                        "state_distribution": args.dist,
                        "row_pitch_bytes": int(X.stride(0)),
                        "step_launch": "hipGraph replay" if args.graph else "three launches + collective per step",
-                       "step_path": ("session: add_device -> all_reduce -> launch, the sequence driver.run_single runs; its finish() (count check, "
-                                     "table verification, exp_freq download: a host sync) runs once after the timed steps -- "
+                       "step_path": ("backend._HipSingleSession: add_device(X, N) -> all_reduce -> launch -- the calls driver.run_single makes "
+                                     "(its add_part is an upload followed by this same add_device(X, N), same default: engine.alloc_hist places the "
+                                     "histogram cache of a resident matrix of >= 1 GiB, smaller ones get a plain allocation).  Here the genome is ONE "
+                                     "resident 12.7 GB matrix, so its cache is placed; the command line holds it as one part per chromosome file "
+                                     "(< 1 GiB each at 833 columns), i.e. plain allocations: `placement.unplaced` is the step with those.  The session's "
+                                     "finish() (count check, table verification, exp_freq download: a host sync) runs once after the timed steps -- "
                                      "s1_paths.session_with_finish_ms_per_step has it inside every job") if use_session else "engine",
                        "partition": "contiguous bin ranges per GPU (helpers.splitRows rule), one RCCL all-reduce of int64[%d]" % S},
             "roofline": {"bound": "hbm", "kernel": "k_bin_hist", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
@@ -965,16 +976,19 @@ def main():
 
     # ---- secondary: the same jobs with the histogram cache where a plain allocation puts it (add_device(place=False))
     placement["report"] = engine.placement_report(dev)
+    if placement["report"]:
+        placement["search_ms"] = placement["report"].get("search_ms")
+        placement["left_in_torch_cache_GiB"] = placement["report"].get("left_in_torch_cache_GiB")
     if args.placement_experiment and world == 1 and R * X.stride(0) >= (1 << 30) and not args.packed and use_session:
         hang_hook("unplaced")
         try:
             kk = min(args.steps, 10)
             dtp, evp, _, _ = timed_steps(X, None, None, kk, 2, session=True, place=False)
             k1p = float(np.mean([e[0].elapsed_time(e[1]) for e in evp]))
-            placement["unplaced"] = {"what": "the same jobs, histogram cache from a plain allocation (add_device(place=False): what "
-                                             "add_part's streamed parts get, and every job before round 5)", "steps": kk,
+            placement["unplaced"] = {"what": "the same jobs, histogram cache from a plain allocation (add_device(place=False): what the command "
+                                             "line's < 1 GiB chromosome parts get under the default rule, and every job before round 5)", "steps": kk,
                                      "k_bin_hist_ms": round(k1p, 4), "frac": round(R * N / (k1p * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
-                                     "ms_per_step": round(dtp / kk * 1e3, 4)}
+                                     "ms_per_step": round(dtp / kk * 1e3, 4), "value": round(R_global * kk / dtp / 1e6, 3), "unit": "Mbins/s"}
             last.clear()
         except Exception as e:                 # an experiment: never let it take the measurement down
             placement["unplaced"] = {"failed": repr(e)[:200]}
@@ -1058,6 +1072,47 @@ def main():
             if line is not None:
                 line["graph_ms_per_step"] = None
                 line["graph_error"] = repr(e)[:300]
+
+    # ---- a prediction for the first real 8-GPU run to be held against (one GPU only): the genome step over the step of one
+    # GPU's share of it plus the device time of an RCCL all-reduce of the count vector -- measured here in a ONE-rank group (the
+    # collective's launch and kernel; the xGMI hops of seven more ranks are NOT in it) --; rank skew is not in it either
+    if world == 1 and line is not None and s1_paths and any(k.startswith("shard_") for k in s1_paths):
+        hang_hook("projected_speedup")
+        try:
+            ar_us, ar_src = None, None
+            if allreduce_probe is not None:
+                ar_us, ar_src = allreduce_probe["device_us_per_call_back_to_back"], "this run's one-rank group (--pg)"
+            elif args.allreduce_leg:
+                os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+                os.environ.setdefault("MASTER_PORT", str(29500 + os.getpid() % 2000))
+                os.environ.setdefault("RANK", "0")
+                os.environ.setdefault("WORLD_SIZE", "1")
+                import datetime
+                dist.init_process_group(backend="nccl", device_id=dev, timeout=datetime.timedelta(seconds=120))
+                t = torch.zeros(S, dtype=torch.int64, device=dev)
+                for _ in range(20):
+                    dist.all_reduce(t)
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(200):
+                    dist.all_reduce(t)
+                e1.record()
+                torch.cuda.synchronize()
+                ar_us, ar_src = round(e0.elapsed_time(e1) / 200 * 1e3, 2), "a one-rank RCCL group joined after the timed region"
+                dist.destroy_process_group()
+            gk = [k for k in s1_paths if k.startswith("genome_")][0]
+            sk = [k for k in s1_paths if k.startswith("shard_")][0]
+            g_ms, s_ms = s1_paths[gk]["session_ms_per_step"], s1_paths[sk]["session_ms_per_step"]
+            line["projected_speedup_8"] = {
+                "value": round(g_ms / (s_ms + (ar_us or 0.0) / 1e3), 2), "genome_step_ms": g_ms, "shard_step_ms": s_ms,
+                "shard_bins": int(sk.split("_")[1]), "allreduce_us": ar_us, "allreduce_source": ar_src,
+                "shard_k_bin_hist_frac": round(int(sk.split("_")[1]) * N / (s1_paths[sk]["session_k_bin_hist_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                "shard_after_k_bin_hist_us": round((s_ms - s1_paths[sk]["session_k_bin_hist_ms"]) * 1e3, 1),
+                "what": "genome step / (step of one of 8 shards + one all-reduce of int64[%d]), all on this one GPU: what the 8-GPU run can "
+                        "reach before rank skew and the hops of a real 8-rank ring; north_star asks for >= 6" % S}
+        except Exception as e:
+            line["projected_speedup_8"] = {"error": repr(e)[:300]}
 
     if watchdog is not None:
         watchdog.cancel()

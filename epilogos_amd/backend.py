@@ -359,23 +359,27 @@ class _HipSession:
 
 class _HipSingleSession(_HipSession):
     def add_part(self, arr, N, ticket):
-        return self.add_device(self._upload(arr, N, ticket), N, place=False)
+        return self.add_device(self._upload(arr, N, ticket), N)
 
-    def add_device(self, X, N, place=True):
-        """Count pass over a RESIDENT part (bench.py and library callers enter here; add_part does after its upload).  place:
-        the histogram cache of a matrix of a GiB or more goes where engine.alloc_hist finds another memory class than the
-        matrix's (a process-lifetime home, one ~5 ms probe per device); add_part's matrices are staging copies of one file each
-        that come and go with their upload -- their histograms are plain allocations."""
+    def add_device(self, X, N, place=None):
+        """Count pass over a RESIDENT part -- the ONE entry of the command line (add_part, after its upload), of bench.py and of
+        library callers.  place=None (everybody's default): engine.alloc_hist decides -- the histogram cache of a matrix of a GiB
+        or more goes where its search finds another memory class than the matrix's (a process-lifetime home block, one bounded
+        probe per device), anything smaller gets a plain allocation, and so does everything when placement is off
+        (engine.placement_enabled: EPILOGOS_PLACEMENT=0, ranks sharing a GPU).  The command line's parts are one chromosome file
+        each -- under a GiB up to ~880 columns -- so a whole-genome run of the reference's shape counts with plain allocations
+        (bench.py reports that figure as placement.unplaced; its count passes hide under the parse anyway) while a caller that holds
+        the genome as one matrix gets the placed cache.  place=False forces a plain allocation (bench.py's comparison)."""
         eng, S = self.eng, self.S
         self.N = max(getattr(self, "N", 0) or 0, N or 0)  # (an empty file has no width)
         if X.shape[0] == 0 or not N:                     # an empty part: nothing to count, and the ABI rejects a zero width
             self.parts.append(self.torch.empty((0, S), dtype=self.torch.int16, device=self.device) if self.sal < 3 else X)
             return len(self.parts) - 1
         if self.sal == 1:
-            H, _ = eng.bin_hist(X, N, S, counts=self._acc(S), H=eng.alloc_hist(X, N, S) if place else None)
+            H, _ = eng.bin_hist(X, N, S, counts=self._acc(S), H=eng.alloc_hist(X, N, S) if place is not False else None)
             self.parts.append(H)
         elif self.sal == 2:                              # the count pass with the pair counts folded in: one launch
-            H, _ = eng.bin_hist_s2(X, N, S, counts2=self._acc(S * S), H=eng.alloc_hist(X, N, S) if place else None)
+            H, _ = eng.bin_hist_s2(X, N, S, counts2=self._acc(S * S), H=eng.alloc_hist(X, N, S) if place is not False else None)
             self.parts.append(H)
         elif self.sal == 3:
             # the ~8 GB workspace of the matrix-core contraction is allocated once per session and grows to the largest

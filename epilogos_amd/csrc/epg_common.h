@@ -48,6 +48,24 @@ extern int g_force[FORCE_COUNT];
 
 static inline int64_t align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) of a kernel that wants more than 64 KB of dynamic LDS: once per kernel AND
+// device, safe when two host threads meet at a kernel's first launch (round 5 kept a plain `static bool` per call site: a second
+// device, or a second thread that saw the flag before the first had made the call, launched without the attribute).  One
+// DynLds object (static, at the call site) per kernel; a bit per device; setting the attribute twice is harmless.
+struct DynLds {
+    unsigned long long done = 0;
+};
+static inline hipError_t ensure_dyn_lds(DynLds& a, const void* kernel, int bytes) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (__atomic_load_n(&a.done, __ATOMIC_ACQUIRE) & bit) return hipSuccess;
+    e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess) __atomic_fetch_or(&a.done, bit, __ATOMIC_RELEASE);
+    return e;
+}
+
 // Rows a wave stages per turn in the kernels that keep whole rows of a wave's tile in LDS (four waves per block, 64 KB of LDS
 // without asking): 64 for the state models the kernels were built for, 32 / 16 / 8 when `row_bytes` (all staged arrays of a
 // row together) grows with a wide model.  A multiple of 8, so that a tile of uint16 or float32 rows starts 16-byte aligned.

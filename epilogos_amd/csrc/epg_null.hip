@@ -641,20 +641,14 @@ int null_hist_parts_impl(int32_t nparts, const uint16_t* const* HA, const uint16
         const bool seq = g_force[FORCE_NULL_SEQ] != 0;          // (tests: the column-by-column kernel on shapes that fit the bit strings)
         if (!seq && !full && 2 * bits_bytes <= 24 * 1024) {     // -g: two thresholds, two bit strings
             const size_t shmem = 4 * ((size_t)2 * TR * 2 * S + 2 * bits_bytes);
-            static bool attr2_set = false;
-            if (!attr2_set) {
-                EPG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_null_hist_h2), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-                attr2_set = true;
-            }
+            static DynLds lds_attr2;
+            EPG_HIP(ensure_dyn_lds(lds_attr2, reinterpret_cast<const void*>(k_null_hist_h2), 160 * 1024));
             hipLaunchKernelGGL(k_null_hist_h2, dim3((unsigned)blocks), dim3(256), shmem, st, pt, S, n_cols, ga, gb, (u64)seed, TR, NW);
             EPG_LAUNCH_CHECK("k_null_hist_h2");
         } else if (!seq && full && bits_bytes <= 24 * 1024) {
             const size_t shmem = 4 * ((size_t)2 * TR * 2 * S + bits_bytes);
-            static bool attr_set = false;
-            if (!attr_set) {
-                EPG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_null_hist_h), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-                attr_set = true;
-            }
+            static DynLds lds_attr;
+            EPG_HIP(ensure_dyn_lds(lds_attr, reinterpret_cast<const void*>(k_null_hist_h), 160 * 1024));
             hipLaunchKernelGGL(k_null_hist_h, dim3((unsigned)blocks), dim3(256), shmem, st, pt, S, n_cols, ga, gb, (u64)seed, TR, NW);
             EPG_LAUNCH_CHECK("k_null_hist_h");
         } else {
@@ -845,12 +839,8 @@ template <int S, int NG>
 static int launch_pair_count_null(const PcParts& pt, int NA, int NB, u64* counts, u64 seed, hipStream_t st) {
     const int NW = (NA + NB + 31) / 32;
     const size_t shmem = 4 * ((size_t)2 * 64 * 2 * S + (size_t)NW * 256);
-    static bool attr_set = false;
-    if (!attr_set) {
-        EPG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pair_count_null<S, NG>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    160 * 1024 - 1024));     // (the kernel also holds a small static array)
-        attr_set = true;
-    }
+    static DynLds lds_attr;                                  // (one per <S, NG> instantiation)
+    EPG_HIP(ensure_dyn_lds(lds_attr, reinterpret_cast<const void*>(k_pair_count_null<S, NG>), 160 * 1024 - 1024));   // (the kernel also holds a small static array)
     long blocks = (pt.t0[pt.n] + 3) / 4;
     const long per_cu = (long)((160 * 1024 - 1024) / shmem);
     const long cap = num_cus() * (per_cu < 1 ? 1 : per_cu);

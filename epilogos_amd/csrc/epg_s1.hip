@@ -679,11 +679,8 @@ static int launch_score_s1_from_hist_t(const uint16_t* H, long total, int32_t S,
         if (nb > (long)num_cus() * per_cu) nb = (long)num_cus() * per_cu;
         if (nb < 1) nb = 1;
         auto kern = k_score_s1_from_hist<OT, true>;
-        static bool attr_set = false;                  // one flag per OT instantiation
-        if (!attr_set) {
-            EPG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-            attr_set = true;
-        }
+        static DynLds lds_attr;                        // one per OT instantiation
+        EPG_HIP(ensure_dyn_lds(lds_attr, reinterpret_cast<const void*>(kern), 150 * 1024));
         hipLaunchKernelGGL(kern, dim3((int)nb), dim3(1024), tbytes, st, H, total, S, T, nent, out, zero_counts, rev);
     } else {
         long nb = (total / 4 + 1023) / 1024;

@@ -785,11 +785,8 @@ int pair_scores_s1_parts_impl(int32_t nparts, const uint16_t* const* HA, const u
     const size_t shmem = tab + (size_t)waves * per_wave;
 #define PF_LAUNCH(SC)                                                                                                            \
     do {                                                                                                                         \
-        static bool attr_set = false;                                                                                            \
-        if (!attr_set) {                                                                                                         \
-            EPG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pair_fused_s1<SC>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
-            attr_set = true;                                                                                                     \
-        }                                                                                                                        \
+        static DynLds lds_attr;                                                                                                  \
+        EPG_HIP(ensure_dyn_lds(lds_attr, reinterpret_cast<const void*>(k_pair_fused_s1<SC>), 160 * 1024));                       \
         hipLaunchKernelGGL(k_pair_fused_s1<SC>, dim3((unsigned)blocks), dim3(64 * waves), shmem, st, pt, S, TA, entA, TB, entB, TnA, entnA, \
                            TnB, entnB, NA, NB, qstate);                                                                          \
     } while (0)

@@ -480,18 +480,14 @@ int hist_s3_gemm(const char* X, int64_t R, int32_t N, int64_t ldx, int32_t S, in
     char* XT = reinterpret_cast<char*>(ws);
     int* tasks = reinterpret_cast<int*>(XT + align_up((int64_t)N * Rp + 64, 1024));
     char* E4 = reinterpret_cast<char*>(tasks) + align_up((int64_t)ntasks * 4, 1024);
-    static bool attr_set = false;
     if (dbg_env & 4) {
         int nblk = -1;
         (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nblk, reinterpret_cast<const void*>(k_s3_syrk_fp4<G_RING_DEFAULT>), 64 * G_NW,
                                                      g_lds_bytes(G_RING_DEFAULT));
         fprintf(stderr, "k_s3_syrk_fp4: %d workgroups of %d threads per CU with %d bytes of LDS\n", nblk, 64 * G_NW, g_lds_bytes(G_RING_DEFAULT));
     }
-    if (!attr_set) {
-        EPG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_s3_syrk_fp4<G_RING_DEFAULT>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    g_lds_bytes(G_RING_DEFAULT)));
-        attr_set = true;
-    }
+    static DynLds lds_attr;
+    EPG_HIP(ensure_dyn_lds(lds_attr, reinterpret_cast<const void*>(k_s3_syrk_fp4<G_RING_DEFAULT>), g_lds_bytes(G_RING_DEFAULT)));
     // chunk = as many bins of the operand as the caller's workspace holds (every chunk ends in one epilogue of ~2 atomics
     // per cell of counts, so fewer, longer chunks are better); EPG_S3_KC overrides for measurements
     static const long kc_env = [] { const char* e = exp_env("EPG_S3_KC"); return e ? atol(e) / 512 * 512 : 0L; }();   // (experiments build only)

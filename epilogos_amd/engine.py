@@ -41,18 +41,19 @@ def alloc_states(R, N, device="cuda"):
 
 # ---- where the histogram cache of a RESIDENT matrix goes
 PLACE_MIN_BYTES = 1 << 30           # a matrix under 1 GiB is counted in < 0.2 ms: not worth a probe
-PLACE_GOOD = 1.11                   # K1 with the H store / K1 counts only: <= this = "H is in another memory class than X" (measured:
-                                    # 1.05-1.105 in another class, 1.14-1.19 in the same, 1.118 with X straddling two classes)
-PLACE_GOOD_WHOLE = 1.125            # the same ratio over the WHOLE matrix (2.24-2.27 / 2.02-2.03 ms = 1.10-1.12 in another class; 1.14-1.20
-                                    # with the matrix straddling classes the slices missed -- one accepted at 1.136 ran K1 at 2.37 ms --;
-                                    # 1.27-1.3 in the same class)
 PLACE_BLOCK = 4 << 30               # candidates are the heads of blocks of this size (see alloc_hist)
-PLACE_TRIES = 24                    # a class is at most a third of the memory in one run (96 GB): 24 blocks and the matrix walk out of it
-_placement = {}                     # device index -> {"key", "home", "report"}
+PLACE_TRIES = 8                     # at most this many blocks (32 GiB) are walked ...
+PLACE_BUDGET_MS = 50.0              # ... and at most this much device time is spent on probes
+PLACE_GAP = 0.03                    # two levels of the probe's ratio are "two memory classes" when they lie >= 3 % apart
+PLACE_SURE = 1.10                   # K1 with the H store / K1 counts only at or under this: the store lands in another class, no
+                                    # contrast needed (every block ever measured in the matrix's own class: >= 1.136; in another: 1.05-1.105)
+PLACE_CONFIRM = 0.05                # the pick's ratio over the WHOLE matrix may exceed its ratio on the slices by this much (a matrix in
+                                    # one class: +0.02-0.03; one that straddles a class boundary between the slices: +0.07-0.10)
+_placement = {}                     # device index -> {"key", "home", "report", "stream"}
 
 
 def _storage_users(t):
-    """Tensors (views included) alive on t's storage, or None when this torch cannot tell."""
+    """Tensors (views included) alive on t's storage, or None when this torch cannot tell (placement is then off)."""
     f = getattr(torch._C, "_storage_Use_Count", None)
     if f is None:
         return None
@@ -69,7 +70,7 @@ def _probe_slices(R, rows=1 << 20):
     return [(0, m), ((R - m) // 2 // 32 * 32, (R - m) // 2 // 32 * 32 + m), ((R - m) // 32 * 32, (R - m) // 32 * 32 + m)]
 
 
-def _probe_ms(X, N, S, Hflat, counts, slices, reps=3):
+def _probe_ms(X, N, S, Hflat, counts, slices, reps=2):
     """Device time of k_bin_hist over `slices` of X, histogram rows into the same rows of the candidate `Hflat` (None = counts
     only); one untimed pass first."""
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
@@ -84,33 +85,88 @@ def _probe_ms(X, N, S, Hflat, counts, slices, reps=3):
     return ev[0].elapsed_time(ev[1]) / reps
 
 
+def place_decide(ratios, excluded=(), gap=PLACE_GAP, sure=PLACE_SURE):
+    """The placement decision from the candidates' slice ratios alone (host logic; tests/test_host_logic.py plays sequences
+    through it).  -> (index of the pick or None, verdict):
+      "sure"         the lowest ratio is <= `sure`: its store lands in another class than the matrix whatever the others say;
+      "two-levels"   the sorted ratios split into two groups at a RELATIVE step >= `gap` (the largest step counts): the groups are
+                     two memory classes as this process sees them now -- no absolute level involved -- and the pick is the lowest
+                     of the lower group;
+      "one-level"    no such step: every candidate lies in one class (the matrix's or another: the probe cannot say) -- the pick
+                     is the lowest, and the caller may walk on.
+    `excluded`: candidates already found to straddle (confirmation failed) -- never picked, still part of the picture."""
+    live = [i for i in range(len(ratios)) if i not in set(excluded)]
+    if not live:
+        return None, "none"
+    order = sorted(live, key=lambda i: ratios[i])
+    best = order[0]
+    if ratios[best] <= sure:
+        return best, "sure"
+    allo = sorted(range(len(ratios)), key=lambda i: ratios[i])
+    steps = [(ratios[allo[k + 1]] / ratios[allo[k]] - 1.0, k) for k in range(len(allo) - 1)]
+    if steps:
+        step, k = max(steps)
+        if step >= gap:
+            lower = [i for i in allo[:k + 1] if i not in set(excluded)]
+            if lower:
+                return lower[0], "two-levels"
+    return best, "one-level"
+
+
+def placement_enabled():
+    """Off with EPILOGOS_PLACEMENT=0, when this torch cannot count a storage's users, and when the launcher put more ranks on the
+    node than it has devices (ranks sharing a GPU -- run.py's gloo mode, tests -- must not each hold a home block and a cache of
+    probe blocks)."""
+    import os
+    if os.environ.get("EPILOGOS_PLACEMENT", "1") == "0" or getattr(torch._C, "_storage_Use_Count", None) is None:
+        return False
+    try:
+        lws = int(os.environ.get("LOCAL_WORLD_SIZE", "1"))
+    except ValueError:
+        lws = 1
+    return lws <= max(torch.cuda.device_count(), 1)
+
+
+def _order_after_last_user(st):
+    """The home is handed out again: whatever the previous holder enqueued on ITS stream must be over before this one's kernels
+    write the block.  The views bypass torch's caching allocator, which would do this for an ordinary tensor: an event on the
+    previous holder's stream, awaited by the current one (nothing when they are the same stream)."""
+    prev, cur = st.get("stream"), torch.cuda.current_stream()
+    if prev is not None and prev != cur:
+        ev = torch.cuda.Event()
+        ev.record(prev)
+        cur.wait_event(ev)
+    st["stream"] = cur
+
+
 def alloc_hist(X, N, S):
     """The [R, S] uint16 histogram cache (int16 storage) for a RESIDENT state matrix X, in another memory CLASS than X.
 
-    The 288 GB of an MI355X fall into three classes of a third each, in contiguous runs of 4-64 GiB of the driver's
+    The 288 GB of an MI355X fall into three classes of a third each, in contiguous runs of 4-96 GiB of the driver's
     allocation order (profiles/r02ae_k1_memory_class_map.txt).  k_bin_hist reads X and writes H: with both in one class the
     launch is 13-17 % slower (2.6 against 2.3 ms for 15 M x 833) whatever the offsets, the data or the other buffers are.  HIP
     does not tell the class of an allocation, so the classifier is the kernel itself, on three 1 M-bin slices of X (head,
-    middle, tail: 0.5 ms per pass): a candidate is good when the launches with the H store cost < 11 % over the counts-only
-    launches (measured: 1.06-1.10 in another class, 1.14-1.18 in the same, profiles/r05a_placement_spread.txt).
-    Candidates are the HEADS OF 4 GiB BLOCKS allocated one after the other and held during the search: the driver serves a
-    small allocation from the smallest free fragment that fits -- the crumbs the matrix's own allocation left behind, i.e.
-    next to the matrix whatever else is held (first version of this search: four H-sized candidates behind 8 / 16 / 32 GiB
-    spacers, all four in the matrix's class in two processes of six) -- while 4 GiB blocks make it walk through its memory.
-    The first good block becomes the HOME of this device's histogram caches for the life of the process (H is a view of its
-    head): every later job on the same matrix gets it without a probe, a job on another matrix after one probe (~2 ms).  The
-    blocks that were not picked go to torch's caching allocator the moment the search is over, from where the job's other
-    buffers are carved: nothing is returned to the driver (freed device memory is scrubbed in the background at every
-    HBM-bound kernel's expense), nothing is withheld from the process but the home block.
-    While a view of the home is alive (another session still holds its parts) the next request gets a plain allocation.
-    EPILOGOS_PLACEMENT=0 switches the search off; EPILOGOS_PLACEMENT_TRIES bounds it (default 24 blocks: a run of one class is at
-    most 16 blocks long)."""
-    import os
+    middle, tail): ratio = launches with the H store into the candidate / counts-only launches.
+    Candidates are the HEADS OF 4 GiB BLOCKS allocated one after the other and held during the search (an H-sized allocation
+    comes from the crumbs next to the matrix; 4 GiB blocks make the driver walk through its memory).  The walk is BOUNDED --
+    PLACE_TRIES blocks, PLACE_BUDGET_MS of probe time, a quarter of the free memory -- and the decision is place_decide's: a
+    candidate at or under PLACE_SURE ends the walk at once; otherwise the walk goes on until the ratios show two levels >= 3 %
+    apart (pick: the lowest of the lower level) or the bounds are reached (pick: the lowest -- never worse than the plain
+    allocation this replaces, which lies next to the matrix).  The pick is confirmed ONCE over the whole matrix (the slices cover
+    a fifth of it and can miss a class boundary inside it): a whole-matrix ratio more than PLACE_CONFIRM above the slices' means
+    the matrix straddles there, and the next pick is confirmed instead.
+    The picked block is the device's HOME for the life of the process (H is a view of its head): later jobs on the same matrix
+    get it without a probe, a job on another matrix after one probe.  The other blocks go back to torch's caching allocator
+    (not to the driver: freed device memory is scrubbed in the background at every HBM-bound kernel's expense); the report says
+    how much.  While a view of the home is alive the next request gets a plain allocation; a hand-out on another stream than
+    the previous one waits for that stream (_order_after_last_user).  release_placement() gives the home up.
+    placement_enabled() says when all of this is off (plain allocations): EPILOGOS_PLACEMENT=0, ranks sharing a GPU."""
+    import time
     R = X.shape[0]
     dev = X.device
     hbytes = R * S * 2
     plain = lambda: torch.empty((R, S), dtype=torch.int16, device=dev)
-    if X.numel() < PLACE_MIN_BYTES or os.environ.get("EPILOGOS_PLACEMENT", "1") == "0":
+    if X.numel() < PLACE_MIN_BYTES or not placement_enabled():
         return plain()
     st = _placement.get(dev.index)
     stor = X.untyped_storage()
@@ -123,75 +179,91 @@ def alloc_hist(X, N, S):
             return plain()
         if st["key"] == key:
             st["report"]["reuses"] += 1
+            _order_after_last_user(st)
             return view(st["home"])
+    t_start = time.perf_counter()
     counts = zeros_counts(S, device=dev)
     slices = _probe_slices(R)
     whole = [(0, R)]
-    base = _probe_ms(X, N, S, None, counts, slices)
-    base_whole = []                                          # (counts-only launch over the whole matrix, timed when first needed)
+    spent = [0.0]                                            # device time of the probes so far (ms)
+
+    def probe(cand, where, reps=2):
+        ms = _probe_ms(X, N, S, cand, counts, where, reps=reps)
+        spent[0] += ms * (reps + 1)
+        return ms
+
+    base = probe(None, slices)
+    base_whole = []
 
     def confirm(cand):
-        """The slices cover a fifth of the matrix; one that straddles memory classes between them (seen: slices 1.075, K1
-        2.39 ms) is found out by ONE comparison over the whole matrix (~12 ms): -> ratio with / without the store."""
         if slices == whole:
             return None
         if not base_whole:
-            base_whole.append(_probe_ms(X, N, S, None, counts, whole, reps=3))
-        return _probe_ms(X, N, S, cand, counts, whole, reps=3) / base_whole[0]
+            base_whole.append(probe(None, whole, reps=1))
+        return probe(cand, whole, reps=1) / base_whole[0]
 
-    tried = []                                               # (block, slice ratio, whole-matrix ratio or None)
     if st is not None and st["home"].numel() >= hbytes:      # another matrix: is the home good for it too?
-        r = _probe_ms(X, N, S, st["home"], counts, slices) / base
-        rw = confirm(st["home"]) if r <= PLACE_GOOD else None
-        if r <= PLACE_GOOD and (rw is None or rw <= PLACE_GOOD_WHOLE):
-            st["key"] = key
-            st["report"].update(revalidated=st["report"].get("revalidated", 0) + 1, ratio=round(r, 3))
-            return view(st["home"])
-        tried.append((st["home"], r, rw))
+        r = probe(st["home"], slices) / base
+        if r <= PLACE_SURE:
+            rw = confirm(st["home"])
+            if rw is None or rw <= r + PLACE_CONFIRM:
+                st["key"] = key
+                st["report"].update(revalidated=st["report"].get("revalidated", 0) + 1, ratio=round(r, 3))
+                _order_after_last_user(st)
+                return view(st["home"])
     _placement.pop(dev.index, None)
     block = max(PLACE_BLOCK, (hbytes + 4095) // 4096 * 4096)
-    cand = None
-    good = False
-    for k in range(int(os.environ.get("EPILOGOS_PLACEMENT_TRIES", PLACE_TRIES))):
-        free, _total = torch.cuda.mem_get_info(dev)
-        if tried and free < block + 16 * hbytes + (8 << 30):   # the rest of the job must still fit after the walk
+    import os
+    tries = int(os.environ.get("EPILOGOS_PLACEMENT_TRIES", PLACE_TRIES))
+    free0, _total = torch.cuda.mem_get_info(dev)
+    tries = min(tries, max(int(free0 // 4 // block), 1 if free0 > block + 16 * hbytes + (8 << 30) else 0))
+    cands, ratios = [], []
+    verdict, pick = "none", None
+    for k in range(tries):
+        if k and spent[0] >= PLACE_BUDGET_MS:
             break
         try:
-            cand = torch.empty(block, dtype=torch.int8, device=dev)
+            cands.append(torch.empty(block, dtype=torch.int8, device=dev))
         except RuntimeError:
             break
-        r = _probe_ms(X, N, S, cand, counts, slices) / base
-        rw = confirm(cand) if r <= PLACE_GOOD else None
-        tried.append((cand, r, rw))
-        if r <= PLACE_GOOD and (rw is None or rw <= PLACE_GOOD_WHOLE):
-            good = True
+        ratios.append(probe(cands[-1], slices) / base)
+        pick, verdict = place_decide(ratios)
+        if verdict in ("sure", "two-levels"):
             break
-        # six blocks that all measure the same: at a NARROW shape (the store a large share of the traffic: 127 columns measure
-        # 1.13-1.16 everywhere) the store does not tell the classes apart, and the search ends.  Behind a wide matrix it goes on:
-        # every block so far lies in the matrix's own class, and on a box whose memory is still in one piece a class is ONE run
-        # of a third of it -- seen: six blocks at 1.15-1.18 (the search of that day gave up: K1 2.47 instead of 2.25 ms), and
-        # seventeen at 1.17-1.18 on another box; PLACE_TRIES blocks (96 GiB) and the matrix are more than a third of the memory
-        rs = [t[1] for t in tried]
-        narrow = 2 * S > 0.10 * X.stride(0)
-        if narrow and len(rs) >= 6 and max(rs) <= 1.04 * min(rs):
-            break
-    if not tried:                                            # not even one block fits: no search, a plain allocation (or torch's OOM)
+    if not cands:                                            # not even one block fits: a plain allocation (or torch's OOM)
         return plain()
-    # the first good block; else the best figure: the whole-matrix one where it was taken, the slices' + 0.03 (how the two differ
-    # on a matrix that lies in one class) where not
-    rank = lambda t: t[2] if t[2] is not None else t[1] + 0.03
-    pick = len(tried) - 1 if good else min(range(len(tried)), key=lambda i: rank(tried[i]))
-    home = tried[pick][0]
-    ratios = [round(t[1], 3) for t in tried]
-    report = {"probe": "k_bin_hist over 3 x %d bins of the matrix, with the store into the candidate / counts only; a candidate "
-                       "that passes (<= %.2f) is confirmed over the whole matrix (<= %.3f)" % (slices[0][1] - slices[0][0], PLACE_GOOD, PLACE_GOOD_WHOLE),
-              "ms_counts_only": round(base * 1.0, 4), "blocks_tried": len(tried), "block_GiB": round(block / 2**30, 2),
-              "ratios": ratios if len(ratios) <= 12 else ratios[:4] + ["..."] + ratios[-6:],
-              "whole_matrix_ratios": {str(i): round(t[2], 3) for i, t in enumerate(tried) if t[2] is not None}, "picked": pick,
-              "good": good, "ratio": round(tried[pick][1], 3), "reuses": 0,
-              "left_in_torch_cache_GiB": round(sum(t[0].numel() for i, t in enumerate(tried) if i != pick) / 2**30, 1)}
-    _placement[dev.index] = {"key": key, "home": home, "report": report}
-    del tried, cand                                          # the other blocks -> torch's cache (not the driver)
+    # the pick over the whole matrix, once; a pick that straddles is set aside and the next one takes its place
+    whole_ratios, excluded = {}, []
+    for _ in range(2):
+        if pick is None:
+            break
+        rw = confirm(cands[pick])
+        if rw is None:
+            break
+        whole_ratios[pick] = rw
+        if rw <= ratios[pick] + PLACE_CONFIRM or spent[0] >= 2 * PLACE_BUDGET_MS:
+            break
+        excluded.append(pick)
+        nxt, v2 = place_decide(ratios, excluded)
+        if nxt is None:
+            break
+        pick, verdict = nxt, v2 + " (after a straddling pick)"
+    if excluded and pick in excluded:                        # every confirmation failed: the lowest whole-matrix ratio
+        pick = min(whole_ratios, key=whole_ratios.get)
+        verdict = "best of the straddling picks"
+    home = cands[pick]
+    good = verdict.startswith(("sure", "two-levels")) and pick not in excluded
+    report = {"probe": "k_bin_hist over 3 x %d bins of the matrix: with the H store into the head of a 4 GiB block / counts only" % (slices[0][1] - slices[0][0]),
+              "decision": verdict, "good": good, "picked": pick, "ratio": round(ratios[pick], 3),
+              "ratios": [round(r, 3) for r in ratios], "whole_matrix_ratios": {str(i): round(v, 3) for i, v in whole_ratios.items()},
+              "straddling": excluded, "blocks_tried": len(cands), "block_GiB": round(block / 2**30, 2),
+              "rules": {"sure_at_or_under": PLACE_SURE, "two_levels_apart_by": PLACE_GAP, "whole_matrix_within": PLACE_CONFIRM,
+                        "max_blocks": PLACE_TRIES, "max_probe_ms": PLACE_BUDGET_MS},
+              "ms_counts_only": round(base, 4), "probe_device_ms": round(spent[0], 2), "reuses": 0,
+              "left_in_torch_cache_GiB": round(sum(c.numel() for i, c in enumerate(cands) if i != pick) / 2**30, 1)}
+    _placement[dev.index] = {"key": key, "home": home, "report": report, "stream": torch.cuda.current_stream()}
+    del cands                                                # the other blocks -> torch's cache (not the driver)
+    report["search_ms"] = round((time.perf_counter() - t_start) * 1e3, 2)
     return view(home)
 
 
@@ -203,7 +275,8 @@ def placement_report(device=None):
 
 
 def release_placement():
-    """Forget the home (its memory goes to torch's cache)."""
+    """Forget the home (its memory goes to torch's cache; torch.cuda.empty_cache() then returns it and the probe blocks to the
+    driver).  For a process that is done with resident-matrix jobs and wants the memory for something else."""
     _placement.clear()
 
 

@@ -567,12 +567,13 @@ def test_get_num_states_counts_whitespace_only_lines_like_pandas(tmp_path):
         assert helpers.getNumStates(f) == pd.read_table(f, header=0, sep="\t").shape[0], repr(text)
 
 
-def test_placement_search_walks_out_of_a_long_run_of_the_matrix_class(monkeypatch):
-    """engine.alloc_hist's search, on the host with the probe faked: behind a WIDE matrix it walks through twenty blocks that
-    measure like the matrix's own memory class (on a box whose memory is in one piece a class is one run of a third of it) and
-    takes the first block of the next class; behind a NARROW matrix, where the store does not tell classes apart, six equal
-    blocks end it; with no good block at all it takes the best; a candidate that passes on the slices and fails over the whole
-    matrix is passed over."""
+def test_placement_decision_on_faked_ratio_sequences(monkeypatch):
+    """engine.alloc_hist's search on the host with the probe faked -- the decision is RELATIVE (two levels of the ratio >= 3 % apart:
+    the lower one is another memory class), BOUNDED (eight blocks, 50 ms of probes) and confirmed once over the whole matrix:
+    a first block that is clearly good ends the walk; behind a run of the matrix's own class the walk ends at the first block
+    3 % under it; a walk that only ever sees one level takes the lowest after eight blocks and says so; the driver's round-5 box
+    (slices 1.105, whole matrix 1.174: the matrix straddles) passes that block over; clock wobble of +-1 % around a level does
+    not split it in two."""
     import torch
     from epilogos_amd import engine
     order = {}
@@ -580,11 +581,11 @@ def test_placement_search_walks_out_of_a_long_run_of_the_matrix_class(monkeypatc
     def level_of(t):
         return order.setdefault(t.untyped_storage().data_ptr(), len(order))
 
-    def run(ldx, levels, whole=None, R=4096, S=18):
+    def run(levels, whole=None, R=4096, S=18, ldx=848):
         order.clear()
         X = torch.zeros((R, ldx), dtype=torch.int8)
 
-        def fake_probe(X_, N_, S_, Hflat, counts, slices, reps=3):
+        def fake_probe(X_, N_, S_, Hflat, counts, slices, reps=2):
             if Hflat is None:
                 return 1.0
             k = level_of(Hflat)
@@ -594,6 +595,9 @@ def test_placement_search_walks_out_of_a_long_run_of_the_matrix_class(monkeypatc
         monkeypatch.setattr(engine, "_probe_ms", fake_probe)
         monkeypatch.setattr(engine, "PLACE_MIN_BYTES", 1024)
         monkeypatch.setattr(engine, "PLACE_BLOCK", 1 << 16)
+        monkeypatch.setattr(engine, "placement_enabled", lambda: True)
+        monkeypatch.setattr(engine, "_order_after_last_user", lambda st: None)
+        monkeypatch.setattr(torch.cuda, "current_stream", lambda *a: None)
         monkeypatch.setattr(engine, "_probe_slices", lambda R_, rows=0: [(0, 1024), (1024, 2048), (3072, 4096)])
         monkeypatch.setattr(torch.cuda, "mem_get_info", lambda dev=None: (1 << 40, 1 << 40))
         engine.release_placement()
@@ -601,13 +605,42 @@ def test_placement_search_walks_out_of_a_long_run_of_the_matrix_class(monkeypatc
         rep = engine.placement_report(X.device) if X.device.index is not None else dict(engine._placement[None]["report"])
         engine.release_placement()
         assert H.shape == (R, S) and H.dtype == torch.int16
+        assert rep["blocks_tried"] <= engine.PLACE_TRIES and rep["left_in_torch_cache_GiB"] >= 0 and "search_ms" in rep
         return rep
 
-    rep = run(848, [1.175] * 20 + [1.08])
-    assert rep["good"] and rep["blocks_tried"] == 21 and rep["picked"] == 20
-    rep = run(128, [1.15] * 24)                                           # narrow: 36 of 128 row bytes are the store
-    assert not rep["good"] and rep["blocks_tried"] == 6
-    rep = run(848, [1.17] * 9 + [1.13] + [1.17] * 14)
-    assert not rep["good"] and rep["blocks_tried"] == engine.PLACE_TRIES and rep["picked"] == 9
-    rep = run(848, [1.17, 1.09, 1.17, 1.08], whole={1: 1.16})            # block 1 straddles: the slices missed it
-    assert rep["good"] and rep["picked"] == 3 and rep["whole_matrix_ratios"] == {"1": 1.16, "3": 1.1}
+    rep = run([1.08])                                                     # clearly another class: one block, no walk
+    assert rep["good"] and rep["decision"] == "sure" and rep["blocks_tried"] == 1 and rep["picked"] == 0
+    rep = run([1.175, 1.17, 1.18, 1.13, 1.17])                            # 3.5 % under the run before it: two levels, no absolute level involved
+    assert rep["good"] and rep["decision"] == "two-levels" and rep["blocks_tried"] == 4 and rep["picked"] == 3
+    rep = run([1.17, 1.165, 1.175, 1.168, 1.172, 1.17, 1.166, 1.174, 1.08])   # one level, +-0.5 % of wobble: bounded at eight, never reaches the ninth
+    assert not rep["good"] and rep["decision"] == "one-level" and rep["blocks_tried"] == 8 and rep["picked"] == 1
+    rep = run([1.105, 1.10], whole={0: 1.174, 1: 1.12})                   # the driver's box of round 5: block 0 passed its slices at 1.105 ...
+    assert rep["good"] and rep["picked"] == 1 and rep["whole_matrix_ratios"] == {"1": 1.12}   # ... here the walk goes on, and block 1 is confirmed
+    rep = run([1.09, 1.17], whole={0: 1.19})                              # sure on the slices, straddling over the whole matrix: set aside
+    assert rep["straddling"] == [0] and rep["picked"] == 0 and rep["decision"] == "best of the straddling picks" and not rep["good"]
+    rep = run([1.09, 1.17, 1.085], whole={0: 1.19})                       # (the walk had ended at block 0: nothing else was tried)
+    assert rep["blocks_tried"] == 1
+    rep = run([1.16, 1.12, 1.17], whole={1: 1.21, 0: 1.18, 2: 1.19})      # two levels, the lower one straddles: the pick falls back to the level above
+    assert rep["straddling"] == [1] and rep["picked"] in (0, 2) and not rep["good"]
+    # the decision function alone: wobble inside a level never reads as two levels, a real step does, excluded picks are skipped
+    assert engine.place_decide([1.14, 1.15, 1.145, 1.16, 1.136])[1] == "one-level"
+    assert engine.place_decide([1.14, 1.15, 1.105]) == (2, "two-levels")
+    assert engine.place_decide([1.14, 1.10, 1.15]) == (1, "sure")
+    assert engine.place_decide([1.17, 1.12, 1.17, 1.118], excluded=[3]) == (1, "two-levels")
+    assert engine.place_decide([], ()) == (None, "none")
+
+
+def test_placement_is_off_for_ranks_sharing_a_device(monkeypatch):
+    import torch
+    from epilogos_amd import engine
+    if getattr(torch._C, "_storage_Use_Count", None) is None:
+        pytest.skip("this torch cannot count storage users: placement is off altogether")
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 1)
+    monkeypatch.delenv("EPILOGOS_PLACEMENT", raising=False)
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "1")
+    assert engine.placement_enabled()
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "8")
+    assert not engine.placement_enabled()
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "1")
+    monkeypatch.setenv("EPILOGOS_PLACEMENT", "0")
+    assert not engine.placement_enabled()
