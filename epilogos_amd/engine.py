@@ -41,14 +41,14 @@ def alloc_states(R, N, device="cuda"):
 
 # ---- where the histogram cache of a RESIDENT matrix goes
 PLACE_MIN_BYTES = 1 << 30           # a matrix under 1 GiB is counted in < 0.2 ms: not worth a probe
-PLACE_BLOCK = 4 << 30               # candidates are the heads of blocks of this size (see alloc_hist)
-PLACE_TRIES = 8                     # at most this many blocks (32 GiB) are walked ...
+PLACE_BLOCK = 4 << 30               # candidates are the heads of blocks of this size (see alloc_hist) ...
+PLACE_SPACER = 12 << 30             # ... with a spacer of this size between two of them: the walk advances 16 GiB per candidate
+PLACE_TRIES = 8                     # at most this many blocks are walked (116 GiB: past the 96 GB one memory class can span) ...
 PLACE_BUDGET_MS = 50.0              # ... and at most this much device time is spent on probes
 PLACE_GAP = 0.03                    # two levels of the probe's ratio are "two memory classes" when they lie >= 3 % apart
 PLACE_SURE = 1.10                   # K1 with the H store / K1 counts only at or under this: the store lands in another class, no
                                     # contrast needed (every block ever measured in the matrix's own class: >= 1.136; in another: 1.05-1.105)
-PLACE_CONFIRM = 0.05                # the pick's ratio over the WHOLE matrix may exceed its ratio on the slices by this much (a matrix in
-                                    # one class: +0.02-0.03; one that straddles a class boundary between the slices: +0.07-0.10)
+PLACE_WIN = 0.01                    # the pick must beat the plain allocation by this much over the WHOLE matrix to replace it
 _placement = {}                     # device index -> {"key", "home", "report", "stream"}
 
 
@@ -142,25 +142,31 @@ def _order_after_last_user(st):
 def alloc_hist(X, N, S):
     """The [R, S] uint16 histogram cache (int16 storage) for a RESIDENT state matrix X, in another memory CLASS than X.
 
-    The 288 GB of an MI355X fall into three classes of a third each, in contiguous runs of 4-96 GiB of the driver's
-    allocation order (profiles/r02ae_k1_memory_class_map.txt).  k_bin_hist reads X and writes H: with both in one class the
-    launch is 13-17 % slower (2.6 against 2.3 ms for 15 M x 833) whatever the offsets, the data or the other buffers are.  HIP
-    does not tell the class of an allocation, so the classifier is the kernel itself, on three 1 M-bin slices of X (head,
-    middle, tail): ratio = launches with the H store into the candidate / counts-only launches.
-    Candidates are the HEADS OF 4 GiB BLOCKS allocated one after the other and held during the search (an H-sized allocation
-    comes from the crumbs next to the matrix; 4 GiB blocks make the driver walk through its memory).  The walk is BOUNDED --
-    PLACE_TRIES blocks, PLACE_BUDGET_MS of probe time, a quarter of the free memory -- and the decision is place_decide's: a
-    candidate at or under PLACE_SURE ends the walk at once; otherwise the walk goes on until the ratios show two levels >= 3 %
-    apart (pick: the lowest of the lower level) or the bounds are reached (pick: the lowest -- never worse than the plain
-    allocation this replaces, which lies next to the matrix).  The pick is confirmed ONCE over the whole matrix (the slices cover
-    a fifth of it and can miss a class boundary inside it): a whole-matrix ratio more than PLACE_CONFIRM above the slices' means
-    the matrix straddles there, and the next pick is confirmed instead.
-    The picked block is the device's HOME for the life of the process (H is a view of its head): later jobs on the same matrix
-    get it without a probe, a job on another matrix after one probe.  The other blocks go back to torch's caching allocator
-    (not to the driver: freed device memory is scrubbed in the background at every HBM-bound kernel's expense); the report says
-    how much.  While a view of the home is alive the next request gets a plain allocation; a hand-out on another stream than
-    the previous one waits for that stream (_order_after_last_user).  release_placement() gives the home up.
+    The 288 GB of an MI355X fall into three classes of a third each (96 GB, contiguous in the driver's allocation order -- the
+    three ranks of its 12-high HBM stacks would look exactly like this; profiles/r02ae_k1_memory_class_map.txt).  k_bin_hist
+    reads X and writes H: with both in one class the launch is 13-17 % slower (2.6 against 2.3 ms for 15 M x 833) whatever the
+    offsets, the data or the other buffers are.  HIP does not tell the class of an allocation, so the classifier is the kernel
+    itself, on three 1 M-bin slices of X (head, middle, tail): ratio = launches with the H store into the candidate /
+    counts-only launches.
+    Candidate 0 is the PLAIN allocation this function replaces (what a caller without placement would get: next to the matrix,
+    as a rule in its class).  The others are the heads of 4 GiB blocks allocated one after the other, 12 GiB spacers between
+    them, all held during the search: the driver then walks through its memory in steps of 16 GiB, and PLACE_TRIES = 8 blocks
+    reach 116 GiB past the matrix -- more than the 96 GB a class can span (four boxes of round 6 needed 3, 6, 6 and more than 8
+    steps of 4 GiB).  The walk is BOUNDED -- PLACE_TRIES blocks, PLACE_BUDGET_MS of probe time, what is free on the device -- and
+    the decision is place_decide's: a candidate at or under PLACE_SURE ends it at once, otherwise it goes on until the ratios
+    show two levels >= 3 % apart (pick: the lowest of the lower level) or a bound is reached (pick: the lowest).
+    Then ONE comparison decides, over the WHOLE matrix (the slices cover a fifth of it and miss a class boundary inside it): the
+    pick against the plain allocation, the faster one wins; a pick that loses is set aside and the next one gets one try.  So the
+    cache is never slower than the plain allocation it replaces (by more than the comparison's noise), whatever the box.
+    A block that wins is the device's HOME for the life of the process (H is a view of its head): later jobs on the same matrix
+    get it without a probe, a job on another matrix after one probe.  Spacers and losing blocks go back to torch's caching
+    allocator (not to the driver: freed device memory is scrubbed in the background at every HBM-bound kernel's expense; torch
+    hands cached blocks out again and returns them to the driver by itself when an allocation would otherwise fail); the report
+    says how much.  When the plain allocation wins, that is remembered too (no further search for this matrix).
+    While a view of the home is alive the next request gets a plain allocation; a hand-out on another stream than the previous
+    one waits for that stream (_order_after_last_user).  release_placement() gives the home up.
     placement_enabled() says when all of this is off (plain allocations): EPILOGOS_PLACEMENT=0, ranks sharing a GPU."""
+    import os
     import time
     R = X.shape[0]
     dev = X.device
@@ -172,7 +178,11 @@ def alloc_hist(X, N, S):
     stor = X.untyped_storage()
     key = (stor.data_ptr(), stor.nbytes())
     view = lambda home: home[:hbytes].view(torch.int16).view(R, S)
-    if st is not None and st["home"].numel() >= hbytes:
+    if st is not None and st["home"] is None:                # the plain allocation won the comparison for this matrix
+        if st["key"] == key:
+            st["report"]["reuses"] += 1
+            return plain()
+    elif st is not None and st["home"].numel() >= hbytes:
         users = _storage_users(st["home"])
         if users is None or users > 1:
             st["report"]["plain_while_home_in_use"] = st["report"].get("plain_while_home_in_use", 0) + 1
@@ -193,78 +203,77 @@ def alloc_hist(X, N, S):
         return ms
 
     base = probe(None, slices)
-    base_whole = []
-
-    def confirm(cand):
-        if slices == whole:
-            return None
-        if not base_whole:
-            base_whole.append(probe(None, whole, reps=1))
-        return probe(cand, whole, reps=1) / base_whole[0]
-
-    if st is not None and st["home"].numel() >= hbytes:      # another matrix: is the home good for it too?
+    if st is not None and st["home"] is not None and st["home"].numel() >= hbytes:      # another matrix: is the home good for it too?
         r = probe(st["home"], slices) / base
         if r <= PLACE_SURE:
-            rw = confirm(st["home"])
-            if rw is None or rw <= r + PLACE_CONFIRM:
-                st["key"] = key
-                st["report"].update(revalidated=st["report"].get("revalidated", 0) + 1, ratio=round(r, 3))
-                _order_after_last_user(st)
-                return view(st["home"])
+            st["key"] = key
+            st["report"].update(revalidated=st["report"].get("revalidated", 0) + 1, ratio=round(r, 3))
+            _order_after_last_user(st)
+            return view(st["home"])
     _placement.pop(dev.index, None)
     block = max(PLACE_BLOCK, (hbytes + 4095) // 4096 * 4096)
-    import os
     tries = int(os.environ.get("EPILOGOS_PLACEMENT_TRIES", PLACE_TRIES))
-    free0, _total = torch.cuda.mem_get_info(dev)
-    tries = min(tries, max(int(free0 // 4 // block), 1 if free0 > block + 16 * hbytes + (8 << 30) else 0))
-    cands, ratios = [], []
-    verdict, pick = "none", None
-    for k in range(tries):
-        if k and spent[0] >= PLACE_BUDGET_MS:
-            break
+    h_plain = plain()
+    cands, ratios, spacers = [h_plain.view(torch.int8).view(-1)], [], []
+    ratios.append(probe(cands[0], slices) / base)
+    whole_ms, excluded = {}, []
+
+    def walk_on():
+        """One more block (behind a spacer), probed on the slices; False when a bound is reached."""
+        k = len(cands) - 1
+        if k >= tries or spent[0] >= PLACE_BUDGET_MS:
+            return False
+        free, _total = torch.cuda.mem_get_info(dev)
+        if free < block + (PLACE_SPACER if k else 0) + 16 * hbytes + (8 << 30):       # the rest of the job must still fit
+            return False
         try:
+            if k and PLACE_SPACER:
+                spacers.append(torch.empty(PLACE_SPACER, dtype=torch.int8, device=dev))
             cands.append(torch.empty(block, dtype=torch.int8, device=dev))
         except RuntimeError:
-            break
+            return False
         ratios.append(probe(cands[-1], slices) / base)
-        pick, verdict = place_decide(ratios)
-        if verdict in ("sure", "two-levels"):
+        return True
+
+    # walk until the slices decide (or a bound is reached), then the comparison that counts: the pick against the plain allocation
+    # over the WHOLE matrix.  A pick that loses is set aside and the walk goes on from where it stopped (three such losses end it).
+    pick, verdict = place_decide(ratios, excluded)
+    while True:
+        while verdict not in ("sure", "two-levels") and walk_on():
+            pick, verdict = place_decide(ratios, excluded)
+        if pick in (None, 0):
             break
-    if not cands:                                            # not even one block fits: a plain allocation (or torch's OOM)
-        return plain()
-    # the pick over the whole matrix, once; a pick that straddles is set aside and the next one takes its place
-    whole_ratios, excluded = {}, []
-    for _ in range(2):
-        if pick is None:
-            break
-        rw = confirm(cands[pick])
-        if rw is None:
-            break
-        whole_ratios[pick] = rw
-        if rw <= ratios[pick] + PLACE_CONFIRM or spent[0] >= 2 * PLACE_BUDGET_MS:
+        if slices == whole:
+            whole_ms = {0: ratios[0] * base, pick: ratios[pick] * base}
+        else:
+            if 0 not in whole_ms:
+                whole_ms[0] = probe(cands[0], whole, reps=1)
+            whole_ms[pick] = probe(cands[pick], whole, reps=1)
+        if whole_ms[pick] < whole_ms[0] * (1.0 - PLACE_WIN):
             break
         excluded.append(pick)
-        nxt, v2 = place_decide(ratios, excluded)
-        if nxt is None:
+        if len(excluded) >= 3 or spent[0] >= 2 * PLACE_BUDGET_MS:
+            pick = 0
             break
-        pick, verdict = nxt, v2 + " (after a straddling pick)"
-    if excluded and pick in excluded:                        # every confirmation failed: the lowest whole-matrix ratio
-        pick = min(whole_ratios, key=whole_ratios.get)
-        verdict = "best of the straddling picks"
-    home = cands[pick]
-    good = verdict.startswith(("sure", "two-levels")) and pick not in excluded
-    report = {"probe": "k_bin_hist over 3 x %d bins of the matrix: with the H store into the head of a 4 GiB block / counts only" % (slices[0][1] - slices[0][0]),
-              "decision": verdict, "good": good, "picked": pick, "ratio": round(ratios[pick], 3),
-              "ratios": [round(r, 3) for r in ratios], "whole_matrix_ratios": {str(i): round(v, 3) for i, v in whole_ratios.items()},
-              "straddling": excluded, "blocks_tried": len(cands), "block_GiB": round(block / 2**30, 2),
-              "rules": {"sure_at_or_under": PLACE_SURE, "two_levels_apart_by": PLACE_GAP, "whole_matrix_within": PLACE_CONFIRM,
+        pick, verdict = place_decide(ratios, excluded)
+        verdict += " (after %d pick(s) that lost over the whole matrix)" % len(excluded)
+    if pick is None or pick in excluded:
+        pick = 0
+    good = pick != 0
+    report = {"probe": "k_bin_hist over 3 x %d bins of the matrix: with the H store into a candidate / counts only; candidate 0 is the plain "
+                       "allocation, the others heads of %d GiB blocks %d GiB apart" % (slices[0][1] - slices[0][0], block >> 30, (block + PLACE_SPACER) >> 30),
+              "decision": verdict if good else "plain allocation kept (%s)" % verdict, "good": good, "picked": pick, "ratio": round(ratios[pick], 3),
+              "ratios": [round(r, 3) for r in ratios], "whole_matrix_ms": {str(i): round(v, 4) for i, v in whole_ms.items()},
+              "lost_over_the_whole_matrix": excluded, "blocks_tried": len(cands) - 1, "walked_GiB": round((sum(c.numel() for c in cands[1:]) + sum(x.numel() for x in spacers)) / 2**30, 1),
+              "rules": {"sure_at_or_under": PLACE_SURE, "two_levels_apart_by": PLACE_GAP, "must_beat_plain_by": PLACE_WIN,
                         "max_blocks": PLACE_TRIES, "max_probe_ms": PLACE_BUDGET_MS},
               "ms_counts_only": round(base, 4), "probe_device_ms": round(spent[0], 2), "reuses": 0,
-              "left_in_torch_cache_GiB": round(sum(c.numel() for i, c in enumerate(cands) if i != pick) / 2**30, 1)}
+              "left_in_torch_cache_GiB": round((sum(c.numel() for i, c in enumerate(cands) if i and i != pick) + sum(x.numel() for x in spacers)) / 2**30, 1)}
+    home = cands[pick] if good else None
     _placement[dev.index] = {"key": key, "home": home, "report": report, "stream": torch.cuda.current_stream()}
-    del cands                                                # the other blocks -> torch's cache (not the driver)
+    del cands, spacers                                       # spacers and losing blocks -> torch's cache (not the driver)
     report["search_ms"] = round((time.perf_counter() - t_start) * 1e3, 2)
-    return view(home)
+    return view(home) if good else h_plain
 
 
 def placement_report(device=None):

@@ -568,12 +568,14 @@ def test_get_num_states_counts_whitespace_only_lines_like_pandas(tmp_path):
 
 
 def test_placement_decision_on_faked_ratio_sequences(monkeypatch):
-    """engine.alloc_hist's search on the host with the probe faked -- the decision is RELATIVE (two levels of the ratio >= 3 % apart:
-    the lower one is another memory class), BOUNDED (eight blocks, 50 ms of probes) and confirmed once over the whole matrix:
-    a first block that is clearly good ends the walk; behind a run of the matrix's own class the walk ends at the first block
-    3 % under it; a walk that only ever sees one level takes the lowest after eight blocks and says so; the driver's round-5 box
-    (slices 1.105, whole matrix 1.174: the matrix straddles) passes that block over; clock wobble of +-1 % around a level does
-    not split it in two."""
+    """engine.alloc_hist's search on the host with the probe faked.  Candidate 0 is the PLAIN allocation the search replaces, the
+    others are blocks further along the driver's memory; the decision is RELATIVE (two levels of the ratio >= 3 % apart: the lower
+    one is another memory class), BOUNDED (eight blocks, 50 ms of probes) and settled by ONE comparison over the whole matrix
+    against the plain allocation -- the placed cache is never slower than what it replaces.  Sequences: a first block that is
+    clearly good; a run of the matrix's own class with a good block behind it; a walk that only ever sees one level (bounded at
+    eight, the plain allocation stays); the driver's round-5 box (a block that passes its slices at 1.105 and loses over the
+    whole matrix, 1.174: the matrix straddles there); a plain allocation that already lies in another class; +-1 % of clock wobble
+    inside a level."""
     import torch
     from epilogos_amd import engine
     order = {}
@@ -582,6 +584,8 @@ def test_placement_decision_on_faked_ratio_sequences(monkeypatch):
         return order.setdefault(t.untyped_storage().data_ptr(), len(order))
 
     def run(levels, whole=None, R=4096, S=18, ldx=848):
+        """levels[k]: slice ratio of candidate k (0 = the plain allocation); whole[k]: its time over the whole matrix (default:
+        ratio + 0.02)."""
         order.clear()
         X = torch.zeros((R, ldx), dtype=torch.int8)
 
@@ -595,6 +599,7 @@ def test_placement_decision_on_faked_ratio_sequences(monkeypatch):
         monkeypatch.setattr(engine, "_probe_ms", fake_probe)
         monkeypatch.setattr(engine, "PLACE_MIN_BYTES", 1024)
         monkeypatch.setattr(engine, "PLACE_BLOCK", 1 << 16)
+        monkeypatch.setattr(engine, "PLACE_SPACER", 1 << 12)
         monkeypatch.setattr(engine, "placement_enabled", lambda: True)
         monkeypatch.setattr(engine, "_order_after_last_user", lambda st: None)
         monkeypatch.setattr(torch.cuda, "current_stream", lambda *a: None)
@@ -603,25 +608,31 @@ def test_placement_decision_on_faked_ratio_sequences(monkeypatch):
         engine.release_placement()
         H = engine.alloc_hist(X, ldx - 15, S)
         rep = engine.placement_report(X.device) if X.device.index is not None else dict(engine._placement[None]["report"])
+        H2 = engine.alloc_hist(X, ldx - 15, S)                            # the same matrix again: no second search
+        rep2 = engine.placement_report(X.device) if X.device.index is not None else dict(engine._placement[None]["report"])
+        assert rep2["reuses"] + rep2.get("plain_while_home_in_use", 0) == 1 and rep2["search_ms"] == rep["search_ms"]
         engine.release_placement()
-        assert H.shape == (R, S) and H.dtype == torch.int16
+        assert H.shape == (R, S) and H.dtype == torch.int16 and H2.shape == (R, S)
         assert rep["blocks_tried"] <= engine.PLACE_TRIES and rep["left_in_torch_cache_GiB"] >= 0 and "search_ms" in rep
+        assert rep["good"] == (rep["picked"] != 0)
         return rep
 
-    rep = run([1.08])                                                     # clearly another class: one block, no walk
-    assert rep["good"] and rep["decision"] == "sure" and rep["blocks_tried"] == 1 and rep["picked"] == 0
+    rep = run([1.17, 1.08])                                               # the first block is clearly another class: no walk
+    assert rep["good"] and rep["decision"] == "sure" and rep["blocks_tried"] == 1 and rep["picked"] == 1
     rep = run([1.175, 1.17, 1.18, 1.13, 1.17])                            # 3.5 % under the run before it: two levels, no absolute level involved
-    assert rep["good"] and rep["decision"] == "two-levels" and rep["blocks_tried"] == 4 and rep["picked"] == 3
-    rep = run([1.17, 1.165, 1.175, 1.168, 1.172, 1.17, 1.166, 1.174, 1.08])   # one level, +-0.5 % of wobble: bounded at eight, never reaches the ninth
-    assert not rep["good"] and rep["decision"] == "one-level" and rep["blocks_tried"] == 8 and rep["picked"] == 1
-    rep = run([1.105, 1.10], whole={0: 1.174, 1: 1.12})                   # the driver's box of round 5: block 0 passed its slices at 1.105 ...
-    assert rep["good"] and rep["picked"] == 1 and rep["whole_matrix_ratios"] == {"1": 1.12}   # ... here the walk goes on, and block 1 is confirmed
-    rep = run([1.09, 1.17], whole={0: 1.19})                              # sure on the slices, straddling over the whole matrix: set aside
-    assert rep["straddling"] == [0] and rep["picked"] == 0 and rep["decision"] == "best of the straddling picks" and not rep["good"]
-    rep = run([1.09, 1.17, 1.085], whole={0: 1.19})                       # (the walk had ended at block 0: nothing else was tried)
-    assert rep["blocks_tried"] == 1
-    rep = run([1.16, 1.12, 1.17], whole={1: 1.21, 0: 1.18, 2: 1.19})      # two levels, the lower one straddles: the pick falls back to the level above
-    assert rep["straddling"] == [1] and rep["picked"] in (0, 2) and not rep["good"]
+    assert rep["good"] and rep["decision"] == "two-levels" and rep["blocks_tried"] == 3 and rep["picked"] == 3
+    rep = run([1.17, 1.165, 1.175, 1.168, 1.172, 1.17, 1.166, 1.174, 1.169, 1.08])   # one level, +-0.5 % of wobble: bounded at eight blocks
+    assert not rep["good"] and rep["blocks_tried"] == 8 and rep["picked"] == 0 and rep["decision"].startswith("plain allocation kept (one-level")
+    rep = run([1.14, 1.105, 1.10], whole={0: 1.17, 1: 1.174, 2: 1.12})    # the driver's box of round 5: block 1 passes its slices ...
+    assert rep["good"] and rep["picked"] == 2 and rep["lost_over_the_whole_matrix"] == [1]         # ... loses over the whole matrix, the walk goes on, block 2 wins
+    rep = run([1.14, 1.09] + [1.145] * 8, whole={0: 1.17, 1: 1.19})       # sure on the slices, slower than the plain allocation over the whole matrix;
+    assert not rep["good"] and rep["picked"] == 0 and rep["lost_over_the_whole_matrix"][0] == 1 and rep["blocks_tried"] == 8   # nothing better behind it
+    rep = run([1.09, 1.17])                                               # the plain allocation already lies in another class: kept, no block tried
+    assert not rep["good"] and rep["blocks_tried"] == 0 and rep["decision"] == "plain allocation kept (sure)"
+    rep = run([1.16, 1.16, 1.12] + [1.17] * 8, whole={0: 1.18, 2: 1.21})  # two levels, the lower one loses over the whole matrix: plain stays
+    assert not rep["good"] and rep["lost_over_the_whole_matrix"][0] == 2 and rep["picked"] == 0
+    rep = run([1.16, 1.16, 1.12] + [1.17] * 8, whole={0: 1.18, 2: 1.175}) # ... wins by less than 1 %: not worth a home block
+    assert not rep["good"] and rep["picked"] == 0
     # the decision function alone: wobble inside a level never reads as two levels, a real step does, excluded picks are skipped
     assert engine.place_decide([1.14, 1.15, 1.145, 1.16, 1.136])[1] == "one-level"
     assert engine.place_decide([1.14, 1.15, 1.105]) == (2, "two-levels")

@@ -19,6 +19,6 @@ for spec in sys.argv[1:] * 2:
         sh = d["s1_paths"]["shard_1875000_bins"]
         print("%-30s %.1f Mbins/s  step %.4f ms  K1 %.4f  rest %.4f | shard step %.4f K1 %.4f | placement %s" % (
             spec, d["value"], d["ms_per_step"], d["kernels_ms"]["k_bin_hist"], d["kernels_ms"]["combine(normalise,table)+score_from_hist"],
-            sh["session_ms_per_step"], sh["session_k_bin_hist_ms"], d["placement"]["report"]["whole_matrix_ratios"]), flush=True)
+            sh["session_ms_per_step"], sh["session_k_bin_hist_ms"], (d["placement"].get("report") or {}).get("whole_matrix_ms")), flush=True)
     except Exception as e:
         print(spec, "failed", r.stderr[-400:])
