@@ -41,15 +41,19 @@ def alloc_states(R, N, device="cuda"):
 
 # ---- where the histogram cache of a RESIDENT matrix goes
 PLACE_MIN_BYTES = 1 << 30           # a matrix under 1 GiB is counted in < 0.2 ms: not worth a probe
-PLACE_BLOCK = 4 << 30               # candidates are the heads of blocks of this size (see alloc_hist) ...
-PLACE_SPACER = 12 << 30             # ... with a spacer of this size between two of them: the walk advances 16 GiB per candidate
-PLACE_TRIES = 8                     # at most this many blocks are walked (116 GiB: past the 96 GB one memory class can span) ...
-PLACE_BUDGET_MS = 50.0              # ... and at most this much device time is spent on probes
+PLACE_BLOCK = 4 << 30               # candidates are the heads of blocks of this size (see alloc_hist)
+PLACE_SEARCH_AT = 2                 # the n-th job on the same resident matrix runs the QUICK search ...
+PLACE_TRIES = 8                     # ... at most 8 blocks (32 GiB: about what a process gets from the driver's pool of cleared memory at
+PLACE_BUDGET_MS = 50.0              #     0.3 ms per block) and 50 ms of probe time
+PLACE_DEEP_AT = 4                   # the n-th job, if the quick search kept the plain allocation, runs the DEEP search, once ...
+PLACE_DEEP_TRIES = 24               # ... 24 blocks = 96 GiB, past what one memory class can span; memory beyond the cleared pool costs the
+PLACE_DEEP_WALL_MS = 5000.0         #     driver ~30 ms per GiB to hand out (tools/alloc_probe.py): seconds, which only a process that keeps
+                                    #     running jobs on the matrix gets back (0.3 ms per 15 M-bin job) -- hence the job count in front of it
 PLACE_GAP = 0.03                    # two levels of the probe's ratio are "two memory classes" when they lie >= 3 % apart
 PLACE_SURE = 1.10                   # K1 with the H store / K1 counts only at or under this: the store lands in another class, no
                                     # contrast needed (every block ever measured in the matrix's own class: >= 1.136; in another: 1.05-1.105)
 PLACE_WIN = 0.01                    # the pick must beat the plain allocation by this much over the WHOLE matrix to replace it
-_placement = {}                     # device index -> {"key", "home", "report", "stream"}
+_placement = {}                     # device index -> {"key", "home", "report", "stream", "seen", "tier"}
 
 
 def _storage_users(t):
@@ -140,34 +144,39 @@ def _order_after_last_user(st):
 
 
 def alloc_hist(X, N, S):
-    """The [R, S] uint16 histogram cache (int16 storage) for a RESIDENT state matrix X, in another memory CLASS than X.
+    """The [R, S] uint16 histogram cache (int16 storage) for a RESIDENT state matrix X -- in another memory CLASS than X once
+    the process has shown that it keeps running jobs on that matrix.
 
     The 288 GB of an MI355X fall into three classes of a third each (96 GB, contiguous in the driver's allocation order -- the
     three ranks of its 12-high HBM stacks would look exactly like this; profiles/r02ae_k1_memory_class_map.txt).  k_bin_hist
     reads X and writes H: with both in one class the launch is 13-17 % slower (2.6 against 2.3 ms for 15 M x 833) whatever the
     offsets, the data or the other buffers are.  HIP does not tell the class of an allocation, so the classifier is the kernel
     itself, on three 1 M-bin slices of X (head, middle, tail): ratio = launches with the H store into the candidate /
-    counts-only launches.
-    Candidate 0 is the PLAIN allocation this function replaces (what a caller without placement would get: next to the matrix,
-    as a rule in its class).  The others are the heads of 4 GiB blocks allocated one after the other, 12 GiB spacers between
-    them, all held during the search: the driver then walks through its memory in steps of 16 GiB, and PLACE_TRIES = 8 blocks
-    reach 116 GiB past the matrix -- more than the 96 GB a class can span (four boxes of round 6 needed 3, 6, 6 and more than 8
-    steps of 4 GiB).  The walk is BOUNDED -- PLACE_TRIES blocks, PLACE_BUDGET_MS of probe time, what is free on the device -- and
-    the decision is place_decide's: a candidate at or under PLACE_SURE ends it at once, otherwise it goes on until the ratios
-    show two levels >= 3 % apart (pick: the lowest of the lower level) or a bound is reached (pick: the lowest).
-    Then ONE comparison decides, over the WHOLE matrix (the slices cover a fifth of it and miss a class boundary inside it): the
-    pick against the plain allocation, the faster one wins; a pick that loses is set aside and the next one gets one try.  So the
-    cache is never slower than the plain allocation it replaces (by more than the comparison's noise), whatever the box.
-    A block that wins is the device's HOME for the life of the process (H is a view of its head): later jobs on the same matrix
-    get it without a probe, a job on another matrix after one probe.  Spacers and losing blocks go back to torch's caching
+    counts-only launches.  Candidate 0 is the PLAIN allocation this function replaces (next to the matrix, as a rule in its
+    class); the others are the heads of 4 GiB blocks allocated one after the other and held during the search, which makes the
+    driver walk through its memory.  place_decide reads the ratios (a candidate at or under PLACE_SURE ends the walk at once;
+    otherwise it goes on until two levels >= 3 % apart show, pick = the lowest of the lower one, or a bound is reached, pick =
+    the lowest), and then ONE comparison decides, over the WHOLE matrix (the slices cover a fifth of it and miss a class
+    boundary inside it): the pick against the plain allocation -- a pick that does not win by 1 % is set aside and the walk
+    goes on; three losses end it.  The cache is therefore never slower than the plain allocation it replaces.
+
+    What the search may cost is tied to what it can earn (0.3 ms per 15 M-bin job):
+      * job 1 on a matrix: no search, a plain allocation -- a command-line run (one job per matrix) never pays anything;
+      * job PLACE_SEARCH_AT: the QUICK search -- <= 8 blocks, <= 50 ms of probes, ~40 ms in all: 32 GiB past the matrix is
+        about what the driver hands out from its pool of cleared memory at 0.3 ms per block; the class boundary lies inside
+        that stretch for roughly a third of the fresh processes (it is 96 GB away at most, anywhere with equal odds);
+      * job PLACE_DEEP_AT, if the plain allocation was kept: the DEEP search, once -- <= 24 blocks (96 GiB, past any class),
+        <= 5 s: beyond the cleared pool the driver takes ~30 ms per GiB to hand memory out, i.e. 1-3 s for the walk
+        (tools/alloc_probe.py; profiles/r06d_*), which a process that keeps running jobs gets back and a single job does not.
+    A block that wins is the device's HOME for the life of the process (H is a view of its head): later jobs on the same
+    matrix get it without a probe, a job on another matrix after one probe.  The other blocks go back to torch's caching
     allocator (not to the driver: freed device memory is scrubbed in the background at every HBM-bound kernel's expense; torch
-    hands cached blocks out again and returns them to the driver by itself when an allocation would otherwise fail); the report
-    says how much.  When the plain allocation wins, that is remembered too (no further search for this matrix).
+    reuses cached blocks and returns them by itself when an allocation would otherwise fail); the report says how much.
     While a view of the home is alive the next request gets a plain allocation; a hand-out on another stream than the previous
     one waits for that stream (_order_after_last_user).  release_placement() gives the home up.
-    placement_enabled() says when all of this is off (plain allocations): EPILOGOS_PLACEMENT=0, ranks sharing a GPU."""
+    placement_enabled() says when all of this is off (plain allocations): EPILOGOS_PLACEMENT=0, ranks sharing a GPU.
+    EPILOGOS_PLACEMENT_EAGER=1: both searches at the first job (tools, tests)."""
     import os
-    import time
     R = X.shape[0]
     dev = X.device
     hbytes = R * S * 2
@@ -178,19 +187,55 @@ def alloc_hist(X, N, S):
     stor = X.untyped_storage()
     key = (stor.data_ptr(), stor.nbytes())
     view = lambda home: home[:hbytes].view(torch.int16).view(R, S)
-    if st is not None and st["home"] is None:                # the plain allocation won the comparison for this matrix
-        if st["key"] == key:
-            st["report"]["reuses"] += 1
-            return plain()
-    elif st is not None and st["home"].numel() >= hbytes:
+    eager = os.environ.get("EPILOGOS_PLACEMENT_EAGER") == "1"
+    if st is not None and st["home"] is not None and st["home"].numel() >= hbytes:
         users = _storage_users(st["home"])
         if users is None or users > 1:
             st["report"]["plain_while_home_in_use"] = st["report"].get("plain_while_home_in_use", 0) + 1
             return plain()
         if st["key"] == key:
-            st["report"]["reuses"] += 1
+            st["report"]["reuses"] = st["report"].get("reuses", 0) + 1
             _order_after_last_user(st)
             return view(st["home"])
+        counts = zeros_counts(S, device=dev)                 # another matrix: is the home good for it too?
+        slices = _probe_slices(R)
+        r = _probe_ms(X, N, S, st["home"], counts, slices) / _probe_ms(X, N, S, None, counts, slices)
+        if r <= PLACE_SURE:
+            st["key"] = key
+            st["report"].update(revalidated=st["report"].get("revalidated", 0) + 1, ratio=round(r, 3))
+            _order_after_last_user(st)
+            return view(st["home"])
+        st = None                                            # no: this matrix starts over (the old home goes to torch's cache)
+        _placement.pop(dev.index, None)
+    if st is None or st["key"] != key:
+        st = _placement[dev.index] = {"key": key, "home": None, "report": {"jobs_seen": 0, "tier": "none yet"}, "stream": None, "seen": 0, "tier": 0}
+    st["seen"] += 1
+    st["report"]["jobs_seen"] = st["seen"]
+    want = 0
+    if st["tier"] < 1 and (eager or st["seen"] >= PLACE_SEARCH_AT):
+        want = 1
+    elif st["tier"] == 1 and (eager or st["seen"] >= PLACE_DEEP_AT):
+        want = 2
+    if not want:
+        return plain()
+    deep = want == 2
+    home, h_plain, report = _place_search(X, N, S, int(os.environ.get("EPILOGOS_PLACEMENT_TRIES", PLACE_DEEP_TRIES if deep else PLACE_TRIES)),
+                                          3 * PLACE_BUDGET_MS if deep else PLACE_BUDGET_MS, PLACE_DEEP_WALL_MS if deep else 10 * PLACE_BUDGET_MS)
+    report.update(tier="deep" if deep else "quick", jobs_seen=st["seen"], reuses=0)
+    if deep and "quick" not in report:
+        report["quick"] = {k: st["report"].get(k) for k in ("decision", "ratios", "blocks_tried", "search_ms")}
+    st.update(home=home, report=report, stream=torch.cuda.current_stream(), tier=want)
+    if home is None and eager and want == 1:
+        return alloc_hist(X, N, S)                           # (eager: the deep search follows at once)
+    return view(home) if home is not None else h_plain
+
+
+def _place_search(X, N, S, tries, budget_ms, wall_ms):
+    """One search of alloc_hist: -> (home block or None = the plain allocation stays, the plain allocation, report)."""
+    import time
+    R = X.shape[0]
+    dev = X.device
+    hbytes = R * S * 2
     t_start = time.perf_counter()
     counts = zeros_counts(S, device=dev)
     slices = _probe_slices(R)
@@ -203,35 +248,27 @@ def alloc_hist(X, N, S):
         return ms
 
     base = probe(None, slices)
-    if st is not None and st["home"] is not None and st["home"].numel() >= hbytes:      # another matrix: is the home good for it too?
-        r = probe(st["home"], slices) / base
-        if r <= PLACE_SURE:
-            st["key"] = key
-            st["report"].update(revalidated=st["report"].get("revalidated", 0) + 1, ratio=round(r, 3))
-            _order_after_last_user(st)
-            return view(st["home"])
-    _placement.pop(dev.index, None)
     block = max(PLACE_BLOCK, (hbytes + 4095) // 4096 * 4096)
-    tries = int(os.environ.get("EPILOGOS_PLACEMENT_TRIES", PLACE_TRIES))
-    h_plain = plain()
-    cands, ratios, spacers = [h_plain.view(torch.int8).view(-1)], [], []
+    h_plain = torch.empty((R, S), dtype=torch.int16, device=dev)
+    cands, ratios = [h_plain.view(torch.int8).view(-1)], []
     ratios.append(probe(cands[0], slices) / base)
-    whole_ms, excluded = {}, []
+    whole_ms, excluded, alloc_ms = {}, [], []
 
     def walk_on():
-        """One more block (behind a spacer), probed on the slices; False when a bound is reached."""
+        """One more block, probed on the slices; False when a bound is reached."""
         k = len(cands) - 1
-        if k >= tries or spent[0] >= PLACE_BUDGET_MS:
+        if k >= tries or spent[0] >= budget_ms or (time.perf_counter() - t_start) * 1e3 >= wall_ms:
             return False
         free, _total = torch.cuda.mem_get_info(dev)
-        if free < block + (PLACE_SPACER if k else 0) + 16 * hbytes + (8 << 30):       # the rest of the job must still fit
+        if free < block + 16 * hbytes + (8 << 30):           # the rest of the job must still fit
             return False
+        t0 = time.perf_counter()
         try:
-            if k and PLACE_SPACER:
-                spacers.append(torch.empty(PLACE_SPACER, dtype=torch.int8, device=dev))
             cands.append(torch.empty(block, dtype=torch.int8, device=dev))
         except RuntimeError:
             return False
+        torch.cuda.synchronize(dev)
+        alloc_ms.append((time.perf_counter() - t0) * 1e3)
         ratios.append(probe(cands[-1], slices) / base)
         return True
 
@@ -252,7 +289,7 @@ def alloc_hist(X, N, S):
         if whole_ms[pick] < whole_ms[0] * (1.0 - PLACE_WIN):
             break
         excluded.append(pick)
-        if len(excluded) >= 3 or spent[0] >= 2 * PLACE_BUDGET_MS:
+        if len(excluded) >= 3 or spent[0] >= 2 * budget_ms:
             pick = 0
             break
         pick, verdict = place_decide(ratios, excluded)
@@ -261,19 +298,20 @@ def alloc_hist(X, N, S):
         pick = 0
     good = pick != 0
     report = {"probe": "k_bin_hist over 3 x %d bins of the matrix: with the H store into a candidate / counts only; candidate 0 is the plain "
-                       "allocation, the others heads of %d GiB blocks %d GiB apart" % (slices[0][1] - slices[0][0], block >> 30, (block + PLACE_SPACER) >> 30),
+                       "allocation, the others heads of %d GiB blocks allocated one after the other" % (slices[0][1] - slices[0][0], block >> 30),
               "decision": verdict if good else "plain allocation kept (%s)" % verdict, "good": good, "picked": pick, "ratio": round(ratios[pick], 3),
               "ratios": [round(r, 3) for r in ratios], "whole_matrix_ms": {str(i): round(v, 4) for i, v in whole_ms.items()},
-              "lost_over_the_whole_matrix": excluded, "blocks_tried": len(cands) - 1, "walked_GiB": round((sum(c.numel() for c in cands[1:]) + sum(x.numel() for x in spacers)) / 2**30, 1),
+              "lost_over_the_whole_matrix": excluded, "blocks_tried": len(cands) - 1,
+              "walked_GiB": round(sum(c.numel() for c in cands[1:]) / 2**30, 1),
+              "block_alloc_ms": [round(a, 1) for a in alloc_ms],
               "rules": {"sure_at_or_under": PLACE_SURE, "two_levels_apart_by": PLACE_GAP, "must_beat_plain_by": PLACE_WIN,
-                        "max_blocks": PLACE_TRIES, "max_probe_ms": PLACE_BUDGET_MS},
-              "ms_counts_only": round(base, 4), "probe_device_ms": round(spent[0], 2), "reuses": 0,
-              "left_in_torch_cache_GiB": round((sum(c.numel() for i, c in enumerate(cands) if i and i != pick) + sum(x.numel() for x in spacers)) / 2**30, 1)}
+                        "max_blocks": tries, "max_probe_ms": budget_ms, "max_wall_ms": wall_ms},
+              "ms_counts_only": round(base, 4), "probe_device_ms": round(spent[0], 2),
+              "left_in_torch_cache_GiB": round(sum(c.numel() for i, c in enumerate(cands) if i and i != pick) / 2**30, 1)}
     home = cands[pick] if good else None
-    _placement[dev.index] = {"key": key, "home": home, "report": report, "stream": torch.cuda.current_stream()}
-    del cands, spacers                                       # spacers and losing blocks -> torch's cache (not the driver)
+    del cands                                                # losing blocks -> torch's cache (not the driver)
     report["search_ms"] = round((time.perf_counter() - t_start) * 1e3, 2)
-    return view(home) if good else h_plain
+    return home, h_plain, report
 
 
 def placement_report(device=None):

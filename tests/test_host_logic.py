@@ -568,14 +568,15 @@ def test_get_num_states_counts_whitespace_only_lines_like_pandas(tmp_path):
 
 
 def test_placement_decision_on_faked_ratio_sequences(monkeypatch):
-    """engine.alloc_hist's search on the host with the probe faked.  Candidate 0 is the PLAIN allocation the search replaces, the
-    others are blocks further along the driver's memory; the decision is RELATIVE (two levels of the ratio >= 3 % apart: the lower
-    one is another memory class), BOUNDED (eight blocks, 50 ms of probes) and settled by ONE comparison over the whole matrix
-    against the plain allocation -- the placed cache is never slower than what it replaces.  Sequences: a first block that is
-    clearly good; a run of the matrix's own class with a good block behind it; a walk that only ever sees one level (bounded at
-    eight, the plain allocation stays); the driver's round-5 box (a block that passes its slices at 1.105 and loses over the
-    whole matrix, 1.174: the matrix straddles there); a plain allocation that already lies in another class; +-1 % of clock wobble
-    inside a level."""
+    """engine.alloc_hist's searches on the host with the probe faked.  The first job on a matrix gets a plain allocation and no
+    search, the second the QUICK search (eight blocks, 50 ms), the fourth -- if the plain allocation was kept -- the DEEP one
+    (24 blocks), once.  Candidate 0 is the PLAIN allocation the search replaces; the decision is RELATIVE (two levels of the ratio
+    >= 3 % apart: the lower one is another memory class) and settled by ONE comparison over the whole matrix against the plain
+    allocation -- the placed cache is never slower than what it replaces.  Sequences: a first block that is clearly good; a run
+    of the matrix's own class with a good block behind it; a walk that only ever sees one level (bounded, the plain allocation
+    stays, the deep search finds the block behind it); the driver's round-5 box (a block that passes its slices at 1.105 and
+    loses over the whole matrix, 1.174: the matrix straddles there); a plain allocation that already lies in another class;
+    +-1 % of clock wobble inside a level."""
     import torch
     from epilogos_amd import engine
     order = {}
@@ -583,15 +584,18 @@ def test_placement_decision_on_faked_ratio_sequences(monkeypatch):
     def level_of(t):
         return order.setdefault(t.untyped_storage().data_ptr(), len(order))
 
-    def run(levels, whole=None, R=4096, S=18, ldx=848):
-        """levels[k]: slice ratio of candidate k (0 = the plain allocation); whole[k]: its time over the whole matrix (default:
-        ratio + 0.02)."""
+    def run(levels, whole=None, jobs=None, R=4096, S=18, ldx=848):
+        """levels[k]: slice ratio of the k-th distinct candidate the searches touch (0 = the first plain allocation); whole[k]: its
+        time over the whole matrix (default: ratio + 0.02).  -> the report after `jobs` jobs on the matrix."""
         order.clear()
+        jobs = jobs or engine.PLACE_SEARCH_AT
         X = torch.zeros((R, ldx), dtype=torch.int8)
+        keep = []                                                         # (the host allocator must not hand a freed block out again)
 
         def fake_probe(X_, N_, S_, Hflat, counts, slices, reps=2):
             if Hflat is None:
                 return 1.0
+            keep.append(Hflat)
             k = level_of(Hflat)
             over_whole = slices == [(0, R)]
             return (whole or {}).get(k, levels[min(k, len(levels) - 1)] + 0.02) if over_whole else levels[min(k, len(levels) - 1)]
@@ -599,30 +603,43 @@ def test_placement_decision_on_faked_ratio_sequences(monkeypatch):
         monkeypatch.setattr(engine, "_probe_ms", fake_probe)
         monkeypatch.setattr(engine, "PLACE_MIN_BYTES", 1024)
         monkeypatch.setattr(engine, "PLACE_BLOCK", 1 << 16)
-        monkeypatch.setattr(engine, "PLACE_SPACER", 1 << 12)
         monkeypatch.setattr(engine, "placement_enabled", lambda: True)
         monkeypatch.setattr(engine, "_order_after_last_user", lambda st: None)
         monkeypatch.setattr(torch.cuda, "current_stream", lambda *a: None)
+        monkeypatch.setattr(torch.cuda, "synchronize", lambda *a: None)
         monkeypatch.setattr(engine, "_probe_slices", lambda R_, rows=0: [(0, 1024), (1024, 2048), (3072, 4096)])
         monkeypatch.setattr(torch.cuda, "mem_get_info", lambda dev=None: (1 << 40, 1 << 40))
         engine.release_placement()
-        H = engine.alloc_hist(X, ldx - 15, S)
-        rep = engine.placement_report(X.device) if X.device.index is not None else dict(engine._placement[None]["report"])
-        H2 = engine.alloc_hist(X, ldx - 15, S)                            # the same matrix again: no second search
-        rep2 = engine.placement_report(X.device) if X.device.index is not None else dict(engine._placement[None]["report"])
-        assert rep2["reuses"] + rep2.get("plain_while_home_in_use", 0) == 1 and rep2["search_ms"] == rep["search_ms"]
+        reps = []
+        for j in range(jobs):
+            H = engine.alloc_hist(X, ldx - 15, S)
+            assert H.shape == (R, S) and H.dtype == torch.int16
+            reps.append(engine.placement_report(X.device) if X.device.index is not None else dict(engine._placement[None]["report"]))
+            del H
         engine.release_placement()
-        assert H.shape == (R, S) and H.dtype == torch.int16 and H2.shape == (R, S)
-        assert rep["blocks_tried"] <= engine.PLACE_TRIES and rep["left_in_torch_cache_GiB"] >= 0 and "search_ms" in rep
-        assert rep["good"] == (rep["picked"] != 0)
+        assert reps[0] == {"jobs_seen": 1, "tier": "none yet"}             # the first job never searches
+        rep = reps[-1]
+        if "blocks_tried" in rep:
+            assert rep["left_in_torch_cache_GiB"] >= 0 and "search_ms" in rep and rep["good"] == (rep["picked"] != 0)
         return rep
 
     rep = run([1.17, 1.08])                                               # the first block is clearly another class: no walk
-    assert rep["good"] and rep["decision"] == "sure" and rep["blocks_tried"] == 1 and rep["picked"] == 1
+    assert rep["tier"] == "quick" and rep["good"] and rep["decision"] == "sure" and rep["blocks_tried"] == 1 and rep["picked"] == 1
+    rep = run([1.17, 1.08], jobs=6)                                       # ... and the later jobs reuse the home, no second search
+    assert rep["tier"] == "quick" and rep["reuses"] == 4 and rep["jobs_seen"] == 2
     rep = run([1.175, 1.17, 1.18, 1.13, 1.17])                            # 3.5 % under the run before it: two levels, no absolute level involved
     assert rep["good"] and rep["decision"] == "two-levels" and rep["blocks_tried"] == 3 and rep["picked"] == 3
-    rep = run([1.17, 1.165, 1.175, 1.168, 1.172, 1.17, 1.166, 1.174, 1.169, 1.08])   # one level, +-0.5 % of wobble: bounded at eight blocks
-    assert not rep["good"] and rep["blocks_tried"] == 8 and rep["picked"] == 0 and rep["decision"].startswith("plain allocation kept (one-level")
+    one_level = [1.17, 1.165, 1.175, 1.168, 1.172, 1.17, 1.166, 1.174, 1.169]     # one level, +-0.5 % of wobble ...
+    rep = run(one_level + [1.17] * 12 + [1.08])
+    assert not rep["good"] and rep["blocks_tried"] == engine.PLACE_TRIES and rep["picked"] == 0       # ... bounded at eight blocks: the plain allocation stays
+    assert rep["decision"].startswith("plain allocation kept (one-level")
+    rep = run(one_level + [1.17] * 12 + [1.08], jobs=3)                   # the third job: nothing new
+    assert rep["tier"] == "quick" and rep["jobs_seen"] == 3
+    rep = run(one_level + [1.17] * 12 + [1.08], jobs=engine.PLACE_DEEP_AT + 2)    # the fourth: the deep search, once, walks past the run
+    assert rep["tier"] == "deep" and rep["good"] and rep["decision"] == "sure" and 8 < rep["blocks_tried"] <= engine.PLACE_DEEP_TRIES
+    assert rep["quick"]["blocks_tried"] == engine.PLACE_TRIES and rep["reuses"] == 2
+    rep = run([1.17] * 60, jobs=engine.PLACE_DEEP_AT + 3)                 # no good block anywhere: both searches bounded, then never again
+    assert rep["tier"] == "deep" and not rep["good"] and rep["blocks_tried"] == engine.PLACE_DEEP_TRIES and rep["jobs_seen"] == engine.PLACE_DEEP_AT + 3
     rep = run([1.14, 1.105, 1.10], whole={0: 1.17, 1: 1.174, 2: 1.12})    # the driver's box of round 5: block 1 passes its slices ...
     assert rep["good"] and rep["picked"] == 2 and rep["lost_over_the_whole_matrix"] == [1]         # ... loses over the whole matrix, the walk goes on, block 2 wins
     rep = run([1.14, 1.09] + [1.145] * 8, whole={0: 1.17, 1: 1.19})       # sure on the slices, slower than the plain allocation over the whole matrix;

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""GPU box: engine.alloc_hist in a FRESH process -- the search's report, then k_bin_hist over the whole matrix with the histogram
-cache at the picked home, at every rejected candidate and at a plain allocation, and ten S1 jobs through the session.
+"""GPU box: engine.alloc_hist's policy in a FRESH process -- fourteen S1 jobs through the session on one resident matrix (job 1 plain,
+job 2 the quick search, job 4 the deep one if the plain allocation was kept), the wall time of every job, the search's report, then
+k_bin_hist over the whole matrix with the histogram cache where the jobs now have it and at a fresh plain allocation.
 usage: placement_check.py [--bins 15000000] [--procs 5]   (--procs > 1: that many child processes, one after the other;
 profiles/r05a_placement_spread.txt)"""
 import argparse
@@ -37,23 +38,9 @@ def one(bins, N, S):
         return round(float(np.median(ts)), 4)
 
     import time
-    t0 = time.perf_counter()
-    H = engine.alloc_hist(X, N, S)
-    torch.cuda.synchronize()
-    search_ms = (time.perf_counter() - t0) * 1e3
-    rep = engine.placement_report()
-    out = {"search_ms": round(search_ms, 2), "report": rep, "k1_counts_only_ms": k1(None), "k1_home_ms": k1(H)}
-    out["k1_plain_ms"] = k1(torch.empty((bins, S), dtype=torch.int16, device=dev))
-    del H
     be = backend.HipBackend(device=dev)
-
-    class D:
-        world = 1
-
-        def all_reduce_tensor(self, t):
-            pass
-    ts = []
-    for k in range(12):
+    ts, per_job = [], []
+    for k in range(14):                                          # the product's policy: job 1 plain, job 2 the quick search, job 4 the deep one if needed
         sess = be.open_single(S, 1)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -63,9 +50,14 @@ def one(bins, N, S):
         o = sess.scores_device(pid)
         torch.cuda.synchronize()
         ts.append((time.perf_counter() - t0) * 1e3)
+        per_job.append(round(ts[-1], 2))
         del o, sess
-    out["session_job_ms_median_of_last_10"] = round(float(np.median(ts[2:])), 4)
-    out["report_after"] = engine.placement_report()
+    rep = engine.placement_report()
+    H = engine.alloc_hist(X, N, S)                               # where the jobs' cache now lies (the home, or a plain allocation)
+    out = {"job_ms": per_job, "session_job_ms_median_of_last_8": round(float(np.median(ts[6:])), 4), "report": rep,
+           "k1_counts_only_ms": k1(None), "k1_home_ms": k1(H)}
+    del H
+    out["k1_plain_ms"] = k1(torch.empty((bins, S), dtype=torch.int16, device=dev))
     out["frac_home"] = round(bins * N / out["k1_home_ms"] / 1e6 / 8000, 4)
     print(json.dumps(out), flush=True)
 
