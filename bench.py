@@ -258,6 +258,21 @@ def bench_single(torch, be, d, sal, X, N, S, R, R_global, world, reps, fence):
                                       "frac": round(pairs / score_ms * 1e3 / LDS_GATHER_PEAK, 4),
                                       "what": "N (N - 1) table terms per bin against the chip's ds_read_b32 lane rate; the phase "
                                               "also holds the table build and the transpose"}}
+        # the kernel's memory side (the 990 MB fixed-point table is re-streamed once per group of workgroups that walk it together):
+        # FETCH_SIZE of the PMC pass of tools/profile_bench.sh on this kernel source and shape, when there is one
+        try:
+            rec = json.loads((ROOT / "profiles" / "hbm_traffic.json").read_text())
+            fb = rec.get("k_s3_score_bl_fetch_bytes_per_launch_%d_%d" % (R, N)) if rec.get("k1_source_sha") == k1_source_sha() else None
+        except Exception:
+            fb = None
+        if fb:
+            gbps = fb / score_ms / 1e6
+            out["roofline"]["scores"]["memory_side"] = {
+                "fetch_bytes_per_bin": round(fb / R), "fetch_GBps_over_the_score_phase": round(gbps, 1), "frac_of_hbm_peak": round(gbps / HBM_PEAK_GBPS, 4),
+                "table_passes": round(fb / (990e6 if N == 833 and S == 18 else max(fb, 1)), 1) if N == 833 and S == 18 else None,
+                "nearer_bound": "lds gathers" if out["roofline"]["scores"]["frac"] >= gbps / 6290.0 else "hbm (table stream)",
+                "what": "FETCH_SIZE x 1024 x 2 of k_s3_score_bl's launch (PMC pass, profiles/hbm_traffic.json) over the phase's device time; "
+                        "nearer_bound compares the gather fraction with the fetch rate over the 6.29 TB/s a copy reaches"}
     return out
 
 

@@ -415,6 +415,11 @@ int score_s3_lanes(const int8_t* X8, int64_t R, int32_t N, int64_t ldx, int32_t 
         hipLaunchKernelGGL(k_s3_score_bl<NP>, dim3((unsigned)(nslices * nchunk)), dim3(BL_THREADS), shmem, st, XT, Rp, (long)R, N, S, SI, chb, \
                            reinterpret_cast<const char*>(TQ), (int)nslices, reinterpret_cast<u64*>(acc), ahead, dbg);             \
     } while (0)
+    // (The kernel's MEMORY side, round 6: FETCH_SIZE says 195-209 KB per bin on 8-15 M bins -- the 990 MB table is streamed once per
+    // ~5000 bins, 3.2 TB/s over the launch: the workgroups that share an L2 do not stay within the ~90 phases of each other that
+    // its 4 MB can bridge.  One launch per 728 slices (1.05 M bins), which puts them back in step every 73 rounds, cuts that to
+    // 137 KB per bin and costs 1.3 % of time (924 against 912 ms per 15 M bins; groups of 364: 964 ms, of 2912: 910 ms) -- the gathers,
+    // not the table stream, are what the kernel waits for, so it stays one launch.  profiles/r06f_s3_score_launch_groups.txt.)
     if (npieces <= 16) BL_LAUNCH(16);
     else if (npieces <= 32) BL_LAUNCH(32);
     else if (npieces <= 43) BL_LAUNCH(43);

@@ -162,9 +162,10 @@ def alloc_hist(X, N, S):
 
     What the search may cost is tied to what it can earn (0.3 ms per 15 M-bin job):
       * job 1 on a matrix: no search, a plain allocation -- a command-line run (one job per matrix) never pays anything;
-      * job PLACE_SEARCH_AT: the QUICK search -- <= 8 blocks, <= 50 ms of probes, ~40 ms in all: 32 GiB past the matrix is
-        about what the driver hands out from its pool of cleared memory at 0.3 ms per block; the class boundary lies inside
-        that stretch for roughly a third of the fresh processes (it is 96 GB away at most, anywhere with equal odds);
+      * job PLACE_SEARCH_AT: the QUICK search -- <= 8 blocks, <= 50 ms of probes, ended by the first block the driver is slow to
+        hand out: 20-40 ms in all, 160 ms at worst.  About 32 GiB past the matrix come from the driver's pool of cleared memory
+        at 0.3 ms per block; the class boundary lies inside that stretch for roughly a third of the fresh processes (it is
+        96 GB away at most, anywhere with equal odds), and for another share the plain allocation is in another class already;
       * job PLACE_DEEP_AT, if the plain allocation was kept: the DEEP search, once -- <= 24 blocks (96 GiB, past any class),
         <= 5 s: beyond the cleared pool the driver takes ~30 ms per GiB to hand memory out, i.e. 1-3 s for the walk
         (tools/alloc_probe.py; profiles/r06d_*), which a process that keeps running jobs gets back and a single job does not.
@@ -220,18 +221,26 @@ def alloc_hist(X, N, S):
         return plain()
     deep = want == 2
     home, h_plain, report = _place_search(X, N, S, int(os.environ.get("EPILOGOS_PLACEMENT_TRIES", PLACE_DEEP_TRIES if deep else PLACE_TRIES)),
-                                          3 * PLACE_BUDGET_MS if deep else PLACE_BUDGET_MS, PLACE_DEEP_WALL_MS if deep else 10 * PLACE_BUDGET_MS)
+                                          3 * PLACE_BUDGET_MS if deep else PLACE_BUDGET_MS, PLACE_DEEP_WALL_MS if deep else 10 * PLACE_BUDGET_MS,
+                                          stop_at_slow_alloc=not deep)
     report.update(tier="deep" if deep else "quick", jobs_seen=st["seen"], reuses=0)
     if deep and "quick" not in report:
         report["quick"] = {k: st["report"].get(k) for k in ("decision", "ratios", "blocks_tried", "search_ms")}
+    if home is None and report["picked"] == 0 and report["decision"].startswith("plain allocation kept (sure"):
+        want = 2                                             # the plain allocation already lies in another class: nothing to look for
     st.update(home=home, report=report, stream=torch.cuda.current_stream(), tier=want)
     if home is None and eager and want == 1:
         return alloc_hist(X, N, S)                           # (eager: the deep search follows at once)
     return view(home) if home is not None else h_plain
 
 
-def _place_search(X, N, S, tries, budget_ms, wall_ms):
-    """One search of alloc_hist: -> (home block or None = the plain allocation stays, the plain allocation, report)."""
+PLACE_SLOW_ALLOC_MS = 20.0          # a 4 GiB block that takes longer to get comes from beyond the driver's pool of cleared memory
+
+
+def _place_search(X, N, S, tries, budget_ms, wall_ms, stop_at_slow_alloc=False):
+    """One search of alloc_hist: -> (home block or None = the plain allocation stays, the plain allocation, report).
+    stop_at_slow_alloc (the quick search): the walk ends with the first block the driver takes more than PLACE_SLOW_ALLOC_MS to
+    hand out -- every further one would cost the same ~120 ms."""
     import time
     R = X.shape[0]
     dev = X.device
@@ -251,13 +260,17 @@ def _place_search(X, N, S, tries, budget_ms, wall_ms):
     block = max(PLACE_BLOCK, (hbytes + 4095) // 4096 * 4096)
     h_plain = torch.empty((R, S), dtype=torch.int16, device=dev)
     cands, ratios = [h_plain.view(torch.int8).view(-1)], []
-    ratios.append(probe(cands[0], slices) / base)
+    t0 = probe(cands[0], slices)
+    base = min(base, probe(None, slices))                    # (the very first launches of a process run on a cold clock: the lower of two)
+    ratios.append(t0 / base)
     whole_ms, excluded, alloc_ms = {}, [], []
 
     def walk_on():
         """One more block, probed on the slices; False when a bound is reached."""
         k = len(cands) - 1
         if k >= tries or spent[0] >= budget_ms or (time.perf_counter() - t_start) * 1e3 >= wall_ms:
+            return False
+        if stop_at_slow_alloc and alloc_ms and alloc_ms[-1] > PLACE_SLOW_ALLOC_MS:
             return False
         free, _total = torch.cuda.mem_get_info(dev)
         if free < block + 16 * hbytes + (8 << 30):           # the rest of the job must still fit

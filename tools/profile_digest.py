@@ -106,7 +106,7 @@ if stats_all.exists():
     log = src / "stats_all.log"
     if log.exists():
         lines += ["```"] + [l for l in log.read_text().splitlines() if l.startswith(("S2", "S3", "paired", "pair_", "quiescent"))] + ["```", ""]
-traffic = {}
+traffic, traffic_max = {}, {}
 for cname in ("fetch", "write"):
     f = src / cname / "p_counter_collection.csv"
     if not f.exists():
@@ -129,6 +129,7 @@ for cname in ("fetch", "write"):
         m = sum(v) / len(v)
         b = m * 1024 * (2 if cname == "fetch" else 1)
         traffic.setdefault(k, {})[c] = b
+        traffic_max.setdefault(k, {})[c] = max(v) * 1024 * (2 if cname == "fetch" else 1)
         lines.append("| `%s` | %s | %.1f | %.4g |" % (k, c, m, b))
     lines.append("")
 if bench and traffic:
@@ -146,6 +147,13 @@ if bench and traffic:
         d["k1_source_sha"] = _bench.k1_source_sha()
         d["k_bin_hist_bytes_per_launch_%d_%d" % (R, N)] = total
         d["source"] = "profiles/%s_summary.md: FETCH_SIZE*1024*2 (gfx950 wide-read correction, MI355X_MICROARCH.md HBM section) + WRITE_SIZE*1024, separate --pmc passes" % label
+        # the memory side of the S3 score kernel: its largest launch of the pass is config s3's (the whole genome); bench.py puts the
+        # figure next to the LDS-gather roofline of configs.s3
+        s3k = [x for x in traffic_max if "k_s3_score_bl" in x]
+        s3bins = ((bench.get("configs") or {}).get("s3") or {}).get("bins_per_gpu")
+        if s3k and s3bins:
+            d["k_s3_score_bl_fetch_bytes_per_launch_%d_%d" % (s3bins, N)] = traffic_max[s3k[0]].get("FETCH_SIZE")
+            d["k_s3_score_bl_write_bytes_per_launch_%d_%d" % (s3bins, N)] = traffic_max[s3k[0]].get("WRITE_SIZE")
         tfile.write_text(json.dumps(d, indent=1) + "\n")
         lines += ["k_bin_hist HBM traffic per launch: %.4g B vs algorithmic %d x %d = %.4g B read (+ %.4g B of H written)"
                   % (total, R, N, R * N, R * 36.0), ""]
