@@ -159,7 +159,12 @@ def _aligned_rows(T, lo, hi):
     (epg_s1.hip check_score_from_hist_args, epg_null.hip, epg_s2.hip), and a row slice of an [R, S] uint16 array starts at
     lo * S * 2 bytes -- a view only when that is a multiple of 16, else a copy of just these rows."""
     t = T[lo:hi]
-    return t if t.data_ptr() % 16 == 0 else t.clone()
+    if t.data_ptr() % 16 == 0 and t.untyped_storage().nbytes() <= 4 * max(t.numel() * t.element_size(), 1):
+        return t
+    # a copy of just these rows: a misaligned slice -- or one that would keep alive an allocation several times its size (the
+    # histograms of a whole batch of parts come from ONE allocation, engine.hist_rows_alloc: a rank that hands most of a batch
+    # over to its neighbours and drops it must not keep all of it for the few rows it scores itself)
+    return t.clone()
 
 
 class _HipSession:
