@@ -440,7 +440,7 @@ def test_bench_gpus_flag_from_a_plain_start(tmp_path):
     assert len(pr["k_bin_hist_ms"]) == 2 and pr["k_bin_hist_ms_min_max"][0] <= pr["k_bin_hist_ms_min_max"][1]
     assert pr["skew_ms_per_step"] >= 0 and len(pr["own_ms_per_step"]) == 2
     assert line["allreduce_probe"]["world"] == 2
-    assert line["config"]["step_path"].startswith("session: add_device -> all_reduce -> launch") and line["s1_table"]["built_on"].startswith("device")
+    assert line["config"]["step_path"].startswith("backend._HipSingleSession: add_device(X, N) -> all_reduce -> launch") and line["s1_table"]["built_on"].startswith("device")
     # one GPU: unchanged contract, plus both S1 paths on the genome and on the shard
     one = subprocess.run([sys.executable, str(root / "bench.py"), "--steps", "3", "--warmup", "1", "--bins", "400000", "--shard-bins", "50000",
                           "--no-cpu-baseline", "--configs", "none", "--placement-experiment", "0"], env=env, capture_output=True, text=True,

@@ -15,7 +15,7 @@ lines = ["# rocprofv3 summary %s (MI355X, `python bench.py --steps 20 --warmup 3
 bench = None
 bj = src / "bench.json"
 if bj.exists() and bj.read_text().strip():
-    bench = json.loads(bj.read_text().strip().splitlines()[-1])
+    bench = json.loads([l for l in bj.read_text().splitlines() if l.startswith("{")][-1])
     (dst / ("%s_bench.json" % label)).write_text(json.dumps(bench, indent=1) + "\n")
     lines += ["## un-profiled bench line", "", "```json", json.dumps(bench), "```", ""]
 stats = src / "stats" / "p_kernel_stats.csv"
