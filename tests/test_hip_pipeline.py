@@ -48,6 +48,47 @@ def test_cli_single_s1_real_slice(tmp_path, golden_real):
     assert not (out / "exp_freq_in10_s1.npy").exists()
 
 
+def test_cli_single_s1_on_input_only_pandas_reads(tmp_path, golden_real, capsys):
+    """The golden slice written the way pandas (the reference's parser, helpers.py:152-155) reads it and the strict native parser
+    does not -- a blank line in the middle, "+7", " 7", "7.0" -- next to a clean second file: the command line re-reads the one
+    file through pandas (into the staging buffer the native attempt had already taken), says so, and writes the reference's text for
+    both files."""
+    from click.testing import CliRunner
+    from epilogos_amd.run import main
+    g = golden_real
+    ind, out = tmp_path / "in10", tmp_path / "out"
+    ind.mkdir()
+    write_tsv(ind / "matrix_chr1.txt", g["x"], start0=int(g["start0"]))
+    lines = (ind / "matrix_chr1.txt").read_text().split("\n")
+    assert lines[-1] == ""
+    for r, form in ((3, "+{}"), (700, " {}"), (1500, "{}.0")):
+        f = lines[r].split("\t")
+        f[5] = form.format(f[5])
+        lines[r] = "\t".join(f)
+    lines.insert(1000, "")                                             # a blank line inside the file
+    (ind / "matrix_chr1.txt").write_text("\n".join(lines))
+    write_tsv(ind / "matrix_chr2.txt", g["x"][:500], chrom="chr2")
+    meta = tmp_path / "metadata.tsv"
+    from tests.conftest import load_golden
+    names = load_golden("roi.npz")["state_names"]
+    meta.write_text("zero_index\tone_index\tshort_name\n" + "".join("%d\t%d\t%s\n" % (i, i + 1, names[i]) for i in range(S)))
+    res = CliRunner().invoke(main, ["-l", "-i", str(ind), "-j", str(meta), "-o", str(out)])
+    assert res.exit_code == 0, res.output
+    assert "through pandas" in res.output and res.output.count("through pandas") == 1
+    # the same two files, clean: identical outputs
+    ind2, out2 = tmp_path / "clean" / "in10", tmp_path / "out2"
+    ind2.mkdir(parents=True)
+    write_tsv(ind2 / "matrix_chr1.txt", g["x"], start0=int(g["start0"]))
+    write_tsv(ind2 / "matrix_chr2.txt", g["x"][:500], chrom="chr2")
+    res2 = CliRunner().invoke(main, ["-l", "-i", str(ind2), "-j", str(meta), "-o", str(out2)])
+    assert res2.exit_code == 0 and "through pandas" not in res2.output
+    for name in ("scores_in10_s1_matrix_chr1.txt.gz", "scores_in10_s1_matrix_chr2.txt.gz"):
+        with gzip.open(out / name, "rb") as a, gzip.open(out2 / name, "rb") as b:
+            ta, tb = a.read(), b.read()
+        assert ta == tb and ta.count(b"\n") == (2048 if "chr1" in name else 500)
+    assert (out / "regionsOfInterest_in10_s1.txt").read_text() == (out2 / "regionsOfInterest_in10_s1.txt").read_text()
+
+
 @pytest.mark.parametrize("sal", [1, 2])
 def test_stage_drivers_hip(tmp_path, golden_real, sal):
     from epilogos_amd import expected, expectedCombination, scores

@@ -70,7 +70,7 @@ if trace.exists() and bench:
         sy = [d for _, d in tsum(lambda n: "k_s3_syrk_fp4" in n, 0) if d > 1e6][-reps:]
         sc = [d for _, d in tsum(lambda n: "k_s3_score_bl" in n, reps)]
         if sy and sc:
-            lines += ["config s3 (%d bins): `k_s3_syrk_fp4` %.2f ms per launch (one per 1 M-bin chunk of the operand) and `k_s3_score_bl` %.2f ms per call in the trace (last %d); bench "
+            lines += ["config s3 (%d bins): `k_s3_syrk_fp4` %.2f ms per launch (one per 2 M-bin chunk of the operand; the gated-off launches of the other contraction return after microseconds and pull the average down: see the MAX column) and `k_s3_score_bl` %.2f ms per call in the trace (last %d); bench "
                       "line phases (events, incl. operand build / reconstruction resp. table build / transpose): expected %.2f ms, scores %.2f ms"
                       % (cfg["s3"]["bins_total"], sum(sy) / len(sy) / 1e6, sum(sc) / len(sc) / 1e6, reps, cfg["s3"]["phases_ms"]["expected"],
                          cfg["s3"]["phases_ms"]["scores"]), ""]
