@@ -313,6 +313,7 @@ int hist_s3_impl(const int8_t* X8, int64_t R, int32_t N, int64_t ldx, int32_t S,
     if (S > 127) return fail(EPG_ERR_UNSUPPORTED, "hist_s3: S=%d > 127 (states are int8)", S);
     if (R == 0) return EPG_OK;
     if (!X8 || !counts) return fail(EPG_ERR_INVALID_ARG, "hist_s3: NULL argument");
+    if (ws && (reinterpret_cast<uintptr_t>(ws) & 15)) return fail(EPG_ERR_INVALID_ARG, "hist_s3: the workspace must be 16-byte aligned");
     if (S > 31) return wide_hist_s3(X8, R, N, ldx, S, counts, st);                      // the wide models: epg_wide.hip
     // matrix-core path (epg_s3_gemm.hip: the precomputed one-hot fp4 contraction) when the caller's workspace holds the transposed
     // matrix and at least a 16 K-bin chunk of the operand (S <= 30: padding rows use pattern 30); the LDS-counter kernel below is
@@ -339,6 +340,7 @@ int score_s3_impl(const int8_t* X8, int64_t R, int32_t N, int64_t ldx, int32_t S
     if (S > 127) return fail(EPG_ERR_UNSUPPORTED, "score_s3: S=%d > 127 (states are int8)", S);
     if (R == 0) return EPG_OK;
     if (!X8 || !q || !ws) return fail(EPG_ERR_INVALID_ARG, "score_s3: NULL argument");
+    if (reinterpret_cast<uintptr_t>(ws) & 15) return fail(EPG_ERR_INVALID_ARG, "score_s3: the workspace must be 16-byte aligned");
     if (S > 31) return wide_score_s3(X8, R, N, ldx, S, q, out64, out32, ws, ws_bytes, st);   // the wide models: epg_wide.hip
     // default: the biosample-lane kernel (epg_s3_lanes.hip, S <= 21) when the workspace holds its table; k_s3_score below is the
     // path for S > 21 and smaller workspaces (epg_test_force(1, 1): on any shape).  Round 3's modal-state kernel (per-biosample base

@@ -13,38 +13,11 @@
 
 namespace epg {
 
-__global__ __launch_bounds__(256) void k_transpose_states(const char* __restrict__ X, long R, int N, long ldx, int S,
-                                                           char* __restrict__ XT, long Rp, int shift, int bad, int* __restrict__ dirty) {
-    __shared__ unsigned char tile[64][65];
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    const long b0 = (long)blockIdx.x * 64;
-    const int s0 = blockIdx.y * 64;
-    bool seen_bad = false;                            // a byte of the matrix proper that is not a state
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const long bin = b0 + ty + 4 * i;
-        const int smp = s0 + tx;
-        unsigned char v = (unsigned char)bad;         // "not a state": bins past R, states outside [0, S)
-        if (bin < R && smp < N) {
-            v = (unsigned char)X[bin * ldx + smp];
-            if (v >= S) { v = (unsigned char)bad; seen_bad = true; }
-        }
-        tile[ty + 4 * i][tx] = (unsigned char)(v << shift);
-    }
-    if (dirty && __any(seen_bad) && (threadIdx.x & 63) == 0) atomicOr(dirty, 1);
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const int smp = s0 + ty + 4 * i;
-        const long bin = b0 + tx;
-        if (smp < N && bin < Rp) XT[(long)smp * Rp + bin] = (char)tile[tx][ty + 4 * i];
-    }
-}
-
-// The same transpose with 16-byte global accesses (round 5): a thread loads 16 state bytes of one bin, the tile goes through LDS, a
-// thread stores 16 bins of one biosample.  The byte-per-thread form above moved 25 GB at 1.25 TB/s (20 ms per transpose of the
-// 15 M-bin genome, two per S3 job).  Needs rows of at least N bytes readable in 16-byte pieces: a piece that would reach past the
-// row pitch is read byte by byte.
+// The transpose with 16-byte global accesses (round 5): a thread loads 16 state bytes of one bin, the tile goes through LDS, a
+// thread stores 16 bins of one biosample.  (The byte-per-thread form of rounds 1-4 moved 25 GB at 1.25 TB/s, 20 ms per transpose of
+// the 15 M-bin genome, two per S3 job; it stayed as the path for a misaligned XT until round 6 -- which no workspace this library
+// lays out produces: the S3 entry points now refuse a workspace that is not 16-byte aligned, and the kernel is gone.)  Needs rows
+// of at least N bytes readable in 16-byte pieces: a piece that would reach past the row pitch is read byte by byte.
 __global__ __launch_bounds__(256) void k_transpose_states16(const char* __restrict__ X, long R, int N, long ldx, int S,
                                                              char* __restrict__ XT, long Rp, int shift, int bad, int* __restrict__ dirty) {
     constexpr int LD = 68;                            // tile row pitch in bytes: 17 dwords, the four 16-bin groups fall on different banks
@@ -116,14 +89,12 @@ int64_t s3_xt_bytes(int64_t R, int N) { return align_up((int64_t)N * align_up(R,
 // `dirty` (optional, device int, caller-zeroed): set to 1 when a byte of the first N columns of a row < R is not a state
 int transpose_states_flag(const char* X, int64_t R, int32_t N, int64_t ldx, int32_t S, char* XT, int64_t Rp, int shift, int bad, int* dirty,
                           hipStream_t st) {
-    // 16-byte stores need XT rows that start 16-byte aligned (Rp a multiple of 16, an aligned base): always so for the workspaces
-    // this library lays out; anything else takes the byte-per-thread kernel
-    if (Rp % 16 == 0 && (reinterpret_cast<uintptr_t>(XT) & 15) == 0)
-        hipLaunchKernelGGL(k_transpose_states16, dim3((unsigned)(((Rp + 63) / 64) * ((N + 63) / 64))), dim3(256), 0, st, X, (long)R, N,
-                           (long)ldx, S, XT, (long)Rp, shift, bad, dirty);
-    else
-        hipLaunchKernelGGL(k_transpose_states, dim3((unsigned)((Rp + 63) / 64), (unsigned)((N + 63) / 64)), dim3(256), 0, st, X, (long)R, N,
-                           (long)ldx, S, XT, (long)Rp, shift, bad, dirty);
+    // 16-byte stores need XT rows that start 16-byte aligned (Rp a multiple of 16, an aligned base): so for every workspace this
+    // library lays out (hist_s3_impl / score_s3_impl refuse a misaligned one)
+    if (Rp % 16 != 0 || (reinterpret_cast<uintptr_t>(XT) & 15) != 0)
+        return fail(EPG_ERR_INVALID_ARG, "transpose_states: the transposed matrix must be 16-byte aligned with a pitch that is a multiple of 16");
+    hipLaunchKernelGGL(k_transpose_states16, dim3((unsigned)(((Rp + 63) / 64) * ((N + 63) / 64))), dim3(256), 0, st, X, (long)R, N,
+                       (long)ldx, S, XT, (long)Rp, shift, bad, dirty);
     EPG_LAUNCH_CHECK("k_transpose_states");
     return EPG_OK;
 }

@@ -106,7 +106,8 @@ int epg_normalise_i64(const int64_t* counts, int64_t n, float* q, void* ws, int6
 int epg_normalise_i32(const int32_t* counts, int64_t n, float* q, void* ws, int64_t ws_bytes, void* stream);
 
 /* ---- score pass (STEP 3) ------------------------------------------------------------------------------------
- * Workspace size in bytes for the score calls of a given saliency (device memory, caller-allocated). */
+ * Workspace size in bytes for the score calls of a given saliency (device memory, caller-allocated; the S3 entry points want it
+ * 16-byte aligned -- any device allocation is -- and return EPG_ERR_INVALID_ARG otherwise). */
 int64_t epg_ws_bytes(int32_t saliency, int64_t R, int32_t N, int32_t S);
 
 /* S1: score[b, s] = kl(h[b,s]/N, q[s]), kl(p, q) = p*log2(p/q), 0 where q == 0 or p == 0

@@ -63,6 +63,11 @@ def test_direct_calls_match_oracle(abi):
     with pytest.raises(abi.EpilogosHipError) as e:
         abi.call("epg_bin_hist", _p(X), R, N, N - 1, S, None, _p(c1), st)
     assert e.value.code == -1
+    ws3 = torch.empty(int(abi.call("epg_ws_bytes", 3, R, N, S)) + 64, dtype=torch.uint8, device="cuda")
+    for name, args in (("epg_hist_s3", (_p(c3),)), ("epg_score_s3", (_p(q3), None, _p(torch.empty((R, S), device="cuda"))))):
+        with pytest.raises(abi.EpilogosHipError) as e:                          # an S3 workspace that is not 16-byte aligned is refused
+            abi.call(name, _p(X), R, N, ldx, S, *args, C.c_void_p(ws3.data_ptr() + 8), ws3.numel() - 64, st)
+        assert e.value.code == -1 and "aligned" in str(e.value)
     with pytest.raises(abi.EpilogosHipError) as e:
         abi.call("epg_bin_hist", _p(X), R, N, ldx, 128, None, _p(c1), st)      # states are int8: 127 is the largest model
     assert e.value.code == -2
