@@ -779,6 +779,10 @@ def main():
 
     if use_session:
         step_session(X)                                                    # untimed: sanity of one whole job
+        # engine.alloc_hist searches at the 2nd and (if needed) the 4th job on a matrix: whatever --warmup says, they are over
+        # before the timed steps
+        for _ in range(max(0, engine.PLACE_DEEP_AT + 1 - (1 + args.warmup))):
+            step_session(X)
     else:
         step_engine(X, H, out32, keep=True)
     dt, ev, host_t, own_dt = timed_steps(X, H, out32, args.steps, args.warmup, graph=args.graph,
