@@ -292,9 +292,11 @@ def bench_single(torch, be, d, sal, X, N, S, R, R_global, world, reps, fence):
             out["roofline"]["scores"]["memory_side"] = {
                 "fetch_bytes_per_bin": round(fb / R), "fetch_GBps_over_the_score_phase": round(gbps, 1), "frac_of_hbm_peak": round(gbps / HBM_PEAK_GBPS, 4),
                 "table_passes": round(fb / (990e6 if N == 833 and S == 18 else max(fb, 1)), 1) if N == 833 and S == 18 else None,
-                "nearer_bound": "lds gathers" if out["roofline"]["scores"]["frac"] >= gbps / 6290.0 else "hbm (table stream)",
-                "what": "FETCH_SIZE x 1024 x 2 of k_s3_score_bl's launch (PMC pass, profiles/hbm_traffic.json) over the phase's device time; "
-                        "nearer_bound compares the gather fraction with the fetch rate over the 6.29 TB/s a copy reaches"}
+                "frac_of_copy_rate": round(gbps / 6290.0, 4),
+                "what": "FETCH_SIZE x 1024 x 2 of k_s3_score_bl's launch (PMC pass, profiles/hbm_traffic.json) over the phase's device time, "
+                        "against the 8 TB/s spec and the 6.29 TB/s a copy reaches: as large a fraction of its ceiling as the gathers are of "
+                        "theirs.  Which one the kernel waits for was measured (profiles/r06f_s3_score_launch_groups.txt): 35 % less fetch "
+                        "(one launch per 1 M bins) made it 1.3 % slower -- the gathers bind, the table stream is next"}
     return out
 
 

@@ -168,7 +168,7 @@ def alloc_hist(X, N, S):
         96 GB away at most, anywhere with equal odds), and for another share the plain allocation is in another class already;
       * job PLACE_DEEP_AT, if the plain allocation was kept: the DEEP search, once -- <= 24 blocks (96 GiB, past any class),
         <= 5 s: beyond the cleared pool the driver takes ~30 ms per GiB to hand memory out, i.e. 1-3 s for the walk
-        (tools/alloc_probe.py; profiles/r06d_*), which a process that keeps running jobs gets back and a single job does not.
+        (tools/alloc_probe.py; profiles/r06d_alloc_probe.txt), which a process that keeps running jobs gets back and a single job does not.
     A block that wins is the device's HOME for the life of the process (H is a view of its head): later jobs on the same
     matrix get it without a probe, a job on another matrix after one probe.  The other blocks go back to torch's caching
     allocator (not to the driver: freed device memory is scrubbed in the background at every HBM-bound kernel's expense; torch
