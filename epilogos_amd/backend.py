@@ -362,9 +362,24 @@ class _HipSession:
         return self.q.cpu().numpy().reshape(shape)
 
 
+_PENDING = object()                                      # a part whose count pass has not been launched yet (see _HipSingleSession._flush)
+
+
 class _HipSingleSession(_HipSession):
+    def __init__(self, be, S, saliency):
+        super().__init__(be, S, saliency)
+        self._pending, self._pending_rows = [], 0        # S1: (pid, X, N) of part-sized matrices waiting for their ONE count launch
+        self._batches = []                               # S1: {"pids", "flat", "starts", "rows", "N"} of the batches counted so far
+
     def add_part(self, arr, N, ticket):
         return self.add_device(self._upload(arr, N, ticket), N)
+
+    # S1 parts of less than a GiB -- the chromosome files of a genome -- are COUNTED IN BATCHES: one epg_bin_hist_parts launch per
+    # 8 M rows or 32 parts (or when anything needs their histograms), histograms in one flat allocation, and later ONE score
+    # launch over that allocation.  Per part this was 24 count launches and 24 score launches of 0.1-0.25 ms with their ramps and
+    # tails: 3.42 ms per 15 M-bin genome against 2.6 ms as one matrix (bench.py s1_paths, round 6); in batches the same job
+    # is two count launches and two score launches.  Same integers, same float32 scores.
+    BATCH_ROWS, BATCH_PARTS = 8_000_000, 32
 
     def add_device(self, X, N, place=None):
         """Count pass over a RESIDENT part -- the ONE entry of the command line (add_part, after its upload), of bench.py and of
@@ -379,6 +394,13 @@ class _HipSingleSession(_HipSession):
         self.N = max(getattr(self, "N", 0) or 0, N or 0)  # (an empty file has no width)
         if X.shape[0] == 0 or not N:                     # an empty part: nothing to count, and the ABI rejects a zero width
             self.parts.append(self.torch.empty((0, S), dtype=self.torch.int16, device=self.device) if self.sal < 3 else X)
+            return len(self.parts) - 1
+        if self.sal == 1 and place is None and X.numel() < eng.PLACE_MIN_BYTES and os.environ.get("EPILOGOS_SINGLE_BATCH", "1") != "0":
+            self.parts.append(_PENDING)
+            self._pending.append((len(self.parts) - 1, X, N))
+            self._pending_rows += X.shape[0]
+            if self._pending_rows >= self.BATCH_ROWS or len(self._pending) >= self.BATCH_PARTS:
+                self._flush()
             return len(self.parts) - 1
         if self.sal == 1:
             H, _ = eng.bin_hist(X, N, S, counts=self._acc(S), H=eng.alloc_hist(X, N, S) if place is not False else None)
@@ -399,15 +421,32 @@ class _HipSingleSession(_HipSession):
             raise ValueError("Please ensure that saliency metric is either 1, 2, or 3")
         return len(self.parts) - 1
 
+    def _flush(self):
+        """The count pass of the pending S1 parts: one launch (per schedule class of their widths), histograms from one allocation."""
+        if not self._pending:
+            return
+        eng, S = self.eng, self.S
+        batch, self._pending, self._pending_rows = self._pending, [], 0
+        rows = [X.shape[0] for _pid, X, _n in batch]
+        flat, starts = eng.hist_rows_flat(rows, S, self.device)
+        Hs = [flat[a:a + r] for a, r in zip(starts, rows)]
+        eng.bin_hist_parts([X for _pid, X, _n in batch], [n for _pid, _X, n in batch], S, counts=self._acc(S), Hs=Hs)
+        for (pid, _X, _n), H in zip(batch, Hs):
+            self.parts[pid] = H
+        if len({n for _pid, _X, n in batch}) == 1:       # (one group width: the batch can be scored in one launch too)
+            self._batches.append({"pids": [pid for pid, _X, _n in batch], "flat": flat, "starts": starts, "rows": rows, "N": batch[0][2]})
+
     # ---- multi-rank hand-over (driver._redistribute): a part is what the score pass reads -- per-bin histograms (S1, S2)
     # or state rows (S3)
     n_export = 1
 
     def slice_part(self, pid, lo, hi, row0=None):
+        self._flush()
         self.parts.append(_aligned_rows(self.parts[pid], lo, hi))
         return len(self.parts) - 1
 
     def export_rows(self, pid, lo, hi):
+        self._flush()
         return [self.parts[pid][lo:hi]]
 
     def import_rows(self, tensors, N, row0=None):
@@ -416,12 +455,22 @@ class _HipSingleSession(_HipSession):
         return len(self.parts) - 1
 
     def drop_part(self, pid):
+        self._flush()
         self.parts[pid] = None
 
     def ensure_acc(self, N):
+        self._flush()
         S = self.S                                       # a rank without bins still takes part in the all-reduce
         self.N = N
         self._acc({1: S, 2: S * S, 3: N * N * S * S}[self.sal], self.torch.int32 if self.sal == 3 else None)
+
+    def all_reduce(self, d):
+        self._flush()
+        super().all_reduce(d)
+
+    def finish_device(self, total_rows, N):
+        self._flush()
+        return super().finish_device(total_rows, N)
 
     def finish(self, total_rows, N):
         S = self.S
@@ -430,6 +479,7 @@ class _HipSingleSession(_HipSession):
 
     def scores_device(self, pid, keep=False):
         """float32 [R, S] scores of part `pid` from its resident data, as a device tensor."""
+        self._flush()
         eng, S, N = self.eng, self.S, self.N
         D = self.parts[pid]
         if not keep:
@@ -452,11 +502,27 @@ class _HipSingleSession(_HipSession):
         return [getattr(self, "N", None)]
 
     def _begin(self, pids):
-        self._early = {pid: self.scores_device(pid, keep=True) for pid in pids if self.parts[pid] is not None}
+        self._flush()
+        want = [pid for pid in pids if self.parts[pid] is not None]
+        self._early = {}
+        asked = set(want)
+        for b in self._batches:
+            # a batch whose parts are all asked for and still hold the rows the count pass left: ONE score launch over its flat
+            # histogram buffer, the parts' scores are views of one flat result
+            if self.sal == 1 and b["N"] == self.N and all(pid in asked and self.parts[pid] is not None and self.parts[pid].shape[0] == r
+                                                          and self.parts[pid].data_ptr() == b["flat"][a:].data_ptr()
+                                                          for pid, a, r in zip(b["pids"], b["starts"], b["rows"])):
+                o32 = self._score_s1(b["flat"], self.N)
+                for pid, a, r in zip(b["pids"], b["starts"], b["rows"]):
+                    self._early[pid] = o32[a:a + r]
+        for pid in want:
+            if pid not in self._early:
+                self._early[pid] = self.scores_device(pid, keep=True)
 
     def _settle(self):
         for pid in self._early:                          # verified: the resident data of the scored parts can go
             self.parts[pid] = None
+        self._batches = [b for b in self._batches if any(self.parts[pid] is not None for pid in b["pids"])]
 
     def early_scores(self, pid):
         """Device tensor of a part scored by launch() (bench.py: the scores stay in HBM)."""

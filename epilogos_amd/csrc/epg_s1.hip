@@ -302,6 +302,9 @@ __global__ __launch_bounds__(LDS_T ? 1024 : 256) void k_score_s1_from_hist(const
         __syncthreads();
         T = Ts;
     }
+    // a count is looked up when it is in 1 .. N (N = nent / S - 1); 0 scores 0 (scores.py:550), and so does anything larger: the
+    // rows between the parts of a batch's flat histogram buffer (engine.hist_rows_flat) are never written by the count pass
+    const u32 cmax = (u32)(nent / S - 1);
     const long nquads = total >> 2;
     const long stride = (long)gridDim.x * blockDim.x;
     long qd = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -320,7 +323,7 @@ __global__ __launch_bounds__(LDS_T ? 1024 : 256) void k_score_s1_from_hist(const
             OT v[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                v[k] = c[k] ? T[(long)c[k] * S + s] : (OT)0;
+                v[k] = c[k] - 1u < cmax ? T[(long)c[k] * S + s] : (OT)0;
                 s = s + 1 == S ? 0 : s + 1;
             }
             // non-temporal: nobody on the device reads the scores again (store_staged_nt, epg_common.h)
@@ -341,14 +344,14 @@ __global__ __launch_bounds__(LDS_T ? 1024 : 256) void k_score_s1_from_hist(const
         int s = (int)(e0 % S);
         for (int k = 0; k < 4; ++k) {
             const u32 c = H[e0 + k];
-            out[e0 + k] = c ? T[(long)c * S + s] : (OT)0;
+            out[e0 + k] = c - 1u < cmax ? T[(long)c * S + s] : (OT)0;
             s = s + 1 == S ? 0 : s + 1;
         }
     }
     if (blockIdx.x == 0 && threadIdx.x < (total & 3)) {
         const long e = (nquads << 2) + threadIdx.x;
         const u32 c = H[e];
-        out[e] = c ? T[(long)c * S + (int)(e % S)] : (OT)0;
+        out[e] = c - 1u < cmax ? T[(long)c * S + (int)(e % S)] : (OT)0;
     }
 }
 

@@ -389,14 +389,20 @@ def _ptr_array(ts):
     return (C.c_void_p * len(ts))(*[t.data_ptr() if t is not None and t.numel() else None for t in ts])
 
 
-def hist_rows_alloc(rows, S, device):
-    """One allocation for the [R_p, S] uint16 histograms of several parts; -> list of views.  Every part starts 16-byte
-    aligned (its first row at a multiple of 8 rows: 8 rows of any S are a multiple of 16 bytes)."""
+def hist_rows_flat(rows, S, device, dtype=torch.int16):
+    """One allocation for the [R_p, S] rows of several parts: -> (flat [R_total_padded, S], starts).  Every part starts 16-byte
+    aligned (its first row at a multiple of 8 rows: 8 rows of any S are a multiple of 16 bytes); the <= 7 rows between two parts
+    are never written by the count pass (the score pass looks nothing up for them: k_score_s1_from_hist)."""
     starts, at = [], 0
     for r in rows:
         starts.append(at)
         at += (r + 7) // 8 * 8
-    flat = torch.empty((max(at, 1), S), dtype=torch.int16, device=device)
+    return torch.empty((max(at, 1), S), dtype=dtype, device=device), starts
+
+
+def hist_rows_alloc(rows, S, device):
+    """hist_rows_flat as a list of views, one per part."""
+    flat, starts = hist_rows_flat(rows, S, device)
     return [flat[a:a + r] for a, r in zip(starts, rows)]
 
 

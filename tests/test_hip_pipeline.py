@@ -89,6 +89,48 @@ def test_cli_single_s1_on_input_only_pandas_reads(tmp_path, golden_real, capsys)
     assert (out / "regionsOfInterest_in10_s1.txt").read_text() == (out2 / "regionsOfInterest_in10_s1.txt").read_text()
 
 
+def test_single_session_counts_and_scores_parts_in_batches(monkeypatch):
+    """S1 parts of less than a GiB are counted in ONE launch per batch (epg_bin_hist_parts, histograms in one flat allocation with
+    unwritten rows between the parts) and scored in ONE launch per batch: the same counts, exp_freq and float32 scores, bit for bit,
+    as a launch per part (EPILOGOS_SINGLE_BATCH=0) and as the oracle -- with row counts that are no multiple of eight, an empty
+    part, a one-row part, parts asked for out of order, a part sliced and one dropped before the batch was counted, and a batch
+    that is only partly scored early."""
+    from epilogos_amd import backend
+    from oracle import oracle_np as onp
+    from tests.conftest import synth_states
+    N = 70
+    rows = [1001, 0, 1, 4096, 777, 13]
+    xs = [synth_states(r, N, seed=40 + k) for k, r in enumerate(rows)]
+    allx = np.concatenate([x for x in xs if len(x)])
+    q_ref = onp.normalise(onp.expected_s1(allx, S))
+    want = [onp.score_s1(x, q_ref, S).astype(np.float32) if len(x) else np.zeros((0, S), np.float32) for x in xs]
+    be = backend.HipBackend()
+
+    def job(batch, early):
+        monkeypatch.setenv("EPILOGOS_SINGLE_BATCH", "1" if batch else "0")
+        sess = be.open_single(S, 1)
+        pids = [sess.add_device(be.to_device(x) if len(x) else torch.empty((0, 80), dtype=torch.int8, device="cuda"), N if len(x) else 0) for x in xs]
+        if batch:
+            assert sum(p is backend._PENDING for p in sess.parts) == 5 and sess._pending_rows == sum(rows)
+        extra = sess.slice_part(pids[3], 100, 1100)                       # (forces the count pass of the pending batch)
+        assert not sess._pending and all(p is not backend._PENDING for p in sess.parts)
+        sess.ensure_acc(N)
+        total = sum(rows)
+        sess.launch(total, N, [pids[k] for k in early] + [extra])
+        q = sess.finish(total, N)
+        out = {k: sess.scores(pids[k]) for k in (5, 0, 4, 3, 2, 1)}      # out of order; some were scored by launch(), some are now
+        return q, out, sess.scores(extra)
+
+    for early in ([0, 1, 2, 3, 4, 5], [0, 2], []):
+        qa, a, ea = job(True, early)
+        qb, b, eb = job(False, early)
+        assert np.array_equal(qa, q_ref) and np.array_equal(qb, q_ref)
+        for k in range(len(rows)):
+            assert a[k].shape == (rows[k], S) and np.array_equal(a[k], b[k]), (k, early)
+            np.testing.assert_allclose(a[k], want[k], rtol=2e-7, atol=0)
+        assert np.array_equal(ea, a[3][100:1100]) and np.array_equal(eb, ea)
+
+
 @pytest.mark.parametrize("sal", [1, 2])
 def test_stage_drivers_hip(tmp_path, golden_real, sal):
     from epilogos_amd import expected, expectedCombination, scores
