@@ -926,8 +926,9 @@ def main():
             del Xshard
         last.clear()
         # the genome the way the COMMAND LINE holds it: 24 chromosome-sized parts (hg19's proportions), each a matrix of its own
-        # (one upload per file), counted and scored part by part through the same session calls -- 24 count launches, one combine,
-        # 24 score launches; every part is under a GiB, so its histogram cache is a plain allocation
+        # (one upload per file), through the same session calls.  Parts under a GiB are counted and scored in BATCHES (8 M rows or
+        # 32 parts per launch; histogram caches from one plain allocation per batch): two count launches, one combine, two score
+        # launches per genome (round 6; a launch pair per part before: 3.42 ms)
         try:
             pieces = [X[a - bin0:b - bin0].clone() for _f, _r0, a, b in chromosome_parts(R_global, bin0, bin0 + R)]
             torch.cuda.synchronize()
@@ -951,8 +952,8 @@ def main():
             last["sess"].finish(R_global, N)
             s1_paths["genome_as_%d_chromosome_parts" % len(pieces)] = {
                 "ms_per_step": round(tp * 1e3, 4), "value": round(R / tp / 1e6, 3), "unit": "Mbins/s", "steps": k,
-                "what": "the same S1 job with the genome held as the command line holds it: one resident matrix per chromosome file, "
-                        "%d count launches + combine + %d score launches, plain histogram caches (every part < 1 GiB)" % (len(pieces), len(pieces))}
+                "what": "the same S1 job with the genome held as the command line holds it: one resident matrix per chromosome file (%d), "
+                        "counted and scored in batches of parts (one launch per 8 M rows / 32 parts), plain histogram caches" % len(pieces)}
             del pieces
             last.clear()
         except Exception as e:                                              # an extra: never let it take the measurement down
@@ -1021,7 +1022,8 @@ def main():
                                      "(its add_part is an upload followed by this same add_device(X, N), same default: engine.alloc_hist places the "
                                      "histogram cache of a resident matrix of >= 1 GiB, smaller ones get a plain allocation).  Here the genome is ONE "
                                      "resident 12.7 GB matrix, so its cache is placed; the command line holds it as one part per chromosome file "
-                                     "(< 1 GiB each at 833 columns), i.e. plain allocations: `placement.unplaced` is the step with those.  The session's "
+                                     "(< 1 GiB each at 833 columns), i.e. plain allocations: `placement.unplaced` is the step with those and "
+                                     "`s1_paths.genome_as_24_chromosome_parts` the job fed as those 24 parts.  The session's "
                                      "finish() (count check, table verification, exp_freq download: a host sync) runs once after the timed steps -- "
                                      "s1_paths.session_with_finish_ms_per_step has it inside every job") if use_session else "engine",
                        "partition": "contiguous bin ranges per GPU (helpers.splitRows rule), one RCCL all-reduce of int64[%d]" % S},
